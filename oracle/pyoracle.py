@@ -1,0 +1,550 @@
+"""Pure-Python big-int oracle for the OpenZL arkworks MSM / NTT / Groth16 hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``openzl_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.
+
+Parity status: **unpinned at the MSM/NTT/Groth16 boundary** (the reference holds no golden
+vector for those) and **pinned for BLS12-381 Fr arithmetic** against the
+reference's own fixtures (tests/golden/ref_poseidon_fixtures.json, extracted from
+/root/reference/plugins/arkworks/src/poseidon/{mds_hardcoded_tests,parameters_hardcoded_test,
+permutation_hardcoded_test}).  MSM / NTT results are additionally pinned by mathematical
+uniqueness: this file computes them from the *definitions* (sum of scalar multiples, DFT sum),
+not from the fast algorithms, so that the C restatement (oracle/zl_oracle.c) and the HIP path
+can both be checked against something independent of Pippenger / Cooley-Tukey.
+
+The algorithms restated here live in third-party crates that are NOT vendored under
+/root/reference (plugins/arkworks/Cargo.toml:113-146): ark-ec 0.3.0 (VariableBaseMSM),
+ark-poly 0.3.0 (Radix2EvaluationDomain), ark-ff 0.3.0 (Fp256/Fp384 Montgomery),
+ark-groth16 0.3.0 (R1CStoQAP::witness_map, create_proof_with_assignment).  The reference
+call sites are plugins/arkworks/src/groth16.rs:438 (setup) and :454 (prove).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+# --------------------------------------------------------------------------------------------
+# Field / curve parameters (re-verified by tests/test_oracle_py.py)
+# --------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class FieldParams:
+    name: str
+    p: int
+    limbs64: int  # number of 64-bit limbs (ark-ff Fp256 -> 4, Fp384 -> 6)
+
+    @property
+    def R(self) -> int:  # Montgomery radix (ark-ff: 2^(64*limbs))
+        return 1 << (64 * self.limbs64)
+
+    @property
+    def bits(self) -> int:
+        return self.p.bit_length()
+
+    def to_mont(self, x: int) -> int:
+        return (x * self.R) % self.p
+
+    def from_mont(self, x: int) -> int:
+        return (x * pow(self.R, -1, self.p)) % self.p
+
+    @property
+    def inv64(self) -> int:  # -p^{-1} mod 2^64
+        return (-pow(self.p, -1, 1 << 64)) % (1 << 64)
+
+    @property
+    def inv32(self) -> int:
+        return (-pow(self.p, -1, 1 << 32)) % (1 << 32)
+
+
+BLS12_381_FQ = FieldParams(
+    "bls12_381_fq",
+    0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    6,
+)
+BLS12_381_FR = FieldParams(
+    "bls12_381_fr",
+    0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    4,
+)
+BN254_FQ = FieldParams(
+    "bn254_fq",
+    0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47,
+    4,
+)
+BN254_FR = FieldParams(
+    "bn254_fr",
+    0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001,
+    4,
+)
+
+
+@dataclass(frozen=True)
+class CurveParams:
+    name: str
+    cid: int  # zl_curve_t value (include/zl_backend.h)
+    fq: FieldParams
+    fr: FieldParams
+    b: int  # y^2 = x^3 + b
+    gx: int
+    gy: int
+    fr_generator: int  # multiplicative generator of Fr (ark: GENERATOR)
+    two_adicity: int
+    # G2: y^2 = x^3 + b2 over Fq2 = Fq[u]/(u^2+1)
+    b2: Tuple[int, int] = (0, 0)
+    g2x: Tuple[int, int] = (0, 0)
+    g2y: Tuple[int, int] = (0, 0)
+
+    @property
+    def two_adic_root(self) -> int:  # ark: TWO_ADIC_ROOT_OF_UNITY = g^((r-1)/2^s)
+        r = self.fr.p
+        return pow(self.fr_generator, (r - 1) >> self.two_adicity, r)
+
+
+BLS12_381 = CurveParams(
+    "bls12_381",
+    1,
+    BLS12_381_FQ,
+    BLS12_381_FR,
+    4,
+    0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+    0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1,
+    7,
+    32,
+    b2=(4, 4),
+    g2x=(
+        0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+        0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,
+    ),
+    g2y=(
+        0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+        0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
+    ),
+)
+BN254 = CurveParams(
+    "bn254",
+    2,
+    BN254_FQ,
+    BN254_FR,
+    3,
+    1,
+    2,
+    5,
+    28,
+    b2=(
+        19485874751759354771024239261021720505790618469301721065564631296452457478373,
+        266929791119991161246907387137283842545076965332900288569378510910307636690,
+    ),
+    g2x=(
+        10857046999023057135944570762232829481370756359578518086990519993285655852781,
+        11559732032986387107991004021392285783925812861821192530917403151452391805634,
+    ),
+    g2y=(
+        8495653923123431417604973247489272438418190587263600148770280649306958101930,
+        4082367875863433681332203403145435568316851327593401208105741076214120093531,
+    ),
+)
+
+CURVES = {"bls12_381": BLS12_381, "bn254": BN254}
+
+# --------------------------------------------------------------------------------------------
+# G1 affine arithmetic straight from the group law (None = point at infinity)
+# --------------------------------------------------------------------------------------------
+
+Point = Optional[Tuple[int, int]]
+
+
+def g1_is_on_curve(c: CurveParams, P: Point) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    p = c.fq.p
+    return (y * y - x * x * x - c.b) % p == 0
+
+
+def g1_neg(c: CurveParams, P: Point) -> Point:
+    if P is None:
+        return None
+    return (P[0], (-P[1]) % c.fq.p)
+
+
+def g1_add(c: CurveParams, P: Point, Q: Point) -> Point:
+    p = c.fq.p
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return None
+        lam = (3 * x1 * x1) * pow(2 * y1, -1, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    y3 = (lam * (x1 - x3) - y1) % p
+    return (x3, y3)
+
+
+def g1_mul(c: CurveParams, k: int, P: Point) -> Point:
+    """Double-and-add (definition of scalar multiplication)."""
+    k %= c.fr.p
+    acc: Point = None
+    add = P
+    while k:
+        if k & 1:
+            acc = g1_add(c, acc, add)
+        add = g1_add(c, add, add)
+        k >>= 1
+    return acc
+
+
+def g1_generator(c: CurveParams) -> Point:
+    return (c.gx, c.gy)
+
+
+def msm_naive(c: CurveParams, scalars: Sequence[int], points: Sequence[Point]) -> Point:
+    """sum_i scalars[i] * points[i] by the definition; the uniqueness anchor for every MSM."""
+    acc: Point = None
+    for s, P in zip(scalars, points):
+        acc = g1_add(c, acc, g1_mul(c, s, P))
+    return acc
+
+
+def ark_window_bits(n: int) -> int:
+    """ark-ec 0.3.0 VariableBaseMSM: c = 3 if n < 32 else ln_without_floats(n) + 2 where
+    ln_without_floats(a) = log2(a) * 69 / 100 with ark_std::log2 = ceil(log2)."""
+    if n < 32:
+        return 3
+    ceil_log2 = (n - 1).bit_length()
+    return ceil_log2 * 69 // 100 + 2
+
+
+def msm_pippenger_ark(c: CurveParams, scalars: Sequence[int], points: Sequence[Point]) -> Point:
+    """Restatement of ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul on affine
+    big-int points; used on small inputs to check that the arkworks schedule (unsigned windows,
+    zero skip, unit-scalar shortcut, running-sum reduce, Horner combine) equals msm_naive."""
+    n = min(len(scalars), len(points))
+    cbits = ark_window_bits(n)
+    num_bits = c.fr.bits
+    window_sums: List[Point] = []
+    for w_start in range(0, num_bits, cbits):
+        res: Point = None
+        buckets: List[Point] = [None] * ((1 << cbits) - 1)
+        for s, P in zip(scalars[:n], points[:n]):
+            if s == 0:
+                continue
+            if s == 1:
+                if w_start == 0:
+                    res = g1_add(c, res, P)
+                continue
+            d = (s >> w_start) & ((1 << cbits) - 1)
+            if d != 0:
+                buckets[d - 1] = g1_add(c, buckets[d - 1], P)
+        run: Point = None
+        for b in reversed(buckets):
+            run = g1_add(c, run, b)
+            res = g1_add(c, res, run)
+        window_sums.append(res)
+    lowest = window_sums[0]
+    total: Point = None
+    for ws in reversed(window_sums[1:]):
+        total = g1_add(c, total, ws)
+        for _ in range(cbits):
+            total = g1_add(c, total, total)
+    return g1_add(c, lowest, total)
+
+
+# --------------------------------------------------------------------------------------------
+# Fq2 / G2 (row f1) -- Fq2 = Fq[u]/(u^2+1)
+# --------------------------------------------------------------------------------------------
+
+F2 = Tuple[int, int]
+Point2 = Optional[Tuple[F2, F2]]
+
+
+def f2_add(p: int, a: F2, b: F2) -> F2:
+    return ((a[0] + b[0]) % p, (a[1] + b[1]) % p)
+
+
+def f2_sub(p: int, a: F2, b: F2) -> F2:
+    return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
+
+
+def f2_mul(p: int, a: F2, b: F2) -> F2:
+    return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+
+
+def f2_inv(p: int, a: F2) -> F2:
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, p)
+    return (a[0] * n % p, (-a[1]) * n % p)
+
+
+def g2_is_on_curve(c: CurveParams, P: Point2) -> bool:
+    if P is None:
+        return True
+    p = c.fq.p
+    x, y = P
+    lhs = f2_mul(p, y, y)
+    rhs = f2_add(p, f2_mul(p, f2_mul(p, x, x), x), c.b2)
+    return lhs == rhs
+
+
+def g2_add(c: CurveParams, P: Point2, Q: Point2) -> Point2:
+    p = c.fq.p
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if f2_add(p, y1, y2) == (0, 0):
+            return None
+        xx = f2_mul(p, x1, x1)
+        num = f2_add(p, f2_add(p, xx, xx), xx)
+        lam = f2_mul(p, num, f2_inv(p, f2_add(p, y1, y1)))
+    else:
+        lam = f2_mul(p, f2_sub(p, y2, y1), f2_inv(p, f2_sub(p, x2, x1)))
+    x3 = f2_sub(p, f2_sub(p, f2_mul(p, lam, lam), x1), x2)
+    y3 = f2_sub(p, f2_mul(p, lam, f2_sub(p, x1, x3)), y1)
+    return (x3, y3)
+
+
+def g2_mul(c: CurveParams, k: int, P: Point2) -> Point2:
+    k %= c.fr.p
+    acc: Point2 = None
+    add = P
+    while k:
+        if k & 1:
+            acc = g2_add(c, acc, add)
+        add = g2_add(c, add, add)
+        k >>= 1
+    return acc
+
+
+def g2_generator(c: CurveParams) -> Point2:
+    return (c.g2x, c.g2y)
+
+
+def msm_g2_naive(c: CurveParams, scalars: Sequence[int], points: Sequence[Point2]) -> Point2:
+    acc: Point2 = None
+    for s, P in zip(scalars, points):
+        acc = g2_add(c, acc, g2_mul(c, s, P))
+    return acc
+
+
+# --------------------------------------------------------------------------------------------
+# NTT over Fr -- ark-poly 0.3.0 Radix2EvaluationDomain semantics (natural order in and out)
+# --------------------------------------------------------------------------------------------
+
+
+def domain_root(c: CurveParams, log_n: int) -> int:
+    """group_gen = TWO_ADIC_ROOT_OF_UNITY ^ (2^(TWO_ADICITY - log_n))."""
+    assert 0 <= log_n <= c.two_adicity
+    return pow(c.two_adic_root, 1 << (c.two_adicity - log_n), c.fr.p)
+
+
+def dft_naive(c: CurveParams, x: Sequence[int], inverse: bool = False, coset: bool = False) -> List[int]:
+    """X_k = sum_j x_j w^{jk} by the definition (O(n^2)); inverse multiplies by n^{-1} and uses
+    w^{-1}; coset variants pre-multiply x_j by g^j (forward) / post-multiply by g^{-j} (inverse)."""
+    r = c.fr.p
+    n = len(x)
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    w = domain_root(c, log_n)
+    g = c.fr_generator
+    x = [v % r for v in x]
+    if inverse:
+        w = pow(w, -1, r)
+    elif coset:
+        x = [v * pow(g, j, r) % r for j, v in enumerate(x)]
+    out = []
+    for k in range(n):
+        wk = pow(w, k, r)
+        acc = 0
+        wjk = 1
+        for j in range(n):
+            acc = (acc + x[j] * wjk) % r
+            wjk = wjk * wk % r
+        out.append(acc)
+    if inverse:
+        ninv = pow(n, -1, r)
+        out = [v * ninv % r for v in out]
+        if coset:
+            ginv = pow(g, -1, r)
+            out = [v * pow(ginv, j, r) % r for j, v in enumerate(out)]
+    return out
+
+
+def ntt(c: CurveParams, x: Sequence[int], inverse: bool = False, coset: bool = False) -> List[int]:
+    """Iterative radix-2 NTT with the same semantics as dft_naive (fast path for tests)."""
+    r = c.fr.p
+    n = len(x)
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    w = domain_root(c, log_n)
+    g = c.fr_generator
+    a = [v % r for v in x]
+    if inverse:
+        w = pow(w, -1, r)
+    elif coset:
+        gp = 1
+        for j in range(n):
+            a[j] = a[j] * gp % r
+            gp = gp * g % r
+    # bit reversal then DIT
+    j = 0
+    for i in range(1, n):
+        bit = n >> 1
+        while j & bit:
+            j ^= bit
+            bit >>= 1
+        j ^= bit
+        if i < j:
+            a[i], a[j] = a[j], a[i]
+    length = 2
+    while length <= n:
+        wl = pow(w, n // length, r)
+        for i in range(0, n, length):
+            wj = 1
+            for k in range(length // 2):
+                u = a[i + k]
+                v = a[i + k + length // 2] * wj % r
+                a[i + k] = (u + v) % r
+                a[i + k + length // 2] = (u - v) % r
+                wj = wj * wl % r
+        length <<= 1
+    if inverse:
+        ninv = pow(n, -1, r)
+        a = [v * ninv % r for v in a]
+        if coset:
+            ginv = pow(g, -1, r)
+            gp = 1
+            for j in range(n):
+                a[j] = a[j] * gp % r
+                gp = gp * ginv % r
+    return a
+
+
+# --------------------------------------------------------------------------------------------
+# Poseidon over Fr (config 5; pinned by the reference's fixtures)
+# --------------------------------------------------------------------------------------------
+
+
+class GrainLFSR:
+    """Restates openzl-crypto/src/poseidon/lfsr.rs:14-100 (80-bit Grain LFSR, GKRRS19 App. A)."""
+
+    SIZE = 80
+
+    def __init__(self, seed: Sequence[Tuple[int, int]]):
+        self.state = [False] * self.SIZE
+        self.head = 0
+        for n, bits in seed:  # append_seed_bits, lfsr.rs:44-50 (MSB first)
+            for i in reversed(range(n)):
+                self._set_next(bool((bits >> i) & 1))
+        for _ in range(self.SIZE * 2):  # skip_updates(160), lfsr.rs:40
+            self._update()
+
+    def _set_next(self, b: bool) -> bool:
+        self.state[self.head] = b
+        self.head = (self.head + 1) % self.SIZE
+        return b
+
+    def _bit(self, i: int) -> bool:
+        return self.state[(i + self.head) % self.SIZE]
+
+    def _update(self) -> bool:  # lfsr.rs:76-80
+        return self._set_next(
+            self._bit(62) ^ self._bit(51) ^ self._bit(38) ^ self._bit(23) ^ self._bit(13) ^ self._bit(0)
+        )
+
+    def next_bit(self) -> bool:  # Iterator::next, lfsr.rs:86-93 (self-shrinking)
+        bit = self._update()
+        while not bit:
+            self._update()
+            bit = self._update()
+        return self._update()
+
+
+def poseidon_round_constants(field: FieldParams, width: int, rf: int, rp: int) -> List[int]:
+    """openzl-crypto/src/poseidon/round_constants.rs:10-59: MODULUS_BITS bits big-endian per
+    candidate, rejection if >= modulus."""
+    lfsr = GrainLFSR(
+        [(2, 1), (4, 0), (12, field.bits), (12, width), (10, rf), (10, rp), (30, (1 << 30) - 1)]
+    )
+    out = []
+    while len(out) < width * (rf + rp):
+        v = 0
+        for _ in range(field.bits):
+            v = (v << 1) | int(lfsr.next_bit())
+        if v < field.p:
+            out.append(v)
+    return out
+
+
+def poseidon_mds(field: FieldParams, t: int) -> List[List[int]]:
+    """openzl-crypto/src/poseidon/mds.rs:84-102: M[i][j] = (i + (t + j))^{-1}."""
+    return [[pow(i + t + j, -1, field.p) for j in range(t)] for i in range(t)]
+
+
+def poseidon_permute(field: FieldParams, state: Sequence[int], rf: int = 8, rp: int = 55) -> List[int]:
+    """openzl-tutorials/src/poseidon.rs:165-222: every round = add keys -> S-box (x^5; all lanes
+    in full rounds, lane 0 in partial rounds) -> MDS multiply."""
+    p = field.p
+    t = len(state)
+    keys = poseidon_round_constants(field, t, rf, rp)
+    mds = poseidon_mds(field, t)
+    s = [v % p for v in state]
+    half = rf // 2
+    for rnd in range(rf + rp):
+        k = keys[rnd * t:(rnd + 1) * t]
+        s = [(v + kk) % p for v, kk in zip(s, k)]
+        if rnd < half or rnd >= half + rp:
+            s = [pow(v, 5, p) for v in s]
+        else:
+            s[0] = pow(s[0], 5, p)
+        s = [sum(mds[i][j] * s[j] for j in range(t)) % p for i in range(t)]
+    return s
+
+
+# --------------------------------------------------------------------------------------------
+# Deterministic inputs shared by tests / bench (SplitMix64)
+# --------------------------------------------------------------------------------------------
+
+MASK64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & MASK64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+
+def sample_fr(field: FieldParams, rng: SplitMix64) -> int:
+    """4 x u64 little-endian, masked to MODULUS_BITS, rejection until < modulus."""
+    while True:
+        v = 0
+        for i in range(field.limbs64):
+            v |= rng.next() << (64 * i)
+        v &= (1 << field.bits) - 1
+        if v < field.p:
+            return v
+
+
+def to_limbs(x: int, nlimbs64: int) -> List[int]:
+    return [(x >> (64 * i)) & MASK64 for i in range(nlimbs64)]
+
+
+def from_limbs(limbs: Sequence[int]) -> int:
+    v = 0
+    for i, l in enumerate(limbs):
+        v |= int(l) << (64 * i)
+    return v
