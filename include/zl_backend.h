@@ -1,0 +1,112 @@
+/* zl_backend.h -- C ABI of libzl_backend.so: the MI355X (gfx950) MSM / NTT backend for OpenZL's arkworks
+ * Groth16 plugin path.
+ *
+ * The reference defines a Rust trait, not an FFI (openzl_crypto::constraint::ProofSystem,
+ * /root/reference/openzl-crypto/src/constraint.rs:31-87, implemented for Groth16<E> at
+ * /root/reference/plugins/arkworks/src/groth16.rs:405-467).  One level below `Groth16::prove`
+ * (groth16.rs:445-457) the work is done by two upstream entry points that the plugin re-exports
+ * (`pub use ec;` lib.rs:28-29, `pub use poly;` lib.rs:70-71, `pub use ff::*;` ff.rs:6):
+ *     ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) -> Projective      -> zl_msm_g1 / zl_msm_g2
+ *     ark_poly::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place(&mut Vec<F>)    -> zl_ntt
+ * and the whole prover call                                                               -> zl_groth16_prove
+ * These are the symbols a Rust shim (`extern "C"` block) binds.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - return 0 (ZL_OK) on success, a negative ZL_E* code otherwise; nothing throws or aborts across the ABI;
+ *   - the caller owns every host buffer; device-resident base tables are owned by the ctx and named by handle
+ *     (a proving key is static per circuit: upload once, prove many times);
+ *   - a ctx is bound to one GPU and one HIP stream and is used from one thread at a time; ctxs are independent;
+ *   - field elements are little-endian arrays of u64 limbs, 4 per Fr / BN254 Fq element, 6 per BLS12-381 Fq
+ *     element.  ZL_MONT = limbs are arkworks' in-memory Montgomery form (value*2^(64*limbs) mod p), i.e. what
+ *     `Fp256/Fp384.0.0` holds; ZL_CANON(0) = canonical integers (what `into_repr()` yields);
+ *   - an affine point is x||y (G1) or x.c0||x.c1||y.c0||y.c1 (G2); the all-zero encoding is the point at
+ *     infinity ((0,0) is on neither curve), or, with a stride, arkworks' `infinity: bool` byte may be passed;
+ *   - results are canonical affine coordinates + an is_infinity byte: unique, hence bit-comparable with the
+ *     reference path (`into_affine()` then `into_repr()`).
+ */
+#ifndef ZL_BACKEND_H
+#define ZL_BACKEND_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { ZL_BLS12_381 = 1, ZL_BN254 = 2 } zl_curve_t;
+typedef enum { ZL_G1 = 1, ZL_G2 = 2 } zl_group_t;
+typedef struct zl_ctx zl_ctx;
+
+enum {
+    ZL_OK = 0,
+    ZL_EINVAL = -1,   /* bad argument (null pointer, unknown curve, n too large, log_n > two-adicity, ...) */
+    ZL_ENOMEM = -2,   /* host or device allocation failed */
+    ZL_EHIP = -3,     /* a HIP runtime call or kernel failed (zl_ctx_last_hip_error has the code) */
+    ZL_ENODEV = -4,   /* no usable gfx950 device */
+    ZL_EHANDLE = -5,  /* unknown / freed bases handle, or handle of the wrong curve/group */
+    ZL_ENOTCURVE = -6 /* ZL_CHECK was set and a base point is not on the curve */
+};
+
+/* flags */
+#define ZL_CANON 0u
+#define ZL_MONT 1u    /* inputs (and NTT outputs) are Montgomery limbs */
+#define ZL_COSET 2u   /* NTT: coset variant (g = Fr multiplicative generator: 7 BLS12-381, 5 BN254) */
+#define ZL_INVERSE 4u /* NTT: inverse transform (scaled by n^-1) */
+#define ZL_CHECK 8u   /* bases upload: verify y^2 = x^3 + b on the device */
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int zl_ctx_create(zl_ctx** out, int device_id);
+void zl_ctx_destroy(zl_ctx* ctx);
+/* run all work of this ctx on the caller's HIP stream (e.g. torch's current stream); NULL = the ctx's own */
+int zl_ctx_set_stream(zl_ctx* ctx, void* hip_stream);
+int zl_ctx_sync(zl_ctx* ctx);
+/* Pippenger window width c (bits); 0 = choose from n.  Results do not depend on it. */
+int zl_ctx_set_msm_window(zl_ctx* ctx, int c);
+int zl_ctx_last_hip_error(const zl_ctx* ctx);
+const char* zl_strerror(int code);
+/* library / device description: writes a NUL-terminated string, returns its length */
+int zl_describe(zl_ctx* ctx, char* buf, size_t buflen);
+
+/* ---- device-resident MSM bases (replaces the `bases: &[G::Affine]` argument of multi_scalar_mul) ------- */
+/* xy: n points at `stride_bytes` intervals (0 = packed).  inf_offset >= 0: byte offset inside each record of
+ * an arkworks-style `infinity: bool`; -1: infinity is the all-zero encoding. */
+int zl_bases_upload(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const void* xy, size_t n, size_t stride_bytes,
+                    long inf_offset, unsigned flags, uint64_t* handle_out);
+/* bases[i] = k[i] * generator, computed on the device (k: n x 4 u64 canonical, host memory).  Input generator
+ * for tests and benches: gives MSM inputs with known discrete logs. */
+int zl_bases_generate(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const uint64_t* k, size_t n, uint64_t* handle_out);
+/* copy bases back as canonical affine x||y (tests) */
+int zl_bases_download(zl_ctx* ctx, uint64_t handle, size_t first, size_t count, uint64_t* out_xy);
+int zl_bases_free(zl_ctx* ctx, uint64_t handle);
+
+/* ---- MSM (replaces VariableBaseMSM::multi_scalar_mul) --------------------------------------------------- */
+/* scalars: n x 4 u64 canonical (< r), host memory; uses bases [first, first+n) of the handle.
+ * out_xy: canonical affine coordinates (2 or 4 field elements); *out_inf = 1 if the sum is infinity. */
+int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* same, scalars already resident in device memory (HBM) */
+int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* multi-GPU building block: the un-normalised partial sum of this shard (opaque, ZL_PARTIAL_WORDS u64s), to
+ * be all-gathered (RCCL/ncclUint64) and folded with zl_partials_sum on any rank. */
+#define ZL_PARTIAL_WORDS 48
+int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial);
+int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- NTT (replaces Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place) -------------------- */
+/* data: 2^log_n Fr elements x 4 u64, in place, natural order in and out; flags: ZL_MONT, ZL_COSET, ZL_INVERSE */
+int zl_ntt(zl_ctx* ctx, zl_curve_t curve, uint64_t* data, unsigned log_n, unsigned flags);
+int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags);
+
+/* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
+typedef struct zl_timing {
+    float total_ms;      /* first kernel start -> last kernel end of the last zl_msm* / zl_ntt* call */
+    float dominant_ms;   /* the dominant kernel: bucket accumulation (MSM) / all butterfly passes (NTT) */
+    uint32_t launches;   /* launches of the dominant kernel in that call */
+    uint32_t window_bits;
+    uint64_t entries;    /* MSM: (point, window) pairs accumulated */
+} zl_timing;
+int zl_ctx_enable_timing(zl_ctx* ctx, int on);
+int zl_last_timing(zl_ctx* ctx, zl_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

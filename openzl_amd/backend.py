@@ -1,0 +1,206 @@
+"""ctypes binding of include/zl_backend.h.  No compute happens in Python and there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzl_backend.so")
+
+ZL_BLS12_381, ZL_BN254 = 1, 2
+ZL_G1, ZL_G2 = 1, 2
+ZL_MONT, ZL_COSET, ZL_INVERSE, ZL_CHECK = 1, 2, 4, 8
+ZL_PARTIAL_WORDS = 48
+CURVES = {"bls12_381": ZL_BLS12_381, "bn254": ZL_BN254}
+FQ_LIMBS = {ZL_BLS12_381: 6, ZL_BN254: 4}
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/zl_backend.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
+    "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_free", "zl_msm",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing",
+]
+
+
+class BackendError(RuntimeError):
+    def __init__(self, code: int, what: str, msg: str = ""):
+        super().__init__(f"{what} failed: {code} ({msg})")
+        self.code = code
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("dominant_ms", C.c_float), ("launches", C.c_uint32), ("window_bits", C.c_uint32),
+                ("entries", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libzl_backend.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.zl_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.zl_ctx_destroy.argtypes = [vp]
+    L.zl_ctx_destroy.restype = None
+    L.zl_ctx_set_stream.argtypes = [vp, vp]
+    L.zl_ctx_sync.argtypes = [vp]
+    L.zl_ctx_set_msm_window.argtypes = [vp, C.c_int]
+    L.zl_ctx_last_hip_error.argtypes = [vp]
+    L.zl_strerror.argtypes = [C.c_int]
+    L.zl_strerror.restype = C.c_char_p
+    L.zl_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.zl_bases_upload.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_long, C.c_uint, u64p]
+    L.zl_bases_generate.argtypes = [vp, C.c_int, C.c_int, u64p, C.c_size_t, u64p]
+    L.zl_bases_download.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t, u64p]
+    L.zl_bases_free.argtypes = [vp, C.c_uint64]
+    L.zl_msm.argtypes = [vp, C.c_uint64, C.c_size_t, u64p, C.c_size_t, u64p, u8p]
+    L.zl_msm_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p, u8p]
+    L.zl_msm_partial_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p]
+    L.zl_partials_sum.argtypes = [C.c_int, C.c_int, u64p, C.c_size_t, u64p, u8p]
+    L.zl_ntt.argtypes = [vp, C.c_int, u64p, C.c_uint, C.c_uint]
+    L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
+    L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]
+    L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _p64(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need contiguous uint64"
+    return a.ctypes.data_as(u64p)
+
+
+class Backend:
+    """One zl_ctx (one GPU, one stream).  Mirrors the two upstream entry points the arkworks plugin surfaces:
+    VariableBaseMSM::multi_scalar_mul -> msm(); Radix2EvaluationDomain::{fft,ifft,coset_*} -> ntt()."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self._ctx = C.c_void_p()
+        self._check(self.L.zl_ctx_create(C.byref(self._ctx), device), "zl_ctx_create")
+        self._bases = {}
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise BackendError(rc, what, self.L.zl_strerror(rc).decode())
+
+    def close(self):
+        if self._ctx:
+            self.L.zl_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(512)
+        self.L.zl_describe(self._ctx, buf, 512)
+        return buf.value.decode()
+
+    def set_stream(self, stream_handle: int):
+        self._check(self.L.zl_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)), "zl_ctx_set_stream")
+
+    def set_msm_window(self, c: int):
+        self._check(self.L.zl_ctx_set_msm_window(self._ctx, c), "zl_ctx_set_msm_window")
+
+    def enable_timing(self, on: bool = True):
+        self._check(self.L.zl_ctx_enable_timing(self._ctx, int(on)), "zl_ctx_enable_timing")
+
+    def last_timing(self) -> Timing:
+        t = Timing()
+        self._check(self.L.zl_last_timing(self._ctx, C.byref(t)), "zl_last_timing")
+        return t
+
+    def sync(self):
+        self._check(self.L.zl_ctx_sync(self._ctx), "zl_ctx_sync")
+
+    # ---- bases ------------------------------------------------------------------------------------------------
+    def bases_upload(self, curve: int, xy: np.ndarray, group: int = ZL_G1, flags: int = 0, stride: int = 0, inf_offset: int = -1,
+                     n: Optional[int] = None) -> int:
+        h = C.c_uint64()
+        if n is None:
+            n = xy.shape[0]
+        ptr = xy.ctypes.data_as(C.c_void_p) if xy.size else None
+        self._check(self.L.zl_bases_upload(self._ctx, curve, group, ptr, n, stride, inf_offset, flags, C.byref(h)), "zl_bases_upload")
+        self._bases[h.value] = (curve, group, n)
+        return h.value
+
+    def bases_generate(self, curve: int, k: np.ndarray, group: int = ZL_G1) -> int:
+        h = C.c_uint64()
+        self._check(self.L.zl_bases_generate(self._ctx, curve, group, _p64(k), k.shape[0], C.byref(h)), "zl_bases_generate")
+        self._bases[h.value] = (curve, group, k.shape[0])
+        return h.value
+
+    def bases_download(self, handle: int, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        curve, group, n = self._bases[handle]
+        if count is None:
+            count = n - first
+        out = np.zeros((count, 2 * group * FQ_LIMBS[curve]), dtype=np.uint64)
+        self._check(self.L.zl_bases_download(self._ctx, handle, first, count, _p64(out)), "zl_bases_download")
+        return out
+
+    def bases_free(self, handle: int):
+        self._check(self.L.zl_bases_free(self._ctx, handle), "zl_bases_free")
+        self._bases.pop(handle, None)
+
+    # ---- MSM --------------------------------------------------------------------------------------------------
+    def _out(self, handle: int):
+        curve, group, _ = self._bases[handle]
+        return np.zeros(2 * group * FQ_LIMBS[curve], dtype=np.uint64)
+
+    def msm(self, handle: int, scalars: np.ndarray, first: int = 0) -> Tuple[np.ndarray, int]:
+        """scalars: (n,4) uint64 canonical, host memory."""
+        out, inf = self._out(handle), C.c_uint8(0)
+        n = scalars.shape[0]
+        self._check(self.L.zl_msm(self._ctx, handle, first, _p64(scalars) if n else None, n, _p64(out), C.byref(inf)), "zl_msm")
+        return out, inf.value
+
+    def msm_dev(self, handle: int, d_scalars: int, n: int, first: int = 0) -> Tuple[np.ndarray, int]:
+        """d_scalars: device pointer (e.g. torch tensor .data_ptr()) to n x 4 u64 canonical scalars in HBM."""
+        out, inf = self._out(handle), C.c_uint8(0)
+        self._check(self.L.zl_msm_dev(self._ctx, handle, first, C.c_void_p(d_scalars), n, _p64(out), C.byref(inf)), "zl_msm_dev")
+        return out, inf.value
+
+    def msm_partial_dev(self, handle: int, d_scalars: int, n: int, first: int = 0) -> np.ndarray:
+        out = np.zeros(ZL_PARTIAL_WORDS, dtype=np.uint64)
+        self._check(self.L.zl_msm_partial_dev(self._ctx, handle, first, C.c_void_p(d_scalars), n, _p64(out)), "zl_msm_partial_dev")
+        return out
+
+    def partials_sum(self, curve: int, partials: np.ndarray, group: int = ZL_G1) -> Tuple[np.ndarray, int]:
+        partials = np.ascontiguousarray(partials.reshape(-1, ZL_PARTIAL_WORDS))
+        out, inf = np.zeros(2 * group * FQ_LIMBS[curve], dtype=np.uint64), C.c_uint8(0)
+        self._check(self.L.zl_partials_sum(curve, group, _p64(partials), partials.shape[0], _p64(out), C.byref(inf)), "zl_partials_sum")
+        return out, inf.value
+
+    # ---- NTT --------------------------------------------------------------------------------------------------
+    def ntt(self, curve: int, data: np.ndarray, inverse: bool = False, coset: bool = False, mont: bool = False) -> np.ndarray:
+        """data: (2^k, 4) uint64, returns the transformed copy (natural order)."""
+        d = np.ascontiguousarray(data.copy())
+        n = d.shape[0]
+        log_n = n.bit_length() - 1
+        if n == 0 or (1 << log_n) != n:
+            raise BackendError(-1, "zl_ntt", "length must be a power of two")
+        flags = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0) | (ZL_MONT if mont else 0)
+        self._check(self.L.zl_ntt(self._ctx, curve, _p64(d), log_n, flags), "zl_ntt")
+        return d
+
+    def ntt_dev(self, curve: int, d_data: int, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = True):
+        flags = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0) | (ZL_MONT if mont else 0)
+        self._check(self.L.zl_ntt_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags), "zl_ntt_dev")

@@ -1,0 +1,80 @@
+"""Build libzl_backend.so (HIP, gfx950) in-tree with hipcc.  Incremental: objects are rebuilt only when a source or
+header they include changed.  Used by __graft_entry__.build(); `python -m openzl_amd.build` works too."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libzl_backend.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
+HEADERS = ["zl_field.h", "zl_curve.h", "zl_params.h", "zl_ctx.h", os.path.join("..", "..", "include", "zl_backend.h")]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest(paths, extra="") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _units():
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", []), ("zl_groth16", "zl_groth16.hip", [])]
+    for g in GROUPS:
+        units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"]))
+    return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
+
+
+def build(verbose: bool = True, jobs: int | None = None) -> str:
+    params = os.path.join(CSRC, "zl_params.h")
+    gen = os.path.join(CSRC, "gen_params.py")
+    if not os.path.exists(params) or os.path.getmtime(params) < os.path.getmtime(gen):
+        subprocess.check_call([sys.executable, gen])
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    todo, objs = [], []
+    for name, src, defs in _units():
+        obj = os.path.join(CSRC, name + ".o")
+        stamp = obj + ".sha"
+        d = _digest([os.path.join(CSRC, src)] + hdrs, " ".join(FLAGS + defs))
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == d:
+            continue
+        todo.append((name, src, defs, obj, stamp, d))
+
+    def compile_one(t):
+        name, src, defs, obj, stamp, d = t
+        cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(d)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, todo))
+    if todo or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build())

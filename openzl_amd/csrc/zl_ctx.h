@@ -1,0 +1,136 @@
+// zl_ctx.h -- internal context shared by the MSM / NTT translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <vector>
+#include "../../include/zl_backend.h"
+#include "zl_curve.h"
+
+#define ZL_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) {                             \
+            (ctx)->last_hip = (int)e_;                      \
+            return e_ == hipErrorOutOfMemory ? ZL_ENOMEM : ZL_EHIP; \
+        }                                                   \
+    } while (0)
+
+// ---- group configurations ---------------------------------------------------------------------------------
+struct BlsG1 {
+    using FqP = BLS12_381_Fq;
+    using FrP = BLS12_381_Fr;
+    using F = Fp<FqP>;
+    using C = BLS12_381_G1;
+    static constexpr int SC_BITS = 255;
+    static constexpr int FQ64 = 6;     // u64 limbs per Fq element
+    static constexpr int COORDS = 1;   // Fq elements per coordinate
+    ZL_HD static F gen_x() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gx(i); return r; }
+    ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
+    ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
+};
+struct BnG1 {
+    using FqP = BN254_Fq;
+    using FrP = BN254_Fr;
+    using F = Fp<FqP>;
+    using C = BN254_G1;
+    static constexpr int SC_BITS = 254;
+    static constexpr int FQ64 = 4;
+    static constexpr int COORDS = 1;
+    ZL_HD static F gen_x() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gx(i); return r; }
+    ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
+    ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
+};
+template <class C2, class FqP_, class FrP_, int SCB, int FQ64_>
+struct G2Cfg {
+    using FqP = FqP_;
+    using FrP = FrP_;
+    using F = Fp2<FqP>;
+    static constexpr int SC_BITS = SCB;
+    static constexpr int FQ64 = FQ64_;
+    static constexpr int COORDS = 2;
+    ZL_HD static F mk(uint32_t (*f0)(int), uint32_t (*f1)(int)) {
+        F r;
+        for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = f0(i); r.c1.l[i] = f1(i); }
+        return r;
+    }
+    ZL_HD static F gen_x() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::gx0(i); r.c1.l[i] = C2::gx1(i); } return r; }
+    ZL_HD static F gen_y() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::gy0(i); r.c1.l[i] = C2::gy1(i); } return r; }
+    ZL_HD static F coeff_b() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::b0(i); r.c1.l[i] = C2::b1(i); } return r; }
+};
+using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, 255, 6>;
+using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, 254, 4>;
+
+// ---- context ----------------------------------------------------------------------------------------------
+struct zl_bases {
+    void* d_pts = nullptr;  // Affine<F>[n], Montgomery
+    size_t n = 0;
+    int curve = 0, group = 0;
+};
+struct zl_scratch {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+struct zl_twiddles {
+    void* d_lo = nullptr;  // w^i, i < 2^lo_bits
+    void* d_hi = nullptr;  // w^(i << lo_bits)
+    void* d_small = nullptr;  // per-radix tables
+    unsigned lo_bits = 0;
+};
+struct zl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // created by the ctx
+    int last_hip = 0;
+    int msm_c = 0;
+    int timing_on = 0;
+    zl_timing timing{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::map<uint64_t, zl_bases> bases;
+    uint64_t next_handle = 1;
+    zl_scratch scratch[8];
+    std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
+    void* d_coset[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+// grow-only device scratch slot
+inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
+    zl_scratch& s = ctx->scratch[slot];
+    if (s.cap < bytes) {
+        if (s.p) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+            (void)hipFree(s.p);
+            s.p = nullptr;
+            s.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&s.p, want);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; s.p = nullptr; return ZL_ENOMEM; }
+        s.cap = want;
+    }
+    *out = s.p;
+    return ZL_OK;
+}
+
+// entry points implemented per translation unit; the MSM file is compiled once per group (suffix = group config)
+#define ZL_DECL_GROUP(G)                                                                                                   \
+    int zl_msm_run_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial); \
+    int zl_partial_to_affine_##G(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf);                              \
+    int zl_partials_fold_##G(const uint64_t* partials, size_t count, uint64_t* out_partial);                                \
+    int zl_bases_upload_##G(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out); \
+    int zl_bases_generate_##G(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out);                                     \
+    int zl_bases_download_##G(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy);
+ZL_DECL_GROUP(BlsG1)
+ZL_DECL_GROUP(BnG1)
+ZL_DECL_GROUP(BlsG2)
+ZL_DECL_GROUP(BnG2)
+// dispatch on (curve, group)
+#define ZL_DISPATCH(curve, group, fn, ...)                                                   \
+    (((curve) == ZL_BLS12_381 && (group) == ZL_G1)   ? fn##_BlsG1(__VA_ARGS__)               \
+     : ((curve) == ZL_BN254 && (group) == ZL_G1)     ? fn##_BnG1(__VA_ARGS__)                \
+     : ((curve) == ZL_BLS12_381 && (group) == ZL_G2) ? fn##_BlsG2(__VA_ARGS__)               \
+     : ((curve) == ZL_BN254 && (group) == ZL_G2)     ? fn##_BnG2(__VA_ARGS__)                \
+                                                     : (int)ZL_EINVAL)
+int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags);
+void zl_ntt_free(zl_ctx* ctx);

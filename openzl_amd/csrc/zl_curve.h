@@ -1,0 +1,165 @@
+// zl_curve.h -- short-Weierstrass (a = 0) group arithmetic in XYZZ coordinates, generic over the coordinate
+// field (Fp<Fq> for G1, Fp2<Fq> for G2).  Host + device.
+//
+// Replaces, for this backend, ark-ec 0.3.0 short_weierstrass_jacobian::{add_assign_mixed, add_assign,
+// double_in_place, into_affine} (surfaced by `pub use ec;`, /root/reference/plugins/arkworks/src/lib.rs:28-29;
+// SURVEY.md §2.1).  arkworks uses Jacobian (X,Y,Z); this backend uses XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2)
+// because the mixed addition is 8M+2S instead of 7M+4S with one temporary fewer in registers.  Only the final
+// *affine* point is ever compared with the reference path (unique, SURVEY.md §8 note N1).
+// Formulas: EFD "xyzz" madd-2008-s / add-2008-s / dbl-2008-s-1 / mdbl-2008-s-1.
+#pragma once
+#include "zl_field.h"
+
+// ---- Fq2 = Fq[u]/(u^2+1) (both curves), the G2 coordinate field -----------------------------------------
+template <class P>
+struct Fp2 {
+    Fp<P> c0, c1;
+    ZL_HD static Fp2 zero() { return Fp2{Fp<P>::zero(), Fp<P>::zero()}; }
+    ZL_HD static Fp2 one() { return Fp2{Fp<P>::one(), Fp<P>::zero()}; }
+    ZL_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    ZL_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+    ZL_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
+};
+namespace zl {
+template <class P> ZL_HD Fp2<P> add(const Fp2<P>& a, const Fp2<P>& b) { return Fp2<P>{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+template <class P> ZL_HD Fp2<P> sub(const Fp2<P>& a, const Fp2<P>& b) { return Fp2<P>{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+template <class P> ZL_HD Fp2<P> dbl(const Fp2<P>& a) { return Fp2<P>{dbl(a.c0), dbl(a.c1)}; }
+template <class P> ZL_HD Fp2<P> neg(const Fp2<P>& a) { return Fp2<P>{neg(a.c0), neg(a.c1)}; }
+template <class P> ZL_HD Fp2<P> mul(const Fp2<P>& a, const Fp2<P>& b) {
+    // Karatsuba: 3 base multiplications
+    Fp<P> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
+    Fp<P> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return Fp2<P>{sub(v0, v1), sub(sub(s, v0), v1)};
+}
+template <class P> ZL_HD Fp2<P> sqr(const Fp2<P>& a) {
+    // (c0+c1)(c0-c1) + 2 c0 c1 u
+    Fp<P> t = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+    Fp<P> m = mul(a.c0, a.c1);
+    return Fp2<P>{t, dbl(m)};
+}
+template <class P> ZL_HD Fp2<P> inv(const Fp2<P>& a) {
+    Fp<P> n = inv(add(sqr(a.c0), sqr(a.c1)));
+    return Fp2<P>{mul(a.c0, n), neg(mul(a.c1, n))};
+}
+template <class P> ZL_HD Fp2<P> to_mont(const Fp2<P>& a) { return Fp2<P>{to_mont(a.c0), to_mont(a.c1)}; }
+template <class P> ZL_HD Fp2<P> from_mont(const Fp2<P>& a) { return Fp2<P>{from_mont(a.c0), from_mont(a.c1)}; }
+}  // namespace zl
+
+// ---- points ----------------------------------------------------------------------------------------------
+// Affine point in device memory.  Infinity is encoded as x = y = 0 ((0,0) is on neither curve: b != 0).
+template <class F>
+struct Affine {
+    F x, y;
+    ZL_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZL_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
+};
+template <class F>
+struct XYZZ {
+    F x, y, zz, zzz;
+    ZL_HD bool is_inf() const { return zz.is_zero(); }
+    ZL_HD static XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
+    ZL_HD static XYZZ from_affine(const Affine<F>& a) {
+        if (a.is_inf()) return inf();
+        return XYZZ{a.x, a.y, F::one(), F::one()};
+    }
+};
+
+namespace zl {
+
+// 2*(x,y) for an affine, non-infinity point (mdbl-2008-s-1, a = 0)
+template <class F>
+ZL_HD XYZZ<F> dbl_affine(const F& x, const F& y) {
+    F u = dbl(y), v = sqr(u), w = mul(u, v), s = mul(x, v);
+    F xx = sqr(x);
+    F m = add(dbl(xx), xx);
+    XYZZ<F> r;
+    r.x = sub(sqr(m), dbl(s));
+    r.y = sub(mul(m, sub(s, r.x)), mul(w, y));
+    r.zz = v;
+    r.zzz = w;
+    return r;  // y == 0 -> zz == 0 -> infinity
+}
+// p = 2p (dbl-2008-s-1, a = 0)
+template <class F>
+ZL_HD void dbl_inplace(XYZZ<F>& p) {
+    if (p.is_inf()) return;
+    F u = dbl(p.y), v = sqr(u), w = mul(u, v), s = mul(p.x, v);
+    F xx = sqr(p.x);
+    F m = add(dbl(xx), xx);
+    F x3 = sub(sqr(m), dbl(s));
+    p.y = sub(mul(m, sub(s, x3)), mul(w, p.y));
+    p.x = x3;
+    p.zz = mul(v, p.zz);
+    p.zzz = mul(w, p.zzz);
+}
+// p += (qx, qy) (affine, q must not be infinity); neg_q selects p -= q.   madd-2008-s
+template <class F>
+ZL_HD void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
+    F qy = neg_q ? neg(qy_in) : qy_in;
+    if (p.is_inf()) {
+        p.x = qx; p.y = qy; p.zz = F::one(); p.zzz = F::one();
+        return;
+    }
+    F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);
+    F pp_ = sub(u2, p.x), r = sub(s2, p.y);
+    if (pp_.is_zero()) {
+        if (r.is_zero()) { p = dbl_affine(qx, qy); return; }
+        p = XYZZ<F>::inf();
+        return;
+    }
+    F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);
+    F x3 = sub(sub(sqr(r), ppp), dbl(q));
+    p.y = sub(mul(r, sub(q, x3)), mul(p.y, ppp));
+    p.x = x3;
+    p.zz = mul(p.zz, pp);
+    p.zzz = mul(p.zzz, ppp);
+}
+// p += q (add-2008-s)
+template <class F>
+ZL_HD void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
+    if (q.is_inf()) return;
+    if (p.is_inf()) { p = q; return; }
+    F u1 = mul(p.x, q.zz), u2 = mul(q.x, p.zz);
+    F s1 = mul(p.y, q.zzz), s2 = mul(q.y, p.zzz);
+    F pp_ = sub(u2, u1), r = sub(s2, s1);
+    if (pp_.is_zero()) {
+        if (r.is_zero()) { dbl_inplace(p); return; }
+        p = XYZZ<F>::inf();
+        return;
+    }
+    F pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(u1, pp);
+    F x3 = sub(sub(sqr(r), ppp), dbl(q_));
+    p.y = sub(mul(r, sub(q_, x3)), mul(s1, ppp));
+    p.x = x3;
+    p.zz = mul(mul(p.zz, q.zz), pp);
+    p.zzz = mul(mul(p.zzz, q.zzz), ppp);
+}
+template <class F>
+ZL_HD Affine<F> to_affine(const XYZZ<F>& p) {
+    if (p.is_inf()) return Affine<F>::inf();
+    F izzz = inv(p.zzz);
+    F t = mul(p.zz, izzz);  // = 1/sqrt-ish: zz/zzz = 1/z
+    F izz = sqr(t);         // zz^2/zzz^2 = 1/zz  (zz^3 = zzz^2)
+    return Affine<F>{mul(p.x, izz), mul(p.y, izzz)};
+}
+// p = k*p for a small unsigned multiplier (double-and-add, MSB first)
+template <class F>
+ZL_HD XYZZ<F> mul_small(const XYZZ<F>& p, uint32_t k) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = 31; i >= 0; i--) {
+        dbl_inplace(acc);
+        if ((k >> i) & 1) add_full(acc, p);
+    }
+    return acc;
+}
+// k*p for a 256-bit little-endian scalar in 8 words (host-side tails, generator kernels)
+template <class F>
+ZL_HD XYZZ<F> mul_scalar(const XYZZ<F>& p, const uint32_t* k) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = 255; i >= 0; i--) {
+        dbl_inplace(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) add_full(acc, p);
+    }
+    return acc;
+}
+}  // namespace zl

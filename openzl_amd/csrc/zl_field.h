@@ -1,0 +1,232 @@
+// zl_field.h -- Montgomery prime-field arithmetic on 32-bit limbs for gfx950 (and the host tail code).
+//
+// Replaces, for this backend, what ark-ff 0.3.0 Fp256/Fp384 does on the CPU (`pub use ff::*`,
+// /root/reference/plugins/arkworks/src/ff.rs:6): same value*R mod p representation with
+// R = 2^(64*ceil(bits/64)), so limbs are byte-compatible with arkworks' in-memory BigInteger limbs
+// (two u32 = one little-endian u64).  Everything is fully reduced to [0,p) on output.
+//
+// gfx950 has no 64-bit multiplier; the work-horse is v_mad_u64_u32 (32x32+64 -> 64).  The CIOS loops below
+// are written so that each inner step is exactly one such mad plus a 64-bit carry add.
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZL_HD __host__ __device__ __forceinline__
+#else
+#define ZL_HD inline
+#endif
+#include "zl_params.h"
+
+template <class P>
+struct alignas(16) Fp {
+    static constexpr int N = P::N;
+    uint32_t l[N];
+
+    ZL_HD static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = 0;
+        return r;
+    }
+    ZL_HD static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = P::one(i);
+        return r;
+    }
+    ZL_HD static Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = P::r2(i);
+        return r;
+    }
+    ZL_HD bool is_zero() const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc |= l[i];
+        return acc == 0;
+    }
+    ZL_HD bool operator==(const Fp& o) const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) acc |= l[i] ^ o.l[i];
+        return acc == 0;
+    }
+    ZL_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+};
+
+namespace zl {
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class P>
+ZL_HD void reduce_once(uint32_t* a) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a[i] - P::mod(i) - br;
+        t[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    // br == 1 -> a < p -> keep a
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = br ? a[i] : t[i];
+}
+
+template <class P>
+ZL_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int N = P::N;
+    Fp<P> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    reduce_once<P>(r.l);  // every modulus here leaves >= 1 spare top bit: no carry out
+    return r;
+}
+template <class P>
+ZL_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int N = P::N;
+    Fp<P> r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
+        r.l[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)br;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)r.l[i] + (P::mod(i) & mask);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+template <class P>
+ZL_HD Fp<P> dbl(const Fp<P>& a) {
+    return add(a, a);
+}
+template <class P>
+ZL_HD Fp<P> neg(const Fp<P>& a) {
+    return sub(Fp<P>::zero(), a);  // a == 0: no borrow, stays 0; otherwise p - a
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS on 32-bit limbs.  All moduli have their top bit clear, so the
+// running value stays < 2p < 2^(32N) and no extra carry word is needed.
+template <class P>
+ZL_HD Fp<P> mul_body(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        // invariant: T = sum t[j] 2^(32j) < 2p < 2^(32N)  (T_i = (a*(b mod 2^(32i)) + M_i*p) / 2^(32i), M_i < 2^(32i))
+        uint64_t c = 0;
+        const uint32_t bi = b.l[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            uint64_t p = (uint64_t)a.l[j] * bi + t[j] + c;
+            t[j] = (uint32_t)p;
+            c = p >> 32;
+        }
+        const uint32_t tn = (uint32_t)c;  // T + a*b_i < 2p + p*2^32: top word fits 32 bits
+        const uint32_t m = t[0] * P::INV;
+        uint64_t p = (uint64_t)m * P::mod(0) + t[0];
+        c = p >> 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            p = (uint64_t)m * P::mod(j) + t[j] + c;
+            t[j - 1] = (uint32_t)p;
+            c = p >> 32;
+        }
+        t[N - 1] = tn + (uint32_t)c;  // new T < 2p: no carry out
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    reduce_once<P>(r.l);
+    return r;
+}
+// The multiplier is ONE out-of-line function per field (arguments and result travel in VGPRs on the device):
+// a fully inlined point addition is ~50 KB of code per call site, which overflows the instruction cache and
+// takes hipcc tens of minutes to schedule; a called 5 KB body stays I-cache resident.
+#if defined(__HIPCC__)
+#define ZL_NOINLINE_HD __host__ __device__ __attribute__((noinline))
+#else
+#define ZL_NOINLINE_HD __attribute__((noinline))
+#endif
+template <class P>
+ZL_NOINLINE_HD Fp<P> mul_call(Fp<P> a, Fp<P> b) {
+    return mul_body(a, b);
+}
+template <class P>
+ZL_NOINLINE_HD Fp<P> sqr_call(Fp<P> a) {
+    return mul_body(a, a);
+}
+template <class P>
+ZL_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+#if !defined(ZL_INLINE_MUL)
+    return mul_call<P>(a, b);
+#else
+    return mul_body(a, b);
+#endif
+}
+template <class P>
+ZL_HD Fp<P> sqr(const Fp<P>& a) {
+#if !defined(ZL_INLINE_MUL)
+    return sqr_call<P>(a);
+#else
+    return mul_body(a, a);
+#endif
+}
+
+template <class P>
+ZL_HD Fp<P> to_mont(const Fp<P>& canon) {
+    return mul(canon, Fp<P>::r2());
+}
+template <class P>
+ZL_HD Fp<P> from_mont(const Fp<P>& a) {
+    Fp<P> o = Fp<P>::zero();
+    o.l[0] = 1;
+    return mul(a, o);
+}
+// a^e for a little-endian exponent of `nbits` bits held in 32-bit words
+template <class P>
+ZL_HD Fp<P> pow_words(const Fp<P>& a, const uint32_t* e, int nbits) {
+    Fp<P> acc = Fp<P>::one();
+    for (int i = nbits - 1; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, a);
+    }
+    return acc;
+}
+// Fermat inverse a^(p-2); inv(0) = 0
+template <class P>
+ZL_HD Fp<P> inv(const Fp<P>& a) {
+    constexpr int N = P::N;
+    uint32_t e[N];
+    uint32_t borrow = 2;  // e = p - 2 with borrow propagation (the low limb of BLS12-381 Fr is 1)
+    for (int i = 0; i < N; i++) {
+        const uint32_t m = P::mod(i);
+        e[i] = m - borrow;
+        borrow = m < borrow ? 1u : 0u;
+    }
+    return pow_words(a, e, 32 * N);
+}
+template <class P>
+ZL_HD Fp<P> from_u64(uint64_t v) {
+    Fp<P> c = Fp<P>::zero();
+    c.l[0] = (uint32_t)v;
+    c.l[1] = (uint32_t)(v >> 32);
+    return to_mont(c);
+}
+
+}  // namespace zl

@@ -1,0 +1,579 @@
+// zl_msm.hip -- variable-base multi-scalar multiplication on gfx950 (Pippenger, bucket method).
+//
+// Replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul (ark-ec 0.3.0; reached from
+// /root/reference/plugins/arkworks/src/groth16.rs:454 through ark-groth16's create_proof).
+// arkworks walks the windows serially with unsigned c-bit digits and 2^c - 1 Jacobian buckets per window.  This
+// backend is organised for a 256-CU / wave64 machine instead:
+//   1. msm_count     signed-digit recoding of every scalar (2^(c-1) buckets per window), global histogram
+//   2. scan          exclusive prefix sum over all W * 2^(c-1) bucket counters
+//   3. msm_scatter   counting sort of (point index, sign) entries by bucket (all windows in one pass)
+//   4. msm_accumulate  the hot kernel: the sorted entry array is cut into fixed chunks of ZL_CHUNK entries, one lane
+//                    per chunk, XYZZ mixed additions; a bucket that lies inside one chunk is written directly,
+//                    buckets cut by chunk boundaries leave <= 2 partial sums per lane -> perfect load balance
+//                    whatever the scalar distribution (Groth16 witnesses are full of 0/1)
+//   5. msm_merge     one lane per bucket folds the partials of cut buckets (block-wide tree for giant buckets)
+//   6. msm_reduce    sum_k k*B_k per window by segmented running sums, then a block tree per window
+//   7. host          Horner over the W window sums (a few hundred field ops), returned as an XYZZ partial
+// The result does not depend on c, on the digit signs or on the order entries land in a bucket (group law).
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "zl_ctx.h"
+
+// This file is compiled once per group: -DZL_G=BlsG1|BnG1|BlsG2|BnG2 (see openzl_amd/build.py)
+#ifndef ZL_G
+#error "compile with -DZL_G=<group config>"
+#endif
+#define ZL_GCAT_(a, b) a##_##b
+#define ZL_GCAT(a, b) ZL_GCAT_(a, b)
+#define ZL_GNAME(f) ZL_GCAT(f, ZL_G)
+
+#define ZL_CHUNK 64        // entries per lane in msm_accumulate
+#define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
+#define ZL_SEG 16          // buckets per lane in msm_reduce
+
+// ------------------------------------------------------------------------------------------------ digits
+__device__ __forceinline__ uint32_t zl_get_bits(const uint32_t* __restrict__ s, int pos, int c) {
+    // bits [pos, pos+c) of a 256-bit little-endian integer (c <= 24); bits above 255 read as 0
+    int word = pos >> 5, sh = pos & 31;
+    if (word >= 8) return 0;
+    uint64_t v = s[word];
+    if (word + 1 < 8) v |= (uint64_t)s[word + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+// MODE 0: histogram; MODE 1: scatter (cursor initialised with the bucket offsets)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ entries) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = scalars + (size_t)i * 8;
+    const uint32_t H = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        uint32_t d = zl_get_bits(s, w * c, c) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > H) { d = (2 * H) - d; neg = 1; carry = 1; }  // d - 2^c < 0, magnitude 2^c - d in [0, H-1]
+        if (d == 0) continue;
+        uint32_t bucket = (uint32_t)w * H + (d - 1);
+        if (MODE == 0) {
+            atomicAdd(&counters[bucket], 1u);
+        } else {
+            uint32_t pos = atomicAdd(&counters[bucket], 1u);
+            entries[pos] = i | (neg << 31);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+// exclusive scan of `count` u32 values, 3 launches; out[count] = total
+#define SCAN_ITEMS 16
+#define SCAN_BLOCK 256
+static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < count) s += in[base + k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = SCAN_BLOCK / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
+    // single block: exclusive scan of block_sums in place
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        uint32_t idx = base + threadIdx.x;
+        uint32_t v = idx < nblocks ? block_sums[idx] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t incl = sh[threadIdx.x];
+        if (idx < nblocks) block_sums[idx] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t count, const uint32_t* __restrict__ block_sums,
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < count) ? in[base + k] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = block_sums[blockIdx.x] + sh[threadIdx.x] - s;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < count) { out[base + k] = run; out2[base + k] = run; }
+        run += v[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+__device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ a, uint32_t n, uint32_t key) {
+    // first index with a[idx] > key
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                        XYZZ<typename G::F>* __restrict__ partials) {
+    using F = typename G::F;
+    const uint32_t E = offsets[NB];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
+    if (start64 >= E) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (uint32_t)min((uint64_t)E, start64 + ZL_CHUNK);
+    uint32_t b = zl_upper_bound(offsets, NB + 1, start) - 1;  // bucket holding entry `start`
+    uint32_t pos = start;
+    while (pos < end) {
+        const uint32_t b_start = offsets[b], b_end = offsets[b + 1];
+        const uint32_t seg_end = min(b_end, end);
+        if (seg_end > pos) {
+            XYZZ<F> acc = XYZZ<F>::inf();
+            for (uint32_t e = pos; e < seg_end; e++) {
+                const uint32_t ent = entries[e];
+                const Affine<F> P = bases[ent & 0x7fffffffu];
+                if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+            }
+            const bool complete = (b_start >= start) && (b_end <= end);
+            if (complete) bucket_sums[b] = acc;
+            else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
+            pos = seg_end;
+        }
+        b++;
+    }
+}
+
+// one lane per bucket: empty -> infinity; cut into <= ZL_BIG_SPAN chunks -> fold partials; else defer to a block
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                   const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
+                                                   uint32_t* __restrict__ big_count) {
+    using F = typename G::F;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    if (s == e) { bucket_sums[b] = XYZZ<F>::inf(); return; }
+    const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+    if (t0 == t1) return;  // written directly by msm_accumulate
+    if (t1 - t0 + 1 > ZL_BIG_SPAN) { big_list[atomicAdd(big_count, 1u)] = b; return; }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t t = t0; t <= t1; t++) {
+        const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+        zl::add_full(acc, p);
+    }
+    bucket_sums[b] = acc;
+}
+// one 256-lane block per giant bucket
+template <class G>
+__global__ void __launch_bounds__(256) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                        const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
+                                                        const uint32_t* __restrict__ big_count) {
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    for (uint32_t item = blockIdx.x; item < *big_count; item += gridDim.x) {
+        const uint32_t b = big_list[item];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+            const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+            zl::add_full(acc, p);
+        }
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                XYZZ<F> a = sh[threadIdx.x];
+                const XYZZ<F> o = sh[threadIdx.x + off];
+                zl::add_full(a, o);
+                sh[threadIdx.x] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) bucket_sums[b] = sh[0];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bucket reduction
+// lane (w, seg): buckets k = k0+1 .. k0+ZL_SEG of window w (bucket index k-1).  sum k*B_k = sum (k-k0) B_k + k0 * sum B_k
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>* __restrict__ bucket_sums, uint32_t H, uint32_t segs_per_window,
+                                                        uint32_t total_segs, XYZZ<typename G::F>* __restrict__ seg_out) {
+    using F = typename G::F;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_segs) return;
+    const uint32_t w = t / segs_per_window, seg = t % segs_per_window;
+    const uint32_t k0 = seg * ZL_SEG;
+    const uint32_t hi = min(H, k0 + ZL_SEG);
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    for (uint32_t k = hi; k > k0; k--) {
+        const XYZZ<F> B = bucket_sums[(size_t)w * H + (k - 1)];
+        zl::add_full(run, B);
+        zl::add_full(acc, run);
+    }
+    if (k0 != 0 && !run.is_inf()) {
+        // k0 * run, k0 < 2^23
+        XYZZ<F> m = XYZZ<F>::inf();
+        for (int i = 31 - __clz(k0); i >= 0; i--) {
+            zl::dbl_inplace(m);
+            if ((k0 >> i) & 1) zl::add_full(m, run);
+        }
+        zl::add_full(acc, m);
+    }
+    seg_out[t] = acc;
+}
+// block per window: tree-sum the segment results
+template <class G>
+__global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t segs_per_window,
+                                                         XYZZ<typename G::F>* __restrict__ window_sums) {
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t w = blockIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t s = threadIdx.x; s < segs_per_window; s += blockDim.x) {
+        const XYZZ<F> p = seg_out[(size_t)w * segs_per_window + s];
+        zl::add_full(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x];
+            const XYZZ<F> o = sh[threadIdx.x + off];
+            zl::add_full(a, o);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) window_sums[w] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------ bases kernels
+// canonical / Montgomery host records -> device Affine<F> (Montgomery).  in: packed x||y u32 limbs per point.
+template <class G>
+__global__ void __launch_bounds__(128) k_bases_import(const uint32_t* __restrict__ in, const uint8_t* __restrict__ inf_flags, uint32_t n, int to_mont,
+                                                       int check, Affine<typename G::F>* __restrict__ out, uint32_t* __restrict__ bad) {
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int WORDS = sizeof(F) / 4;
+    Affine<F> p;
+    const uint32_t* src = in + (size_t)i * 2 * WORDS;
+    uint32_t* px = reinterpret_cast<uint32_t*>(&p.x);
+    uint32_t* py = reinterpret_cast<uint32_t*>(&p.y);
+    for (int k = 0; k < WORDS; k++) { px[k] = src[k]; py[k] = src[WORDS + k]; }
+    bool inf = p.is_inf() || (inf_flags && inf_flags[i]);
+    if (inf) { out[i] = Affine<F>::inf(); return; }
+    if (to_mont) { p.x = zl::to_mont(p.x); p.y = zl::to_mont(p.y); }
+    if (check) {
+        F lhs = zl::sqr(p.y);
+        F rhs = zl::add(zl::mul(zl::sqr(p.x), p.x), G::coeff_b());
+        if (lhs != rhs) atomicAdd(bad, 1u);
+    }
+    out[i] = p;
+}
+// out[i] = canonical affine x||y of bases[i]
+template <class G>
+__global__ void __launch_bounds__(128) k_bases_export(const Affine<typename G::F>* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int WORDS = sizeof(F) / 4;
+    Affine<F> p = in[i];
+    if (!p.is_inf()) { p.x = zl::from_mont(p.x); p.y = zl::from_mont(p.y); }
+    const uint32_t* px = reinterpret_cast<const uint32_t*>(&p.x);
+    const uint32_t* py = reinterpret_cast<const uint32_t*>(&p.y);
+    uint32_t* dst = out + (size_t)i * 2 * WORDS;
+    for (int k = 0; k < WORDS; k++) { dst[k] = px[k]; dst[WORDS + k] = py[k]; }
+}
+// bases[i] = k[i] * G by double-and-add, then one inversion per point (input generator, untimed)
+template <class G>
+__global__ void __launch_bounds__(64) k_bases_generate(const uint32_t* __restrict__ k, uint32_t n, Affine<typename G::F>* __restrict__ out) {
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = k + (size_t)i * 8;
+    const F gx = G::gen_x(), gy = G::gen_y();
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 255; bit >= 0; bit--) {
+        zl::dbl_inplace(acc);
+        if ((s[bit >> 5] >> (bit & 31)) & 1) zl::add_mixed(acc, gx, gy, false);
+    }
+    out[i] = zl::to_affine(acc);
+}
+
+// ------------------------------------------------------------------------------------------------ host driver
+static int zl_pick_window(size_t n, int sc_bits) {
+    // minimise accumulate adds (n per window) + per-bucket overhead (merge + reduce, ~16 add-equivalents)
+    double best = 1e300;
+    int best_c = 2;
+    for (int c = 2; c <= 20; c++) {
+        int W = (sc_bits + 1 + c - 1) / c;
+        double cost = (double)n * W + 16.0 * W * (double)(1u << (c - 1));
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    return best_c;
+}
+
+template <class G>
+static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
+    using F = typename G::F;
+    using X = XYZZ<F>;
+    X total = X::inf();
+    ctx->timing = zl_timing{};
+    if (n > 0) {
+        int c = ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS);
+        if (c < 2) c = 2;
+        if (c > 22) c = 22;
+        const int W = (G::SC_BITS + 1 + c - 1) / c;
+        const uint32_t H = 1u << (c - 1);
+        const uint64_t NB64 = (uint64_t)W * H;
+        const uint64_t maxE = (uint64_t)n * W;
+        if (n >= (1ull << 31) || maxE >= (1ull << 32) || NB64 >= (1ull << 31)) return ZL_EINVAL;
+        const uint32_t NB = (uint32_t)NB64;
+        const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
+        const uint32_t segs_per_window = (H + ZL_SEG - 1) / ZL_SEG;
+        const uint32_t total_segs = segs_per_window * W;
+        const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+        const uint32_t max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
+
+        uint32_t *d_counts, *d_offsets, *d_cursor, *d_entries, *d_small;
+        X *d_buckets, *d_partials, *d_segs;
+        void* p;
+        int rc;
+        // slot 0: counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | big count
+        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + 1 + 16;
+        if ((rc = zl_scratch_get(ctx, 0, small_words * 4, &p))) return rc;
+        d_counts = (uint32_t*)p;
+        d_offsets = d_counts + (NB + 1);
+        d_cursor = d_offsets + (NB + 1);
+        d_small = d_cursor + (NB + 1);
+        uint32_t* d_block_sums = d_small;
+        uint32_t* d_big_list = d_block_sums + scan_blocks + 1;
+        uint32_t* d_big_count = d_big_list + max_big;
+        if ((rc = zl_scratch_get(ctx, 1, maxE * 4, &p))) return rc;
+        d_entries = (uint32_t*)p;
+        if ((rc = zl_scratch_get(ctx, 2, (size_t)NB * sizeof(X), &p))) return rc;
+        d_buckets = (X*)p;
+        if ((rc = zl_scratch_get(ctx, 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
+        d_partials = (X*)p;
+        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + W) * sizeof(X), &p))) return rc;
+        d_segs = (X*)p;
+        X* d_windows = d_segs + total_segs;
+
+        hipStream_t st = ctx->stream;
+        const Affine<F>* d_bases = reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
+        const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+        ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
+        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 4, st));
+        const uint32_t nblk = (uint32_t)((n + 255) / 256);
+        hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+        hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries);
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials);
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count);
+        hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(256), 256 * sizeof(X), st, d_offsets, d_buckets,
+                           d_partials, d_big_list, d_big_count);
+        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_window, total_segs, d_segs);
+        hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(W), dim3(256), 256 * sizeof(X), st, d_segs, segs_per_window, d_windows);
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        ZL_HIP(ctx, hipGetLastError());
+        std::vector<X> hw(W);
+        uint32_t hE = 0;
+        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_windows, sizeof(X) * W, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(&hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->timing_on) {
+            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]));
+            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.dominant_ms, ctx->ev[1], ctx->ev[2]));
+        }
+        ctx->timing.launches = 1;
+        ctx->timing.window_bits = (uint32_t)c;
+        ctx->timing.entries = hE;
+        // Horner over windows, high to low: total = sum 2^(c*w) * window[w]
+        for (int w = W - 1; w >= 0; w--) {
+            if (w != W - 1) for (int k = 0; k < c; k++) zl::dbl_inplace(total);
+            zl::add_full(total, hw[w]);
+        }
+    }
+    static_assert(sizeof(X) <= ZL_PARTIAL_WORDS * 8, "partial too small");
+    memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);
+    memcpy(out_partial, &total, sizeof(X));
+    return ZL_OK;
+}
+
+int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
+    return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);
+}
+
+// host: XYZZ partial (Montgomery) -> canonical affine
+template <class G>
+static int partial_to_affine_t(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf) {
+    using F = typename G::F;
+    XYZZ<F> p;
+    memcpy(&p, partial, sizeof p);
+    Affine<F> a = zl::to_affine(p);
+    const bool inf = p.is_inf();
+    if (out_inf) *out_inf = inf ? 1 : 0;
+    if (!inf) { a.x = zl::from_mont(a.x); a.y = zl::from_mont(a.y); }
+    memcpy(out_xy, &a.x, sizeof(F));
+    memcpy(reinterpret_cast<unsigned char*>(out_xy) + sizeof(F), &a.y, sizeof(F));
+    return ZL_OK;
+}
+int ZL_GNAME(zl_partial_to_affine)(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf) {
+    return partial_to_affine_t<ZL_G>(partial, out_xy, out_inf);
+}
+template <class G>
+static int partials_sum_t(const uint64_t* partials, size_t count, uint64_t* out_partial) {
+    using F = typename G::F;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = 0; i < count; i++) {
+        XYZZ<F> p;
+        memcpy(&p, partials + i * ZL_PARTIAL_WORDS, sizeof p);
+        zl::add_full(acc, p);
+    }
+    memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);
+    memcpy(out_partial, &acc, sizeof acc);
+    return ZL_OK;
+}
+int ZL_GNAME(zl_partials_fold)(const uint64_t* partials, size_t count, uint64_t* out_partial) {
+    return partials_sum_t<ZL_G>(partials, count, out_partial);
+}
+
+// ------------------------------------------------------------------------------------------------ bases host side
+template <class G>
+static int bases_upload_t(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out) {
+    using F = typename G::F;
+    const size_t rec = 2 * sizeof(F);
+    if (stride == 0) stride = rec;
+    if (stride < rec || n >= (1ull << 31)) return ZL_EINVAL;
+    if (inf_off >= 0 && (size_t)inf_off >= stride) return ZL_EINVAL;
+    void* d_pts = nullptr;
+    ZL_HIP(ctx, hipMalloc(&d_pts, std::max<size_t>(n, 1) * sizeof(Affine<F>)));
+    int rc = ZL_OK;
+    if (n) {
+        // stage packed records (+ optional flag bytes) on the host, one H2D copy
+        std::vector<unsigned char> packed;
+        std::vector<uint8_t> flags_host;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(xy);
+        const unsigned char* send = src;
+        if (stride != rec) {
+            packed.resize(n * rec);
+            for (size_t i = 0; i < n; i++) memcpy(&packed[i * rec], src + i * stride, rec);
+            send = packed.data();
+        }
+        if (inf_off >= 0) {
+            flags_host.resize(n);
+            for (size_t i = 0; i < n; i++) flags_host[i] = src[i * stride + (size_t)inf_off] ? 1 : 0;
+        }
+        void* d_in;
+        if ((rc = zl_scratch_get(ctx, 5, n * rec + n + 64, &d_in))) { (void)hipFree(d_pts); return rc; }
+        uint8_t* d_flags = reinterpret_cast<uint8_t*>(d_in) + n * rec;
+        uint32_t* d_bad = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(d_in) + ((n * rec + n + 15) / 16) * 16);
+        hipStream_t st = ctx->stream;
+        hipError_t e = hipMemcpyAsync(d_in, send, n * rec, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && inf_off >= 0) e = hipMemcpyAsync(d_flags, flags_host.data(), n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_bases_import<G>), dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st, (const uint32_t*)d_in,
+                               inf_off >= 0 ? d_flags : (const uint8_t*)nullptr, (uint32_t)n, (flags & ZL_MONT) ? 0 : 1, (flags & ZL_CHECK) ? 1 : 0,
+                               (Affine<F>*)d_pts, d_bad);
+            e = hipGetLastError();
+        }
+        uint32_t bad = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(d_pts); return ZL_EHIP; }
+        if (bad) { (void)hipFree(d_pts); return ZL_ENOTCURVE; }
+    }
+    out->d_pts = d_pts;
+    out->n = n;
+    return ZL_OK;
+}
+int ZL_GNAME(zl_bases_upload)(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out) {
+    return bases_upload_t<ZL_G>(ctx, xy, n, stride, inf_off, flags, out);
+}
+template <class G>
+static int bases_generate_t(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out) {
+    using F = typename G::F;
+    if (n >= (1ull << 31)) return ZL_EINVAL;
+    void* d_pts = nullptr;
+    ZL_HIP(ctx, hipMalloc(&d_pts, std::max<size_t>(n, 1) * sizeof(Affine<F>)));
+    if (n) {
+        void* d_k;
+        int rc;
+        if ((rc = zl_scratch_get(ctx, 5, n * 32, &d_k))) { (void)hipFree(d_pts); return rc; }
+        hipStream_t st = ctx->stream;
+        hipError_t e = hipMemcpyAsync(d_k, k, n * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_bases_generate<G>), dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_k, (uint32_t)n, (Affine<F>*)d_pts);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(d_pts); return ZL_EHIP; }
+    }
+    out->d_pts = d_pts;
+    out->n = n;
+    return ZL_OK;
+}
+int ZL_GNAME(zl_bases_generate)(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out) {
+    return bases_generate_t<ZL_G>(ctx, k, n, out);
+}
+template <class G>
+static int bases_download_t(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy) {
+    using F = typename G::F;
+    if (!count) return ZL_OK;
+    void* d_out;
+    int rc;
+    if ((rc = zl_scratch_get(ctx, 5, count * 2 * sizeof(F), &d_out))) return rc;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL((k_bases_export<G>), dim3((uint32_t)((count + 127) / 128)), dim3(128), 0, st,
+                       reinterpret_cast<const Affine<F>*>(b.d_pts) + first, (uint32_t)count, (uint32_t*)d_out);
+    ZL_HIP(ctx, hipGetLastError());
+    ZL_HIP(ctx, hipMemcpyAsync(out_xy, d_out, count * 2 * sizeof(F), hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipStreamSynchronize(st));
+    return ZL_OK;
+}
+int ZL_GNAME(zl_bases_download)(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy) {
+    return bases_download_t<ZL_G>(ctx, b, first, count, out_xy);
+}

@@ -1,0 +1,367 @@
+// zl_ntt.hip -- radix-2 number-theoretic transform over the scalar field on gfx950.
+//
+// Replaces ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place (ark-poly 0.3.0; reached from
+// /root/reference/plugins/arkworks/src/groth16.rs:454 through R1CStoQAP::witness_map, and surfaced by `pub use poly;`
+// /root/reference/plugins/arkworks/src/lib.rs:70-71).  Same contract: natural order in and out,
+// group_gen = TWO_ADIC_ROOT^(2^(TWO_ADICITY - log n)), inverse scaled by n^-1, coset variants pre-multiply by g^i /
+// post-multiply by g^-i.  arkworks runs log n in-place butterfly sweeps over a tabulated root vector; here the
+// transform is factored N = N1*N2*..*NP (each Np <= 2^10, usually 2^8) and every factor is one kernel pass:
+//   pass p: a workgroup owns a tile of 2^sp rows x C columns (C*32 B contiguous in HBM), stages it in LDS (limb-major
+//           SoA, swizzled), applies the inter-factor twiddle w_N^(j_p * K) on load, runs the 2^sp-point DIF
+//           butterflies entirely in LDS with the w_(2^sp) table also in LDS, and stores rows bit-reversed.
+//   pass 1 reads the caller's buffer and writes a scratch buffer, the last pass reads scratch and writes the caller's
+//   buffer transposed into natural order, so the transform is in place for the caller with no extra copy.
+// HBM traffic: P reads + P writes of the vector (P = 3 at 2^24); everything else stays in LDS / registers.
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "zl_ctx.h"
+
+#define NTT_THREADS 256
+#define NTT_TILE 2048   // elements per workgroup tile (64 KiB of LDS)
+#define NTT_MAX_S 10
+
+struct NttArgs {
+    uint32_t n_log, s, logC, P, p;
+    uint32_t sizes[4];
+    uint32_t S_prev;        // s_1 + .. + s_(p-1)
+    uint32_t L;             // two-level table split: e = hi << L | lo
+    uint32_t pre_coset, post_scale, post_coset, to_mont, from_mont;
+    const void *t_lo, *t_hi;  // w^lo, w^(hi << L)
+    const void* w_small;      // w_(2^s)^i, i < 2^(s-1)
+    const void *g_lo, *g_hi;  // coset powers (hi table carries n^-1 for the inverse)
+    uint32_t ninv[8];
+};
+
+template <class F>
+__device__ __forceinline__ F lds_load(const uint32_t* sh, uint32_t pos) {
+    F r;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) r.l[k] = sh[k * NTT_TILE + pos];
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_store(uint32_t* sh, uint32_t pos, const F& v) {
+#pragma unroll
+    for (int k = 0; k < F::N; k++) sh[k * NTT_TILE + pos] = v.l[k];
+}
+__device__ __forceinline__ uint32_t tile_pos(uint32_t row, uint32_t col, uint32_t logC) {
+    // swizzle columns so that consecutive rows of one column fall into different LDS banks
+    uint32_t C = 1u << logC;
+    uint32_t rows_per_wrap_log = logC >= 5 ? 0 : 5 - logC;
+    uint32_t cs = (col + (row >> rows_per_wrap_log)) & (C - 1);
+    return (row << logC) | cs;
+}
+template <class F>
+__device__ __forceinline__ F twiddle2(const F* lo, const F* hi, uint32_t L, uint64_t e) {
+    const F a = lo[e & ((1ull << L) - 1)];
+    const F b = hi[e >> L];
+    return zl::mul(a, b);
+}
+
+template <class FrP, bool LAST>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
+    using F = Fp<FrP>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                       // [8][NTT_TILE]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = a.s, logC = a.logC, R = 1u << s, C = 1u << logC;
+    F* sh_w = reinterpret_cast<F*>(smem + (size_t)F::N * 4 * NTT_TILE);      // [2^(s-1)] butterfly roots
+    F* sh_row = sh_w + (R >> 1);                                             // [2^s] per-row twiddles (non-last passes)
+    const uint32_t n_log = a.n_log;
+    const F* t_lo = reinterpret_cast<const F*>(a.t_lo);
+    const F* t_hi = reinterpret_cast<const F*>(a.t_hi);
+
+    // ---- tile addressing -------------------------------------------------------------------------------
+    uint64_t in_base, out_base, in_row, in_col, out_row;
+    uint64_t K0 = 0;  // digit-reversed index of the already transformed factors (column 0)
+    {
+        const uint64_t tile = blockIdx.x;
+        if (!LAST) {
+            const uint32_t stride_log = n_log - a.S_prev - s;  // elements between consecutive rows
+            const uint64_t lo_blocks = (1ull << stride_log) >> logC;
+            const uint64_t hi = tile / lo_blocks, lo0 = (tile % lo_blocks) << logC;
+            in_base = (hi << (s + stride_log)) + lo0;
+            out_base = in_base;
+            in_row = 1ull << stride_log;
+            in_col = 1;
+            out_row = in_row;
+            uint64_t rem = hi;
+            uint32_t Sq = a.S_prev;
+            for (int q = (int)a.p - 2; q >= 0; q--) {  // digits k_(p-1) .. k_1, least significant first
+                Sq -= a.sizes[q];
+                K0 += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+                rem >>= a.sizes[q];
+            }
+        } else if (a.P == 1) {
+            in_base = out_base = 0;
+            in_row = out_row = 1;
+            in_col = 1;
+        } else {
+            const uint32_t s1 = a.sizes[0];
+            const uint32_t rest_log = a.S_prev - s1;  // bits of (k_2 .. k_(P-1))
+            const uint64_t k1_blocks = (1ull << s1) >> logC;
+            const uint64_t k1_0 = (tile % k1_blocks) << logC, rest = tile / k1_blocks;
+            in_base = ((k1_0 << rest_log) + rest) << s;
+            in_col = 1ull << (rest_log + s);
+            in_row = 1;
+            uint64_t rem = rest, Krest = 0;
+            uint32_t Sq = a.S_prev;
+            for (int q = (int)a.P - 2; q >= 1; q--) {
+                Sq -= a.sizes[q];
+                Krest += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+                rem >>= a.sizes[q];
+            }
+            K0 = k1_0 + Krest;
+            out_base = K0;
+            out_row = 1ull << a.S_prev;
+        }
+    }
+    // ---- stage the small tables ----------------------------------------------------------------------------
+    {
+        const F* w_small = reinterpret_cast<const F*>(a.w_small);
+        for (uint32_t i = tid; i < (R >> 1); i += NTT_THREADS) sh_w[i] = w_small[i];
+        if (!LAST && a.p > 1) {
+            const uint32_t shift = n_log - a.S_prev - s;  // N / M_p
+            for (uint32_t r = tid; r < R; r += NTT_THREADS) sh_row[r] = twiddle2(t_lo, t_hi, a.L, ((uint64_t)r * K0) << shift);
+        }
+    }
+    __syncthreads();
+    // ---- load (+ Montgomery entry, coset scaling, inter-factor twiddle) ------------------------------------
+    for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
+        uint32_t r, col;
+        if (LAST && a.P > 1) { r = idx & (R - 1); col = idx >> s; } else { col = idx & (C - 1); r = idx >> logC; }
+        const uint64_t m = in_base + (uint64_t)r * in_row + (uint64_t)col * in_col;
+        F x = in[m];
+        if (a.p == 1) {
+            if (a.to_mont) x = zl::to_mont(x);
+            if (a.pre_coset) x = zl::mul(x, twiddle2(reinterpret_cast<const F*>(a.g_lo), reinterpret_cast<const F*>(a.g_hi), a.L, m));
+        } else if (!LAST) {
+            x = zl::mul(x, sh_row[r]);
+        } else {
+            x = zl::mul(x, twiddle2(t_lo, t_hi, a.L, (uint64_t)r * (K0 + col)));
+        }
+        lds_store(sh, tile_pos(r, col, logC), x);
+    }
+    __syncthreads();
+    // ---- 2^s-point DIF butterflies in LDS (all C columns) --------------------------------------------------
+    for (uint32_t hl = s; hl-- > 0;) {
+        const uint32_t h = 1u << hl;
+        for (uint32_t q = tid; q < (R >> 1) * C; q += NTT_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t k = rr & (h - 1), blk = rr >> hl;
+            const uint32_t i = (blk << (hl + 1)) | k;
+            const uint32_t pu = tile_pos(i, col, logC), pv = tile_pos(i + h, col, logC);
+            const F u = lds_load<F>(sh, pu), v = lds_load<F>(sh, pv);
+            lds_store(sh, pu, zl::add(u, v));
+            F d = zl::sub(u, v);
+            if (k != 0) d = zl::mul(d, sh_w[k << (s - 1 - hl)]);
+            lds_store(sh, pv, d);
+        }
+        __syncthreads();
+    }
+    // ---- store: output row k sits at LDS row bitrev(k) ------------------------------------------------------
+    for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
+        const uint32_t col = idx & (C - 1), k = idx >> logC;
+        const uint32_t row = s ? (__brev(k) >> (32 - s)) : 0;
+        F x = lds_load<F>(sh, tile_pos(row, col, logC));
+        const uint64_t m = out_base + (uint64_t)k * out_row + col;
+        if (LAST) {
+            if (a.post_coset) {
+                x = zl::mul(x, twiddle2(reinterpret_cast<const F*>(a.g_lo), reinterpret_cast<const F*>(a.g_hi), a.L, m));
+            } else if (a.post_scale) {
+                F ni;
+#pragma unroll
+                for (int w = 0; w < F::N; w++) ni.l[w] = a.ninv[w];
+                x = zl::mul(x, ni);
+            }
+            if (a.from_mont) x = zl::from_mont(x);
+        }
+        out[m] = x;
+    }
+}
+
+// table[i] = scale * base^(i << shift), i < count
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_pow_table(Fp<FrP>* __restrict__ table, uint32_t count, uint32_t shift, Fp<FrP> base, Fp<FrP> scale) {
+    using F = Fp<FrP>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t e = (uint64_t)i << shift;
+    F acc = scale, b = base;
+    while (e) {
+        if (e & 1) acc = zl::mul(acc, b);
+        b = zl::sqr(b);
+        e >>= 1;
+    }
+    table[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ host driver
+struct NttPlan {
+    uint32_t P;
+    uint32_t sizes[4];
+};
+static NttPlan ntt_plan(unsigned n) {
+    NttPlan pl{};
+    if (n <= NTT_MAX_S) { pl.P = 1; pl.sizes[0] = n; return pl; }
+    uint32_t P = (n + 7) / 8;
+    if (P > 4) P = 4;
+    pl.P = P;
+    uint32_t rem = n;
+    for (uint32_t p = 0; p < P; p++) {
+        uint32_t s = (rem + (P - p) - 1) / (P - p);
+        pl.sizes[p] = s;
+        rem -= s;
+    }
+    return pl;
+}
+
+template <class FrP>
+static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twiddles** out) {
+    using F = Fp<FrP>;
+    const uint64_t key = ((uint64_t)curve << 16) | ((uint64_t)n << 1) | (inverse ? 1 : 0);
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) { *out = &it->second; return ZL_OK; }
+    // root of unity of order 2^n (host)
+    F w;
+    for (int i = 0; i < F::N; i++) w.l[i] = FrP::two_adic_root(i);
+    for (unsigned i = n; i < (unsigned)FrP::TWO_ADICITY; i++) w = zl::sqr(w);
+    F g;
+    for (int i = 0; i < F::N; i++) g.l[i] = FrP::generator(i);
+    F scale = F::one();
+    if (inverse) {
+        w = zl::inv(w);
+        g = zl::inv(g);
+        scale = zl::inv(zl::from_u64<FrP>(1ull << n));
+    }
+    zl_twiddles tw;
+    const unsigned L = (n + 1) / 2;
+    tw.lo_bits = L;
+    const uint32_t n_lo = 1u << L, n_hi = 1u << (n - L);
+    // layout: t_lo | t_hi | g_lo | g_hi | small tables for s = 1..NTT_MAX_S (2^(s-1) each)
+    const size_t small_total = (1u << NTT_MAX_S);
+    const size_t total = (size_t)2 * (n_lo + n_hi) + small_total;
+    F* d;
+    ZL_HIP(ctx, hipMalloc((void**)&d, total * sizeof(F)));
+    hipStream_t st = ctx->stream;
+    F* t_lo = d;
+    F* t_hi = t_lo + n_lo;
+    F* g_lo = t_hi + n_hi;
+    F* g_hi = g_lo + n_lo;
+    F* small = g_hi + n_hi;
+    const F one = F::one();
+    hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_lo + 255) / 256), dim3(256), 0, st, t_lo, n_lo, 0u, w, one);
+    hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_hi + 255) / 256), dim3(256), 0, st, t_hi, n_hi, L, w, one);
+    hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_lo + 255) / 256), dim3(256), 0, st, g_lo, n_lo, 0u, g, one);
+    hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_hi + 255) / 256), dim3(256), 0, st, g_hi, n_hi, L, g, scale);
+    // small[s] at offset 2^(s-1): w_(2^s)^i = w^(i << (n - s)), i < 2^(s-1)
+    for (unsigned s = 1; s <= NTT_MAX_S && s <= n; s++) {
+        const uint32_t cnt = 1u << (s - 1);
+        hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((cnt + 255) / 256), dim3(256), 0, st, small + cnt, cnt, n - s, w, one);
+    }
+    ZL_HIP(ctx, hipGetLastError());
+    tw.d_lo = t_lo;
+    tw.d_hi = t_hi;
+    tw.d_small = small;
+    ctx->twiddles[key] = tw;
+    *out = &ctx->twiddles[key];
+    return ZL_OK;
+}
+
+template <class FrP>
+static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned flags) {
+    using F = Fp<FrP>;
+    if (n > (unsigned)FrP::TWO_ADICITY || n > 30) return ZL_EINVAL;
+    const bool inverse = flags & ZL_INVERSE, coset = flags & ZL_COSET, mont = flags & ZL_MONT;
+    ctx->timing = zl_timing{};
+    if (n == 0) {
+        // one element: forward/inverse are the identity (n^-1 = 1, g^0 = 1)
+        return ZL_OK;
+    }
+    zl_twiddles* tw;
+    int rc;
+    if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw))) return rc;
+    const NttPlan pl = ntt_plan(n);
+    const size_t N = (size_t)1 << n;
+    F* data = reinterpret_cast<F*>(d_data);
+    F* scratch = nullptr;
+    if (pl.P > 1) {
+        void* p;
+        if ((rc = zl_scratch_get(ctx, 6, N * sizeof(F), &p))) return rc;
+        scratch = reinterpret_cast<F*>(p);
+    }
+    const unsigned L = tw->lo_bits;
+    const F* t_lo = reinterpret_cast<const F*>(tw->d_lo);
+    const F* t_hi = reinterpret_cast<const F*>(tw->d_hi);
+    const F* g_lo = t_hi + ((size_t)1 << (n - L));
+    const F* g_hi = g_lo + ((size_t)1 << L);
+    const F* small = reinterpret_cast<const F*>(tw->d_small);
+    F ninv = zl::inv(zl::from_u64<FrP>(1ull << n));
+    hipStream_t st = ctx->stream;
+    static bool attr_done = false;
+    if (!attr_done) {  // tiles + tables can exceed the 64 KiB default dynamic-LDS limit (gfx950 has 160 KiB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    uint32_t S_prev = 0;
+    for (uint32_t p = 1; p <= pl.P; p++) {
+        const bool last = p == pl.P;
+        NttArgs a{};
+        a.n_log = n;
+        a.s = pl.sizes[p - 1];
+        a.P = pl.P;
+        a.p = p;
+        for (int k = 0; k < 4; k++) a.sizes[k] = pl.sizes[k];
+        a.S_prev = S_prev;
+        a.L = L;
+        a.t_lo = t_lo;
+        a.t_hi = t_hi;
+        a.g_lo = g_lo;
+        a.g_hi = g_hi;
+        a.w_small = small + ((size_t)1 << (a.s ? a.s - 1 : 0));
+        a.to_mont = (p == 1 && !mont) ? 1 : 0;
+        a.pre_coset = (p == 1 && coset && !inverse) ? 1 : 0;
+        a.from_mont = (last && !mont) ? 1 : 0;
+        a.post_coset = (last && coset && inverse) ? 1 : 0;
+        a.post_scale = (last && inverse && !coset) ? 1 : 0;
+        for (int k = 0; k < 8; k++) a.ninv[k] = ninv.l[k];
+        // columns per tile
+        uint32_t cols_avail_log;
+        if (pl.P == 1) cols_avail_log = 0;
+        else if (!last) cols_avail_log = n - S_prev - a.s;
+        else cols_avail_log = pl.sizes[0];
+        uint32_t logC = 11 - a.s;  // NTT_TILE = 2^11
+        if (a.s > 11) return ZL_EINVAL;
+        if (logC > cols_avail_log) logC = cols_avail_log;
+        a.logC = logC;
+        const uint64_t tiles = (uint64_t)N >> (a.s + logC);
+        const size_t lds = (size_t)F::N * 4 * NTT_TILE + sizeof(F) * (((size_t)1 << a.s) / 2 + ((size_t)1 << a.s));
+        const F* src = (p == 1) ? data : scratch;
+        F* dst = last ? data : scratch;
+        if (last) hipLaunchKernelGGL((k_ntt_pass<FrP, true>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
+        else hipLaunchKernelGGL((k_ntt_pass<FrP, false>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
+        S_prev += a.s;
+    }
+    ZL_HIP(ctx, hipGetLastError());
+    if (ctx->timing_on) {
+        ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        ZL_HIP(ctx, hipStreamSynchronize(st));
+        ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing.dominant_ms = ctx->timing.total_ms;
+    }
+    ctx->timing.launches = pl.P;
+    return ZL_OK;
+}
+
+int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags) {
+    if (curve == ZL_BLS12_381) return ntt_run_t<BLS12_381_Fr>(ctx, curve, d_data, log_n, flags);
+    if (curve == ZL_BN254) return ntt_run_t<BN254_Fr>(ctx, curve, d_data, log_n, flags);
+    return ZL_EINVAL;
+}
+void zl_ntt_free(zl_ctx* ctx) {
+    for (auto& kv : ctx->twiddles) if (kv.second.d_lo) (void)hipFree(kv.second.d_lo);
+    ctx->twiddles.clear();
+}

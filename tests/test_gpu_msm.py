@@ -1,0 +1,157 @@
+"""GPU parity: zl_msm (HIP Pippenger) vs the CPU oracle, bit-exact on canonical affine coordinates."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import po
+from openzl_amd import ZL_G1, ZL_CHECK, ZL_MONT, BackendError
+
+pytestmark = pytest.mark.gpu
+CURVES = [po.BLS12_381, po.BN254]
+
+
+def _bases(curve, n, seed):
+    k = ol.random_scalars(curve, n, seed)
+    return k, ol.oracle_g1_mul_gen(curve, k)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 100, 1000, 4097])
+def test_msm_matches_oracle(backend, curve, n):
+    k, B = _bases(curve, n, 100 + n)
+    S = ol.random_scalars(curve, n, 200 + n)
+    h = backend.bases_upload(curve.cid, B)
+    got, inf = backend.msm(h, S)
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=8)
+    backend.bases_free(h)
+    assert inf == einf
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_window_independent(backend, curve, c):
+    n = 777
+    k, B = _bases(curve, n, 7)
+    S = ol.random_scalars(curve, n, 8)
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=8)
+    h = backend.bases_upload(curve.cid, B)
+    backend.set_msm_window(c)
+    try:
+        got, inf = backend.msm(h, S)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
+    assert inf == einf and (got == exp).all()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_edge_inputs(backend, curve):
+    """scalar 0 / 1 / r-1, infinity bases, repeated points, P and -P in one bucket, all scalars equal."""
+    n = 300
+    k, B = _bases(curve, n, 11)
+    S = ol.random_scalars(curve, n, 12)
+    r = curve.fr.p
+    S[0] = 0
+    S[1] = ol.ints_to_limbs([1], 4)[0]
+    S[2] = ol.ints_to_limbs([r - 1], 4)[0]
+    S[3] = ol.ints_to_limbs([1], 4)[0]
+    B[4] = 0  # infinity
+    B[5] = B[6]  # repeated point, same scalar -> doubling inside a bucket
+    S[5] = S[6]
+    # B[7] = -B[8] with equal scalars -> cancels inside a bucket
+    pt = ol.limbs_to_point(curve, B[8], 0)
+    B[7] = ol.points_to_limbs(curve, [po.g1_neg(curve, pt)])[0]
+    S[7] = S[8]
+    S[100:200] = S[100]  # many equal scalars -> one hot bucket per window
+    S[200:260] = 0
+    S[260:300] = ol.ints_to_limbs([1], 4)[0]
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=8)
+    naive, ninf = ol.oracle_msm_g1(curve, B, S, algo=1)
+    assert (exp == naive).all() and einf == ninf
+    h = backend.bases_upload(curve.cid, B)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    assert inf == einf and (got == exp).all()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_result_infinity(backend, curve):
+    k, B = _bases(curve, 2, 5)
+    B[1] = B[0]
+    r = curve.fr.p
+    S = ol.ints_to_limbs([5, r - 5], 4)
+    h = backend.bases_upload(curve.cid, B)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    assert inf == 1 and not got.any()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_bases_montgomery_upload_and_download(backend, curve):
+    n = 64
+    k, B = _bases(curve, n, 21)
+    Bm = np.zeros_like(B)
+    fid = 1 if curve.cid == 1 else 3
+    ol.lib().zlo_field_to_mont(fid, ol.p64(B.reshape(-1)), ol.p64(Bm.reshape(-1)), B.size // ol.nlq(curve))
+    h1 = backend.bases_upload(curve.cid, B, flags=ZL_CHECK)
+    h2 = backend.bases_upload(curve.cid, Bm, flags=ZL_MONT | ZL_CHECK)
+    assert (backend.bases_download(h1) == B).all()
+    assert (backend.bases_download(h2) == B).all()
+    S = ol.random_scalars(curve, n, 22)
+    a = backend.msm(h1, S)
+    b = backend.msm(h2, S)
+    assert (a[0] == b[0]).all()
+    backend.bases_free(h1)
+    backend.bases_free(h2)
+    # off-curve point is rejected when ZL_CHECK is set
+    bad = B.copy()
+    bad[3, 0] ^= np.uint64(1)
+    with pytest.raises(BackendError) as ei:
+        backend.bases_upload(curve.cid, bad, flags=ZL_CHECK)
+    assert ei.value.code == -6
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_bases_generate_matches_oracle(backend, curve):
+    n = 200
+    k = ol.random_scalars(curve, n, 31)
+    k[0] = 0
+    k[1] = ol.ints_to_limbs([1], 4)[0]
+    h = backend.bases_generate(curve.cid, k)
+    got = backend.bases_download(h)
+    backend.bases_free(h)
+    exp = ol.oracle_g1_mul_gen(curve, k)
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("curve,log_n", [(po.BLS12_381, 16), (po.BN254, 16), (po.BLS12_381, 20)], ids=["bls-2^16", "bn254-2^16", "bls-2^20"])
+def test_msm_known_discrete_log(backend, curve, log_n):
+    """Full-size exact check without a CPU MSM: P_i = k_i G  =>  MSM(s, P) = (sum s_i k_i) G."""
+    n = 1 << log_n
+    k = ol.random_scalars(curve, n, 41)
+    S = ol.random_scalars(curve, n, 42)
+    h = backend.bases_generate(curve.cid, k)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    r = curve.fr.p
+    ki, si = ol.limbs_to_ints(k), ol.limbs_to_ints(S)
+    dot = sum(a * b for a, b in zip(ki, si)) % r
+    exp = po.g1_mul(curve, dot, po.g1_generator(curve))
+    assert ol.limbs_to_point(curve, got, inf) == exp
+
+
+def test_msm_skewed_scalars_bls(backend):
+    """Groth16-witness-like distribution: 50% zeros, 25% ones, rest uniform (giant bucket path)."""
+    curve = po.BLS12_381
+    n = 1 << 16
+    k = ol.random_scalars(curve, n, 51)
+    S = ol.random_scalars(curve, n, 52)
+    S[: n // 2] = 0
+    S[n // 2: 3 * n // 4] = ol.ints_to_limbs([1], 4)[0]
+    h = backend.bases_generate(curve.cid, k)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    r = curve.fr.p
+    dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % r
+    assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
