@@ -1,0 +1,68 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/zl_backend.h declares, reports errors by
+code, and its host tail (zl_partials_sum: XYZZ fold + affine normalisation) matches the oracle.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import po
+from openzl_amd.backend import ABI_SYMBOLS, ZL_PARTIAL_WORDS, load_library
+from openzl_amd.sharded import fold_partials
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = load_library()
+    hdr = open(os.path.join(ROOT, "include", "zl_backend.h")).read()
+    declared = set(re.findall(r"^\s*(?:const char\*|int|void)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared, "header parse failed"
+    assert declared == set(ABI_SYMBOLS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+
+
+def test_strerror_and_argument_checks():
+    L = load_library()
+    assert L.zl_strerror(0) == b"ok"
+    assert L.zl_strerror(-5) == b"unknown bases handle"
+    assert L.zl_ctx_create(None, 0) == -1  # ZL_EINVAL
+    out = np.zeros(12, dtype=np.uint64)
+    inf = C.c_uint8(0)
+    assert L.zl_partials_sum(99, 1, None, 0, ol.p64(out), C.byref(inf)) == -1
+
+
+def _partial_from_affine(curve, pt):
+    """encode an affine point as the backend's XYZZ partial (Montgomery limbs, zz = zzz = R mod p)"""
+    n = curve.fq.limbs64
+    out = np.zeros(ZL_PARTIAL_WORDS, dtype=np.uint64)
+    if pt is None:
+        one = ol.ints_to_limbs([curve.fq.to_mont(1)], n)[0]
+        out[0:n], out[n:2 * n] = one, one  # x = y = 1, zz = zzz = 0
+        return out
+    vals = [curve.fq.to_mont(pt[0]), curve.fq.to_mont(pt[1]), curve.fq.to_mont(1), curve.fq.to_mont(1)]
+    for i, v in enumerate(vals):
+        out[i * n:(i + 1) * n] = ol.ints_to_limbs([v], n)[0]
+    return out
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_partials_sum_host_tail_matches_oracle(curve):
+    G = po.g1_generator(curve)
+    pts = [po.g1_mul(curve, k, G) for k in (5, 7, 11, 5)] + [None, po.g1_neg(curve, po.g1_mul(curve, 7, G))]
+    parts = np.stack([_partial_from_affine(curve, p) for p in pts])
+    xy, inf = fold_partials(curve.cid, parts)
+    exp = None
+    for p in pts:
+        exp = po.g1_add(curve, exp, p)
+    assert ol.limbs_to_point(curve, xy, inf) == exp == po.g1_mul(curve, 21, G)
+    # doubling inside the fold, cancellation to infinity, empty input
+    xy, inf = fold_partials(curve.cid, parts[[0, 3]])
+    assert ol.limbs_to_point(curve, xy, inf) == po.g1_mul(curve, 10, G)
+    xy, inf = fold_partials(curve.cid, parts[[1, 5]])
+    assert inf == 1 and not xy.any()
+    xy, inf = fold_partials(curve.cid, parts[:0])
+    assert inf == 1

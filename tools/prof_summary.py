@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / avg / min / max (us) + registers.
+    python tools/prof_summary.py gpurun_out/prof/x_results.db > profiles/rNN_name.txt"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(accum_vgpr_count), "
+        "max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc"
+    ).fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
+    print(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>11} {'max_us':>11} {'%':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7} {'scratch':>7} {'grid':>10} {'wg':>5}")
+    for r in rows:
+        name = r[0].split("(")[0].replace("void ", "")
+        print(f"{name:<70} {r[1]:>6} {r[2]/1e3:>12.1f} {r[3]/1e3:>11.1f} {r[4]/1e3:>11.1f} {r[5]/1e3:>11.1f} {100*r[2]/total:>6.2f} {r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>7} {r[11]:>10} {r[12]:>5}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
