@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libzl_backend.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
-HEADERS = ["zl_field.h", "zl_curve.h", "zl_params.h", "zl_ctx.h", os.path.join("..", "..", "include", "zl_backend.h")]
+HEADERS = ["zl_field.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_ctx.h", os.path.join("..", "..", "include", "zl_backend.h")]
 
 
 def _hipcc() -> str:

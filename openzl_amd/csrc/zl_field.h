@@ -16,6 +16,7 @@
 #define ZL_HD inline
 #endif
 #include "zl_params.h"
+#include "zl_mul_gfx950.h"
 
 template <class P>
 struct alignas(16) Fp {
@@ -155,6 +156,20 @@ ZL_HD Fp<P> mul_body(const Fp<P>& a, const Fp<P>& b) {
     reduce_once<P>(r.l);
     return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 multiplier: product-scanning (column-wise) Montgomery with a 96-bit column accumulator -------------
+// One MAC = v_mad_u64_u32 (64-bit accumulate, carry-out to VCC) + v_addc_co_u32 into the third word: no
+// zero-extension moves, no 64-bit adds.  Fully expanded by gen_mul.py (zl_mul_gfx950.h).
+template <class P>
+__device__ __forceinline__ Fp<P> mul_dev(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> out;
+    if constexpr (P::N == 8) mul_dev_8<P>(out.l, a.l, b.l);
+    else mul_dev_12<P>(out.l, a.l, b.l);
+    reduce_once<P>(out.l);
+    return out;
+}
+#endif
+
 // The multiplier is ONE out-of-line function per field (arguments and result travel in VGPRs on the device):
 // a fully inlined point addition is ~50 KB of code per call site, which overflows the instruction cache and
 // takes hipcc tens of minutes to schedule; a called 5 KB body stays I-cache resident.
@@ -165,11 +180,19 @@ ZL_HD Fp<P> mul_body(const Fp<P>& a, const Fp<P>& b) {
 #endif
 template <class P>
 ZL_NOINLINE_HD Fp<P> mul_call(Fp<P> a, Fp<P> b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_PORTABLE_MUL)
+    return mul_dev(a, b);
+#else
     return mul_body(a, b);
+#endif
 }
 template <class P>
 ZL_NOINLINE_HD Fp<P> sqr_call(Fp<P> a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_PORTABLE_MUL)
+    return mul_dev(a, a);
+#else
     return mul_body(a, a);
+#endif
 }
 template <class P>
 ZL_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {

@@ -155,24 +155,29 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t* __restric
     const uint32_t start = (uint32_t)start64;
     const uint32_t end = (uint32_t)min((uint64_t)E, start64 + ZL_CHUNK);
     uint32_t b = zl_upper_bound(offsets, NB + 1, start) - 1;  // bucket holding entry `start`
-    uint32_t pos = start;
-    while (pos < end) {
-        const uint32_t b_start = offsets[b], b_end = offsets[b + 1];
-        const uint32_t seg_end = min(b_end, end);
-        if (seg_end > pos) {
-            XYZZ<F> acc = XYZZ<F>::inf();
-            for (uint32_t e = pos; e < seg_end; e++) {
-                const uint32_t ent = entries[e];
-                const Affine<F> P = bases[ent & 0x7fffffffu];
-                if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+    uint32_t b_start = offsets[b], b_end = offsets[b + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    // ONE flat loop of exactly (end - start) mixed additions per lane: a per-segment inner loop would make the
+    // wave run max-over-lanes iterations per segment (measured 2.4x slower).  Bucket boundaries only flush.
+    for (uint32_t e = start; e < end; e++) {
+        while (e == b_end) {  // lane crosses into the next bucket (empty buckets: zero-length, skipped here)
+            if (b_end > b_start) {
+                if (b_start >= start) bucket_sums[b] = acc;  // bucket lies inside this chunk (b_end <= e < end)
+                else partials[(size_t)2 * t] = acc;          // head bucket started in an earlier chunk
+                acc = XYZZ<F>::inf();
             }
-            const bool complete = (b_start >= start) && (b_end <= end);
-            if (complete) bucket_sums[b] = acc;
-            else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
-            pos = seg_end;
+            b++;
+            b_start = b_end;
+            b_end = offsets[b + 1];
         }
-        b++;
+        const uint32_t ent = entries[e];
+        const Affine<F> P = bases[ent & 0x7fffffffu];
+        if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
     }
+    // last segment [max(b_start,start), end) of bucket b
+    const bool complete = (b_start >= start) && (b_end <= end);
+    if (complete) bucket_sums[b] = acc;
+    else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
 }
 
 // one lane per bucket: empty -> infinity; cut into <= ZL_BIG_SPAN chunks -> fold partials; else defer to a block
