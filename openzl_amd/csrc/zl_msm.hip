@@ -67,6 +67,85 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
     }
 }
 
+// ---- LDS counting sort (c <= 16): no global atomics -------------------------------------------------------------
+// k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
+//   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
+static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 lo = sp[0], hi = sp[1];
+    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const uint32_t H = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        const int pos = w * c;
+        const int word = pos >> 5, sh = pos & 31;
+        uint64_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {  // register-resident select instead of a dynamically indexed array
+            if (k == word) v |= s[k];
+            if (k == word + 1) v |= (uint64_t)s[k] << 32;
+        }
+        uint32_t d = ((uint32_t)(v >> sh) & ((1u << c) - 1)) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
+        digits[(size_t)w * n + i] = d == 0 ? (uint16_t)0xFFFF : (uint16_t)((neg << 15) | (d - 1));
+    }
+}
+// block (slice, w): private LDS histogram of window w over a slice of the scalars -> counts[slice][w*H + bin]
+static __global__ void __launch_bounds__(1024) k_msm_hist_lds(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t per_slice, uint32_t NB,
+                                                        uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
+    const uint16_t* dw = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t code = dw[i];
+        if (code != 0xFFFFu) atomicAdd(&hist[code & 0x7FFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = counts + (size_t)slice * NB + (size_t)w * H;
+    for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) out[b] = hist[b];
+}
+// lane per bucket: counts[slice][bucket] -> exclusive prefix over slices (in place), tot[bucket] = sum
+static __global__ void __launch_bounds__(256) k_msm_slice_prefix(uint32_t* __restrict__ counts, uint32_t NB, uint32_t nslices, uint32_t* __restrict__ tot) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    uint32_t run = 0;
+    for (uint32_t sl = 0; sl < nslices; sl++) {
+        const uint32_t v = counts[(size_t)sl * NB + b];
+        counts[(size_t)sl * NB + b] = run;
+        run += v;
+    }
+    tot[b] = run;
+}
+// block (slice, w): LDS cursors = bucket offset + this slice's prefix; scatter (index | sign << 31)
+static __global__ void __launch_bounds__(1024) k_msm_scatter_lds(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t per_slice, uint32_t NB,
+                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    const uint32_t* cs = counts + (size_t)slice * NB + (size_t)w * H;
+    const uint32_t* os = offsets + (size_t)w * H;
+    for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) cur[b] = os[b] + cs[b];
+    __syncthreads();
+    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
+    const uint16_t* dw = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t code = dw[i];
+        if (code != 0xFFFFu) {
+            const uint32_t pos = atomicAdd(&cur[code & 0x7FFFu], 1u);
+            entries[pos] = i | ((code >> 15) << 31);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan of `count` u32 values, 3 launches; out[count] = total
 #define SCAN_ITEMS 16
@@ -408,11 +487,39 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 4, st));
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
-        hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
-        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-        hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries);
+        if (c <= 16) {
+            // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, LDS-cursor scatter
+            uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
+            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+            if (nslices > max_slices) nslices = max_slices;
+            if (nslices < 1) nslices = 1;
+            const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
+            void* pd;
+            if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
+            uint16_t* d_digits = (uint16_t*)pd;
+            uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits);
+            hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
+            hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+            hipLaunchKernelGGL(k_msm_scatter_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts,
+                               d_offsets, d_entries);
+        } else {
+            // wide windows: histogram / scatter with global atomics
+            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries);
+        }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
