@@ -95,6 +95,37 @@ int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials
 int zl_ntt(zl_ctx* ctx, zl_curve_t curve, uint64_t* data, unsigned log_n, unsigned flags);
 int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags);
 
+/* ---- Groth16 prover (replaces ark_groth16::create_random_proof behind Groth16::<E>::prove, groth16.rs:445-457) - */
+/* R1CS in CSR form, as ark-relations' ConstraintMatrices hold it: variable order = instance block (index 0 is the
+ * constant ONE, then the public inputs) followed by the witness block; coefficients and assignment are canonical
+ * Fr integers, 4 u64 each.  [0] = A, [1] = B, [2] = C. */
+typedef struct zl_r1cs {
+    uint32_t n_constraints, n_instance, n_witness;
+    const uint32_t* row_ptr[3]; /* n_constraints + 1 entries */
+    const uint32_t* col[3];
+    const uint64_t* val[3];
+} zl_r1cs;
+/* Proving key = ark_groth16::ProvingKey<E> (ProvingContext<E>, groth16.rs:127-140): the five query vectors are
+ * device-resident bases handles (zl_bases_upload), the single points canonical affine host buffers. */
+typedef struct zl_g16_pk {
+    zl_curve_t curve;
+    uint64_t a_query, b_g1_query, h_query, l_query; /* ZL_G1 handles: m+1, m+1, N-1, n_witness points */
+    uint64_t b_g2_query;                            /* ZL_G2 handle: m+1 points */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1;  /* G1: x||y */
+    const uint64_t *beta_g2, *delta_g2;             /* G2: x.c0||x.c1||y.c0||y.c1 */
+} zl_g16_pk;
+typedef struct zl_g16_proof {
+    uint64_t a[12], b[24], c[12]; /* canonical affine A (G1), B (G2), C (G1); BN254 uses the first 8/16/8 words */
+    uint8_t a_inf, b_inf, c_inf;
+} zl_g16_proof;
+/* assignment: (n_instance + n_witness) x 4 u64 canonical (z = 1, public..., witness...); r, s: the two blinding
+ * scalars ark samples from the rng (explicit here so that proofs are reproducible, SURVEY.md §8 note N3).
+ * Runs witness_map (3 iFFT, 3 coset FFT, 1 coset iFFT on the device) and the 4 G1 + 1 G2 MSMs. */
+int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r,
+                     const uint64_t* s, zl_g16_proof* out);
+/* the quotient polynomial h of the last zl_groth16_prove call (N x 4 u64 canonical), for tests */
+int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n);
+
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
 typedef struct zl_timing {
     float total_ms;      /* first kernel start -> last kernel end of the last zl_msm* / zl_ntt* call */

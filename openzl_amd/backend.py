@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h",
 ]
 
 
@@ -37,6 +37,21 @@ class BackendError(RuntimeError):
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("dominant_ms", C.c_float), ("launches", C.c_uint32), ("window_bits", C.c_uint32),
                 ("entries", C.c_uint64)]
+
+
+class R1csC(C.Structure):
+    _fields_ = [("n_constraints", C.c_uint32), ("n_instance", C.c_uint32), ("n_witness", C.c_uint32),
+                ("row_ptr", C.POINTER(C.c_uint32) * 3), ("col", C.POINTER(C.c_uint32) * 3), ("val", u64p * 3)]
+
+
+class G16PkC(C.Structure):
+    _fields_ = [("curve", C.c_int), ("a_query", C.c_uint64), ("b_g1_query", C.c_uint64), ("h_query", C.c_uint64), ("l_query", C.c_uint64),
+                ("b_g2_query", C.c_uint64), ("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p), ("beta_g2", u64p), ("delta_g2", u64p)]
+
+
+class G16ProofC(C.Structure):
+    _fields_ = [("a", C.c_uint64 * 12), ("b", C.c_uint64 * 24), ("c", C.c_uint64 * 12), ("a_inf", C.c_uint8), ("b_inf", C.c_uint8),
+                ("c_inf", C.c_uint8)]
 
 
 _lib = None
@@ -74,6 +89,8 @@ def load_library(path: Optional[str] = None):
     L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
     L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.zl_groth16_prove.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(R1csC), u64p, u64p, u64p, C.POINTER(G16ProofC)]
+    L.zl_groth16_last_h.argtypes = [vp, u64p, C.c_size_t]
     if path is None:
         _lib = L
     return L
@@ -204,3 +221,43 @@ class Backend:
     def ntt_dev(self, curve: int, d_data: int, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = True):
         flags = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0) | (ZL_MONT if mont else 0)
         self._check(self.L.zl_ntt_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags), "zl_ntt_dev")
+
+    # ---- Groth16 ----------------------------------------------------------------------------------------------
+    def groth16_prove(self, curve: int, pk: dict, r1cs: dict, assignment: np.ndarray, r: np.ndarray, s: np.ndarray):
+        """pk: {'a_query','b_g1_query','h_query','l_query','b_g2_query': handles, 'alpha_g1','beta_g1','delta_g1','beta_g2',
+        'delta_g2': uint64 arrays}; r1cs: {'n_constraints','n_instance','n_witness', 'A'/'B'/'C': (ptr u32, col u32, val (nnz,4) u64)}.
+        Returns (a, a_inf, b, b_inf, c, c_inf) as canonical affine limb arrays."""
+        cs = R1csC()
+        cs.n_constraints, cs.n_instance, cs.n_witness = r1cs["n_constraints"], r1cs["n_instance"], r1cs["n_witness"]
+        keep = []
+        for m, key in enumerate("ABC"):
+            ptr, col, val = r1cs[key]
+            ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val = np.ascontiguousarray(val, dtype=np.uint64)
+            keep += [ptr, col, val]
+            cs.row_ptr[m] = ptr.ctypes.data_as(C.POINTER(C.c_uint32))
+            cs.col[m] = col.ctypes.data_as(C.POINTER(C.c_uint32))
+            cs.val[m] = val.ctypes.data_as(u64p)
+        pkc = G16PkC()
+        pkc.curve = curve
+        for k in ("a_query", "b_g1_query", "h_query", "l_query", "b_g2_query"):
+            setattr(pkc, k, pk[k])
+        for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
+            arr = np.ascontiguousarray(pk[k], dtype=np.uint64)
+            keep.append(arr)
+            setattr(pkc, k, arr.ctypes.data_as(u64p))
+        proof = G16ProofC()
+        z = np.ascontiguousarray(assignment, dtype=np.uint64)
+        self._check(self.L.zl_groth16_prove(self._ctx, C.byref(pkc), C.byref(cs), _p64(z), _p64(np.ascontiguousarray(r)),
+                                            _p64(np.ascontiguousarray(s)), C.byref(proof)), "zl_groth16_prove")
+        nq = FQ_LIMBS[curve]
+        a = np.array(proof.a[: 2 * nq], dtype=np.uint64)
+        b = np.array(proof.b[: 4 * nq], dtype=np.uint64)
+        c = np.array(proof.c[: 2 * nq], dtype=np.uint64)
+        return a, proof.a_inf, b, proof.b_inf, c, proof.c_inf
+
+    def groth16_last_h(self, n: int) -> np.ndarray:
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._check(self.L.zl_groth16_last_h(self._ctx, _p64(out), n), "zl_groth16_last_h")
+        return out

@@ -88,9 +88,10 @@ struct zl_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<uint64_t, zl_bases> bases;
     uint64_t next_handle = 1;
-    zl_scratch scratch[8];
+    zl_scratch scratch[10];
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
-    void* d_coset[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 7)
+    size_t g16_h_n = 0;
 };
 
 // grow-only device scratch slot

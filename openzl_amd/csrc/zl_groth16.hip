@@ -1,0 +1,227 @@
+// zl_groth16.hip -- Groth16 prover on the device: QAP witness map (NTT block) + the five MSMs + host assembly.
+//
+// Replaces ark_groth16::create_random_proof / create_proof_with_assignment + R1CStoQAP::witness_map (ark-groth16 0.3.0)
+// behind `Groth16::<E>::prove` (/root/reference/plugins/arkworks/src/groth16.rs:445-457):
+//   a_i = <A_i,z>, b_i = <B_i,z>, c_i = <C_i,z>; a[n_constraints + j] = z[j] for the instance block
+//   a,b,c <- coset_fft(ifft(.)); ab = (a o b - c) / (g^N - 1); h = coset_ifft(ab)
+//   A = r*delta1 + a_query[0] + MSM(a_query[1..], z[1..]) + alpha1      (B1 in G1, B2 in G2 likewise with s, beta)
+//   C = s*A + r*B1 - r*s*delta1 + MSM(l_query, z_wit) + MSM(h_query, h[..N-1])
+// The R1CS arrives already synthesised (the reference moves a pre-built constraint system into arkworks the same way,
+// plugins/arkworks/src/constraint/mod.rs:179-197); sparse mat-vec, pointwise ops and Montgomery entry/exit are small
+// elementwise kernels around zl_ntt_run / zl_msm_run; the window Horner and the final few group operations run on host.
+#include <string.h>
+#include <vector>
+#include "zl_ctx.h"
+
+template <class FrP>
+__global__ void __launch_bounds__(256) k_fr_to_mont(Fp<FrP>* __restrict__ v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = zl::to_mont(v[i]);
+}
+template <class FrP>
+__global__ void __launch_bounds__(256) k_fr_from_mont(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = zl::from_mont(in[i]);
+}
+// out[row] = sum_k val[k] * z[col[k]]  (Montgomery); rows >= n_rows: out[n_rows + j] = z[j] for j < tail (A only), else 0
+template <class FrP>
+__global__ void __launch_bounds__(256) k_r1cs_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ col, const Fp<FrP>* __restrict__ val,
+                                                    const Fp<FrP>* __restrict__ z, uint32_t n_rows, uint32_t tail, uint32_t N,
+                                                    Fp<FrP>* __restrict__ out) {
+    using F = Fp<FrP>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    F acc = F::zero();
+    if (i < n_rows) {
+        for (uint32_t k = ptr[i]; k < ptr[i + 1]; k++) acc = zl::add(acc, zl::mul(val[k], z[col[k]]));
+    } else if (i - n_rows < tail) {
+        acc = z[i - n_rows];
+    }
+    out[i] = acc;
+}
+// a = (a*b - c) * zinv
+template <class FrP>
+__global__ void __launch_bounds__(256) k_qap_pointwise(Fp<FrP>* __restrict__ a, const Fp<FrP>* __restrict__ b, const Fp<FrP>* __restrict__ c,
+                                                        Fp<FrP> zinv, uint32_t N) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) a[i] = zl::mul(zl::sub(zl::mul(a[i], b[i]), c[i]), zinv);
+}
+
+template <class G>
+static XYZZ<typename G::F> affine_from_canon(const uint64_t* xy) {
+    using F = typename G::F;
+    Affine<F> a;
+    memcpy(&a.x, xy, sizeof(F));
+    memcpy(&a.y, reinterpret_cast<const unsigned char*>(xy) + sizeof(F), sizeof(F));
+    if (a.is_inf()) return XYZZ<F>::inf();
+    a.x = zl::to_mont(a.x);
+    a.y = zl::to_mont(a.y);
+    return XYZZ<F>::from_affine(a);
+}
+template <class G>
+static void store_canon(uint64_t* out_xy, uint8_t* out_inf, const XYZZ<typename G::F>& p) {
+    using F = typename G::F;
+    Affine<F> a = zl::to_affine(p);
+    *out_inf = p.is_inf() ? 1 : 0;
+    if (!p.is_inf()) { a.x = zl::from_mont(a.x); a.y = zl::from_mont(a.y); }
+    memcpy(out_xy, &a.x, sizeof(F));
+    memcpy(reinterpret_cast<unsigned char*>(out_xy) + sizeof(F), &a.y, sizeof(F));
+}
+template <class F>
+static XYZZ<F> from_partial(const uint64_t* partial) {
+    XYZZ<F> p;
+    memcpy(&p, partial, sizeof p);
+    return p;
+}
+
+template <class G1, class G2>
+static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
+                           zl_g16_proof* out) {
+    using FrP = typename G1::FrP;
+    using Fr = Fp<FrP>;
+    using F1 = typename G1::F;
+    using F2 = typename G2::F;
+    const uint32_t nc = cs->n_constraints, ni = cs->n_instance, nw = cs->n_witness;
+    const uint64_t nv64 = (uint64_t)ni + nw;
+    if (ni < 1 || nv64 >= (1ull << 31)) return ZL_EINVAL;
+    const uint32_t nv = (uint32_t)nv64;
+    unsigned log_n = 1;
+    while ((1ull << log_n) < (uint64_t)nc + ni) log_n++;
+    if (log_n > (unsigned)FrP::TWO_ADICITY || log_n > 28) return ZL_EINVAL;
+    const uint32_t N = 1u << log_n;
+    // handles
+    const uint64_t hs[5] = {pk->a_query, pk->b_g1_query, pk->h_query, pk->l_query, pk->b_g2_query};
+    const zl_bases* bs[5];
+    for (int i = 0; i < 5; i++) {
+        auto it = ctx->bases.find(hs[i]);
+        if (it == ctx->bases.end()) return ZL_EHANDLE;
+        if (it->second.curve != (int)pk->curve || it->second.group != (i == 4 ? ZL_G2 : ZL_G1)) return ZL_EHANDLE;
+        bs[i] = &it->second;
+    }
+    if (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw) return ZL_EINVAL;
+
+    hipStream_t st = ctx->stream;
+    if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    // ---- stage R1CS + assignment on the device -------------------------------------------------------------------
+    size_t nnz[3], off_ptr[3], off_col[3], off_val[3];
+    size_t bytes = 0;
+    auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) / 256 * 256; return o; };
+    for (int m = 0; m < 3; m++) {
+        nnz[m] = cs->row_ptr[m][nc];
+        off_ptr[m] = take((size_t)(nc + 1) * 4);
+        off_col[m] = take(nnz[m] * 4);
+        off_val[m] = take(nnz[m] * 32);
+    }
+    const size_t off_zc = take((size_t)nv * 32), off_zm = take((size_t)nv * 32);
+    const size_t off_a = take((size_t)N * 32), off_b = take((size_t)N * 32), off_c = take((size_t)N * 32), off_h = take((size_t)N * 32);
+    void* base;
+    int rc;
+    if ((rc = zl_scratch_get(ctx, 8, bytes, &base))) return rc;  // slots 0-7 belong to the MSM / NTT / staging paths
+    unsigned char* d = reinterpret_cast<unsigned char*>(base);
+    for (int m = 0; m < 3; m++) {
+        ZL_HIP(ctx, hipMemcpyAsync(d + off_ptr[m], cs->row_ptr[m], (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, st));
+        if (nnz[m]) {
+            ZL_HIP(ctx, hipMemcpyAsync(d + off_col[m], cs->col[m], nnz[m] * 4, hipMemcpyHostToDevice, st));
+            ZL_HIP(ctx, hipMemcpyAsync(d + off_val[m], cs->val[m], nnz[m] * 32, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((uint32_t)((nnz[m] + 255) / 256)), dim3(256), 0, st, (Fr*)(d + off_val[m]), (uint32_t)nnz[m]);
+        }
+    }
+    Fr* d_zc = (Fr*)(d + off_zc);
+    Fr* d_zm = (Fr*)(d + off_zm);
+    ZL_HIP(ctx, hipMemcpyAsync(d_zc, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
+    ZL_HIP(ctx, hipMemcpyAsync(d_zm, d_zc, (size_t)nv * 32, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, nv);
+    Fr *d_a = (Fr*)(d + off_a), *d_b = (Fr*)(d + off_b), *d_c = (Fr*)(d + off_c), *d_h = (Fr*)(d + off_h);
+    Fr* dv[3] = {d_a, d_b, d_c};
+    for (int m = 0; m < 3; m++)
+        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, (const uint32_t*)(d + off_ptr[m]), (const uint32_t*)(d + off_col[m]),
+                           (const Fr*)(d + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+    ZL_HIP(ctx, hipGetLastError());
+    // ---- witness map: 3 x (ifft, coset fft), pointwise, coset ifft --------------------------------------------------
+    const int timing_saved = ctx->timing_on;
+    ctx->timing_on = 0;  // inner calls must not sync / overwrite the prover's events
+    for (int m = 0; m < 3; m++) {
+        if ((rc = zl_ntt_run(ctx, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) { ctx->timing_on = timing_saved; return rc; }
+        if ((rc = zl_ntt_run(ctx, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) { ctx->timing_on = timing_saved; return rc; }
+    }
+    Fr g;
+    for (int i = 0; i < Fr::N; i++) g.l[i] = FrP::generator(i);
+    Fr gN = g;
+    for (unsigned i = 0; i < log_n; i++) gN = zl::sqr(gN);
+    const Fr zinv = zl::inv(zl::sub(gN, Fr::one()));
+    hipLaunchKernelGGL((k_qap_pointwise<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, d_a, d_b, d_c, zinv, N);
+    if ((rc = zl_ntt_run(ctx, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE | ZL_COSET))) { ctx->timing_on = timing_saved; return rc; }
+    hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, d_a, d_h, N);
+    ZL_HIP(ctx, hipGetLastError());
+    // ---- the five MSMs ----------------------------------------------------------------------------------------------
+    uint64_t part[5][ZL_PARTIAL_WORDS];
+    const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
+    rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[2], 0, d_h, (size_t)N - 1, part[2]);
+    if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[3], 0, zc + (size_t)ni * 32, nw, part[3]);
+    if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[0], 1, zc + 32, nv - 1, part[0]);
+    if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[1], 1, zc + 32, nv - 1, part[1]);
+    if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G2, zl_msm_run, ctx, *bs[4], 1, zc + 32, nv - 1, part[4]);
+    ctx->timing_on = timing_saved;
+    if (rc) return rc;
+    // first points of the a / b queries (index 0 pairs with z[0] = 1)
+    uint64_t a0_xy[12], b0_xy[12], b20_xy[24];
+    if ((rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_bases_download, ctx, *bs[0], 0, 1, a0_xy))) return rc;
+    if ((rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_bases_download, ctx, *bs[1], 0, 1, b0_xy))) return rc;
+    if ((rc = ZL_DISPATCH(pk->curve, ZL_G2, zl_bases_download, ctx, *bs[4], 0, 1, b20_xy))) return rc;
+    if (ctx->timing_on) {
+        ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        ZL_HIP(ctx, hipStreamSynchronize(st));
+        ctx->timing = zl_timing{};
+        ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[1]));
+        ctx->timing.launches = 5;
+    }
+    ctx->g16_h = d_h;
+    ctx->g16_h_n = N;
+    // ---- host assembly (a few hundred group operations) ---------------------------------------------------------------
+    uint32_t rw[8], sw[8];
+    memcpy(rw, r, 32);
+    memcpy(sw, s, 32);
+    const XYZZ<F1> delta1 = affine_from_canon<G1>(pk->delta_g1);
+    const XYZZ<F2> delta2 = affine_from_canon<G2>(pk->delta_g2);
+    XYZZ<F1> g_a = zl::mul_scalar(delta1, rw);
+    zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
+    zl::add_full(g_a, from_partial<F1>(part[0]));
+    zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
+    XYZZ<F1> g1_b = zl::mul_scalar(delta1, sw);
+    zl::add_full(g1_b, affine_from_canon<G1>(b0_xy));
+    zl::add_full(g1_b, from_partial<F1>(part[1]));
+    zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
+    XYZZ<F2> g2_b = zl::mul_scalar(delta2, sw);
+    zl::add_full(g2_b, affine_from_canon<G2>(b20_xy));
+    zl::add_full(g2_b, from_partial<F2>(part[4]));
+    zl::add_full(g2_b, affine_from_canon<G2>(pk->beta_g2));
+    XYZZ<F1> g_c = zl::mul_scalar(g_a, sw);
+    zl::add_full(g_c, zl::mul_scalar(g1_b, rw));
+    XYZZ<F1> rs_delta = zl::mul_scalar(zl::mul_scalar(delta1, rw), sw);
+    rs_delta.y = zl::neg(rs_delta.y);
+    zl::add_full(g_c, rs_delta);
+    zl::add_full(g_c, from_partial<F1>(part[3]));
+    zl::add_full(g_c, from_partial<F1>(part[2]));
+    memset(out, 0, sizeof *out);
+    store_canon<G1>(out->a, &out->a_inf, g_a);
+    store_canon<G2>(out->b, &out->b_inf, g2_b);
+    store_canon<G1>(out->c, &out->c_inf, g_c);
+    return ZL_OK;
+}
+
+extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
+                                zl_g16_proof* out) {
+    if (!ctx || !pk || !cs || !assignment || !r || !s || !out) return ZL_EINVAL;
+    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
+    for (int m = 0; m < 3; m++) if (!cs->row_ptr[m] || (cs->row_ptr[m][cs->n_constraints] && (!cs->col[m] || !cs->val[m]))) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, cs, assignment, r, s, out);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, cs, assignment, r, s, out);
+    return ZL_EINVAL;
+}
+extern "C" int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n) {
+    if (!ctx || !out || !ctx->g16_h || n > ctx->g16_h_n) return ZL_EINVAL;
+    ZL_HIP(ctx, hipMemcpyAsync(out, ctx->g16_h, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZL_OK;
+}

@@ -548,3 +548,278 @@ def from_limbs(limbs: Sequence[int]) -> int:
     for i, l in enumerate(limbs):
         v |= int(l) << (64 * i)
     return v
+
+
+# --------------------------------------------------------------------------------------------
+# R1CS + Groth16 (config 5).  Restates ark-groth16 0.3.0 (third-party, not vendored; pinned
+# plugins/arkworks/Cargo.toml:113; reached from plugins/arkworks/src/groth16.rs:438 `circuit_specific_setup`
+# and :454 `prove`): R1CStoQAP::witness_map, generate_parameters (with an explicit, KNOWN trapdoor so that
+# every proof element can also be recomputed in the exponent) and
+# create_proof_with_assignment.  Circuit synthesis is CPU-side in the reference too
+# (plugins/arkworks/src/constraint/mod.rs:64-108,179-197).
+# --------------------------------------------------------------------------------------------
+
+
+class LC:
+    """linear combination sum coeff*var; variables are ('i', k) instance (k = 0 is the constant ONE) or ('w', k)."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, terms=None):
+        self.t = dict(terms or {})
+
+    @staticmethod
+    def const(v: int) -> "LC":
+        return LC({("i", 0): v}) if v else LC()
+
+    def is_const(self) -> bool:
+        return all(k == ("i", 0) for k in self.t)
+
+    def add(self, o: "LC", p: int) -> "LC":
+        r = dict(self.t)
+        for k, v in o.t.items():
+            nv = (r.get(k, 0) + v) % p
+            if nv:
+                r[k] = nv
+            else:
+                r.pop(k, None)
+        return LC(r)
+
+    def scale(self, c: int, p: int) -> "LC":
+        c %= p
+        return LC({k: v * c % p for k, v in self.t.items()}) if c else LC()
+
+
+class R1CS:
+    """A*z o B*z = C*z with z = (1, public..., witness...) -- the layout ark-relations hands to ark-groth16."""
+
+    def __init__(self, field: FieldParams):
+        self.f = field
+        self.pub = [1]  # instance assignment, index 0 = ONE
+        self.wit: List[int] = []
+        self.A: List[LC] = []
+        self.B: List[LC] = []
+        self.C: List[LC] = []
+
+    def new_public(self, value: int) -> LC:
+        self.pub.append(value % self.f.p)
+        return LC({("i", len(self.pub) - 1): 1})
+
+    def new_witness(self, value: int) -> LC:
+        self.wit.append(value % self.f.p)
+        return LC({("w", len(self.wit) - 1): 1})
+
+    def value(self, lc: LC) -> int:
+        p = self.f.p
+        acc = 0
+        for (kind, k), c in lc.t.items():
+            acc += c * (self.pub[k] if kind == "i" else self.wit[k])
+        return acc % p
+
+    def enforce(self, a: LC, b: LC, c: LC):
+        self.A.append(a)
+        self.B.append(b)
+        self.C.append(c)
+
+    def mul(self, a: LC, b: LC) -> LC:
+        """allocate out = a*b (one constraint); constants fold without a constraint"""
+        p = self.f.p
+        if a.is_const():
+            return b.scale(self.value(a), p)
+        if b.is_const():
+            return a.scale(self.value(b), p)
+        out = self.new_witness(self.value(a) * self.value(b))
+        self.enforce(a, b, out)
+        return out
+
+    # -- shape as arkworks reports it
+    @property
+    def n_constraints(self) -> int:
+        return len(self.A)
+
+    @property
+    def n_instance(self) -> int:
+        return len(self.pub)
+
+    @property
+    def n_witness(self) -> int:
+        return len(self.wit)
+
+    def var_index(self, key) -> int:
+        return key[1] if key[0] == "i" else self.n_instance + key[1]
+
+    def assignment(self) -> List[int]:
+        return list(self.pub) + list(self.wit)
+
+    def is_satisfied(self) -> bool:
+        p = self.f.p
+        return all(self.value(a) * self.value(b) % p == self.value(c) for a, b, c in zip(self.A, self.B, self.C))
+
+    def csr(self, which: str):
+        rows = {"A": self.A, "B": self.B, "C": self.C}[which]
+        ptr, col, val = [0], [], []
+        for lc in rows:
+            for k in sorted(lc.t, key=self.var_index):
+                col.append(self.var_index(k))
+                val.append(lc.t[k])
+            ptr.append(len(col))
+        return ptr, col, val
+
+    def domain_log(self) -> int:
+        need = self.n_constraints + self.n_instance
+        return max(1, (need - 1).bit_length())
+
+
+def poseidon_hash_gadget(cs: R1CS, x: LC, y: LC, keys, mds, rf: int = 8, rp: int = 55) -> LC:
+    """In-circuit Poseidon arity-2 hash: state (2^arity - 1, x, y), tutorial/hasher schedule
+    (openzl-crypto/src/poseidon/hash.rs:93-104,123-135, mod.rs:229-282; plugin ops
+    plugins/arkworks/src/poseidon/mod.rs:225-298: add/add_const/mul_const are linear (0 constraints),
+    apply_sbox = x^5 = 3 multiplication constraints).  Returns lane 0."""
+    p = cs.f.p
+    t = 3
+    state = [LC.const(3), x, y]
+    half = rf // 2
+    for rnd in range(rf + rp):
+        k = keys[rnd * t:(rnd + 1) * t]
+        state = [s.add(LC.const(kk), p) for s, kk in zip(state, k)]
+        lanes = range(t) if (rnd < half or rnd >= half + rp) else range(1)
+        for i in lanes:
+            v = state[i]
+            x2 = cs.mul(v, v)
+            x4 = cs.mul(x2, x2)
+            state[i] = cs.mul(x4, v)
+        nxt = []
+        for i in range(t):
+            acc = LC()
+            for j in range(t):
+                acc = acc.add(state[j].scale(mds[i][j], p), p)
+            nxt.append(acc)
+        state = nxt
+    return state[0]
+
+
+def poseidon_chain_circuit(field: FieldParams, k: int, x0: int = 1, x1: int = 2) -> R1CS:
+    """config 5: h_1 = H(x0, x1), h_{j+1} = H(h_j, x1); public input = h_k."""
+    cs = R1CS(field)
+    keys = poseidon_round_constants(field, 3, 8, 55)
+    mds = poseidon_mds(field, 3)
+    expected = x0 % field.p
+    for _ in range(k):
+        expected = poseidon_permute(field, [3, expected, x1])[0]
+    out_pub = cs.new_public(expected)  # publics are allocated first (instance block precedes witnesses)
+    a = cs.new_witness(x0)
+    b = cs.new_witness(x1)
+    h = a
+    for _ in range(k):
+        h = poseidon_hash_gadget(cs, h, b, keys, mds)
+    cs.enforce(h, LC.const(1), out_pub)
+    assert cs.value(h) == expected
+    return cs
+
+
+def qap_witness_map(c: CurveParams, cs: R1CS) -> List[int]:
+    """ark-groth16 0.3.0 R1CStoQAP::witness_map (SURVEY.md App. B): h coefficients, N of them."""
+    r = c.fr.p
+    n = 1 << cs.domain_log()
+    z = cs.assignment()
+    a = [0] * n
+    b = [0] * n
+    cc = [0] * n
+    for i in range(cs.n_constraints):
+        a[i] = cs.value(cs.A[i])
+        b[i] = cs.value(cs.B[i])
+        cc[i] = cs.value(cs.C[i])
+    for j in range(cs.n_instance):
+        a[cs.n_constraints + j] = z[j]
+    a = ntt(c, ntt(c, a, inverse=True), coset=True)
+    b = ntt(c, ntt(c, b, inverse=True), coset=True)
+    cc = ntt(c, ntt(c, cc, inverse=True), coset=True)
+    zinv = pow(pow(c.fr_generator, n, r) - 1, -1, r)  # vanishing polynomial on the coset is the constant g^n - 1
+    ab = [((x * y - w) % r) * zinv % r for x, y, w in zip(a, b, cc)]
+    return ntt(c, ab, inverse=True, coset=True)
+
+
+def lagrange_at(c: CurveParams, log_n: int, tau: int) -> List[int]:
+    """evaluate_all_lagrange_coefficients(tau) for tau outside the domain: L_j = Z(tau)/n * w^j / (tau - w^j)"""
+    r = c.fr.p
+    n = 1 << log_n
+    w = domain_root(c, log_n)
+    zt = (pow(tau, n, r) - 1) % r
+    ninv = pow(n, -1, r)
+    out = []
+    wj = 1
+    for _ in range(n):
+        out.append(zt * ninv % r * wj % r * pow((tau - wj) % r, -1, r) % r)
+        wj = wj * w % r
+    return out
+
+
+@dataclass
+class Groth16Trapdoor:
+    alpha: int
+    beta: int
+    gamma: int
+    delta: int
+    tau: int
+
+
+def groth16_setup_exponents(c: CurveParams, cs: R1CS, td: Groth16Trapdoor):
+    """ark-groth16 0.3.0 generate_parameters in the exponent: discrete logs (w.r.t. the G1 / G2 generators) of
+    every proving-key element.  Returns dict of lists / scalars (all mod r)."""
+    r = c.fr.p
+    log_n = cs.domain_log()
+    n = 1 << log_n
+    L = lagrange_at(c, log_n, td.tau)
+    nv = cs.n_instance + cs.n_witness
+    u = [0] * nv
+    v = [0] * nv
+    w = [0] * nv
+    for j in range(cs.n_instance):
+        u[j] = L[cs.n_constraints + j]
+    for row in range(cs.n_constraints):
+        for k, coef in cs.A[row].t.items():
+            i = cs.var_index(k)
+            u[i] = (u[i] + coef * L[row]) % r
+        for k, coef in cs.B[row].t.items():
+            i = cs.var_index(k)
+            v[i] = (v[i] + coef * L[row]) % r
+        for k, coef in cs.C[row].t.items():
+            i = cs.var_index(k)
+            w[i] = (w[i] + coef * L[row]) % r
+    zt = (pow(td.tau, n, r) - 1) % r
+    dinv = pow(td.delta, -1, r)
+    ginv = pow(td.gamma, -1, r)
+    comb = [(td.beta * u[i] + td.alpha * v[i] + w[i]) % r for i in range(nv)]
+    h = []
+    tp = 1
+    for _ in range(n - 1):
+        h.append(zt * dinv % r * tp % r)
+        tp = tp * td.tau % r
+    return {
+        "a_query": u, "b_query": v,
+        "h_query": h,
+        "l_query": [comb[i] * dinv % r for i in range(cs.n_instance, nv)],
+        "gamma_abc": [comb[i] * ginv % r for i in range(cs.n_instance)],
+        "u": u, "v": v, "w": w, "zt": zt, "n": n,
+    }
+
+
+def groth16_prove_exponents(c: CurveParams, cs: R1CS, td: Groth16Trapdoor, ex, h: Sequence[int], r_: int, s_: int):
+    """Discrete logs of the proof (A in G1, B in G2, C in G1) per create_proof_with_assignment."""
+    r = c.fr.p
+    z = cs.assignment()
+    nv = len(z)
+    A = (td.alpha + sum(z[i] * ex["u"][i] for i in range(nv)) + r_ * td.delta) % r
+    B = (td.beta + sum(z[i] * ex["v"][i] for i in range(nv)) + s_ * td.delta) % r
+    l_acc = sum(z[cs.n_instance + i] * ex["l_query"][i] for i in range(cs.n_witness)) % r
+    h_acc = sum(hj * q for hj, q in zip(h, ex["h_query"])) % r
+    C = (s_ * A + r_ * B - r_ * s_ % r * td.delta + l_acc + h_acc) % r
+    return A, B, C
+
+
+def groth16_check_exponents(c: CurveParams, cs: R1CS, td: Groth16Trapdoor, ex, A: int, B: int, C: int) -> bool:
+    """the Groth16 pairing equation e(A,B) = e(alpha,beta) e(sum pub, gamma) e(C, delta), in the exponent"""
+    r = c.fr.p
+    z = cs.assignment()
+    pub = sum(z[i] * ex["gamma_abc"][i] for i in range(cs.n_instance)) % r
+    return (A * B - td.alpha * td.beta - pub * td.gamma - C * td.delta) % r == 0

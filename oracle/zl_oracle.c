@@ -372,3 +372,5 @@ int zlo_poseidon3(const uint64_t *keys, const uint64_t *mds, int rf, int rp, uin
     for (int i = 0; i < 3; i++) blsr_to_canon(state + 4 * i, &s[i]);
     return 0;
 }
+
+#include "zl_oracle_groth16.inc"

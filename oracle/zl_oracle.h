@@ -58,6 +58,28 @@ int zlo_ntt(int curve, uint64_t *data, unsigned log_n, int inverse, int coset, i
  * keys (3*(rf+rp) canonical), mds (9 canonical, row-major), state 3 canonical in/out. */
 int zlo_poseidon3(const uint64_t *keys, const uint64_t *mds, int rf, int rp, uint64_t *state);
 
+/* ---- Groth16 prove (ark-groth16 0.3.0 create_proof_with_assignment + R1CStoQAP::witness_map) ----------------
+ * R1CS in CSR form (A, B, C), variable order = instance block (index 0 is the constant ONE) then witnesses;
+ * coefficients and assignment canonical 4 x u64.  Proving key as host arrays of canonical affine points. */
+typedef struct zlo_r1cs {
+    uint32_t n_constraints, n_instance, n_witness;
+    const uint32_t *row_ptr[3];
+    const uint32_t *col[3];
+    const uint64_t *val[3];
+} zlo_r1cs;
+typedef struct zlo_g16_pk {
+    const uint64_t *a_query, *b_g1_query, *h_query, *l_query; /* G1: x||y */
+    const uint64_t *b_g2_query;                               /* G2: x.c0||x.c1||y.c0||y.c1 */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1, *beta_g2, *delta_g2;
+} zlo_g16_pk;
+typedef struct zlo_g16_proof {
+    uint64_t a[12], b[24], c[12]; /* canonical affine, sized for BLS12-381 (BN254 uses the prefix) */
+    uint8_t a_inf, b_inf, c_inf;
+    uint64_t *h_out; /* optional: N x 4 u64 quotient coefficients (witness_map output), may be NULL */
+} zlo_g16_proof;
+int zlo_groth16_prove(int curve, const zlo_r1cs *cs, const uint64_t *assignment, const zlo_g16_pk *pk, const uint64_t *r,
+                      const uint64_t *s, int threads, zlo_g16_proof *out);
+
 #ifdef __cplusplus
 }
 #endif

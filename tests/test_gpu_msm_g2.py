@@ -1,0 +1,54 @@
+"""GPU parity: G2 MSM (Fq2 coordinates; the 5th MSM of every Groth16 prove) vs the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import groth16_util as gu
+import oracle_lib as ol
+from oracle_lib import po
+from openzl_amd import ZL_G2, ZL_CHECK
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_msm_g2(curve, bases, scalars, threads=8):
+    out = np.zeros(4 * ol.nlq(curve), dtype=np.uint64)
+    inf = C.c_uint8(0)
+    assert ol.lib().zlo_msm_g2(curve.cid, ol.p64(bases), 0, ol.p64(scalars), scalars.shape[0], 0, threads, ol.p64(out), C.byref(inf)) == 0
+    return out, inf.value
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [1, 33, 500, 3000])
+def test_msm_g2_matches_oracle(backend, curve, n):
+    ks = ol.limbs_to_ints(ol.random_scalars(curve, n, 300 + n))
+    B = gu.g2_mul_gen(curve, ks)
+    S = ol.random_scalars(curve, n, 400 + n)
+    if n > 10:
+        S[0] = 0
+        S[1] = ol.ints_to_limbs([1], 4)[0]
+        S[2] = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]
+        B[3] = 0        # infinity base
+        B[5] = B[4]     # doubling inside a bucket
+        S[5] = S[4]
+    h = backend.bases_upload(curve.cid, B, group=ZL_G2, flags=ZL_CHECK)
+    got, inf = backend.msm(h, S)
+    assert (backend.bases_download(h, 0, min(n, 8)) == B[: min(n, 8)]).all()
+    backend.bases_free(h)
+    exp, einf = _oracle_msm_g2(curve, B, S)
+    assert inf == einf and (got == exp).all()
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_g2_generate_and_known_discrete_log(backend, curve):
+    n = 1 << 12
+    k = ol.random_scalars(curve, n, 61)
+    S = ol.random_scalars(curve, n, 62)
+    h = backend.bases_generate(curve.cid, k, group=ZL_G2)
+    first = backend.bases_download(h, 0, 4)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    assert (first == gu.g2_mul_gen(curve, ol.limbs_to_ints(k[:4]))).all()
+    dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % curve.fr.p
+    assert inf == 0 and (got == gu.g2_mul_gen(curve, [dot])[0]).all()
