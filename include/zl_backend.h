@@ -126,6 +126,28 @@ int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const 
 /* the quotient polynomial h of the last zl_groth16_prove call (N x 4 u64 canonical), for tests */
 int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n);
 
+/* ---- host mirror of the plugin interface (C hooks over the C++ classes of openzl_amd/csrc/zl_host.h) ------------
+ * openzl::R1CS<F> / poseidon gadget / Groth16<E>::{compile, prove} restated in C++ (the reference is Rust; no Rust
+ * toolchain here).  These hooks let a C / ctypes caller drive them; a C++ caller uses the classes directly. */
+typedef struct zl_circuit zl_circuit;   /* an R1CS<F> compiler in proof mode holding the config-5 circuit */
+typedef struct zl_g16_keys zl_g16_keys; /* Groth16<E>::ProvingContext (+ the setup trapdoor, kept for exponent checks) */
+/* k chained Poseidon arity-2 hashes over the curve's Fr: h_1 = H(x0,x1), h_{j+1} = H(h_j,x1), public input h_k */
+int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out);
+void zl_circuit_free(zl_circuit* c);
+/* CSR view + assignment (pointers stay valid until zl_circuit_free) */
+int zl_circuit_export(const zl_circuit* c, zl_r1cs* view, const uint64_t** assignment);
+int zl_circuit_is_satisfied(const zl_circuit* c); /* 1 / 0 */
+/* native Poseidon permutation, width 3 (tutorial schedule): state = 3 x 4 u64 canonical, in place */
+int zl_poseidon_permute(zl_curve_t curve, uint64_t* state);
+/* Groth16::compile with rng = SplitMix64(seed): trapdoor setup, proving key generated on the device */
+int zl_groth16_compile(zl_ctx* ctx, const zl_circuit* c, uint64_t seed, zl_g16_keys** out);
+void zl_groth16_keys_free(zl_g16_keys* k);
+int zl_groth16_keys_pk(const zl_g16_keys* k, zl_g16_pk* pk);
+int zl_groth16_keys_trapdoor(const zl_g16_keys* k, uint64_t* out20); /* alpha, beta, gamma, delta, tau (canonical) */
+/* Groth16::prove with rng = SplitMix64(seed); r_out / s_out (optional) receive the sampled blinding scalars */
+int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* c, uint64_t seed, zl_g16_proof* proof,
+                             uint64_t* r_out, uint64_t* s_out);
+
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
 typedef struct zl_timing {
     float total_ms;      /* first kernel start -> last kernel end of the last zl_msm* / zl_ntt* call */

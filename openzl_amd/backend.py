@@ -24,7 +24,9 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
+    "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit",
 ]
 
 
@@ -91,6 +93,18 @@ def load_library(path: Optional[str] = None):
     L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.zl_groth16_prove.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(R1csC), u64p, u64p, u64p, C.POINTER(G16ProofC)]
     L.zl_groth16_last_h.argtypes = [vp, u64p, C.c_size_t]
+    L.zl_circuit_poseidon_chain.argtypes = [C.c_int, C.c_uint32, u64p, u64p, C.POINTER(vp)]
+    L.zl_circuit_free.argtypes = [vp]
+    L.zl_circuit_free.restype = None
+    L.zl_circuit_export.argtypes = [vp, C.POINTER(R1csC), C.POINTER(u64p)]
+    L.zl_circuit_is_satisfied.argtypes = [vp]
+    L.zl_poseidon_permute.argtypes = [C.c_int, u64p]
+    L.zl_groth16_compile.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.zl_groth16_keys_free.argtypes = [vp]
+    L.zl_groth16_keys_free.restype = None
+    L.zl_groth16_keys_pk.argtypes = [vp, C.POINTER(G16PkC)]
+    L.zl_groth16_keys_trapdoor.argtypes = [vp, u64p]
+    L.zl_groth16_prove_circuit.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(G16ProofC), u64p, u64p]
     if path is None:
         _lib = L
     return L
@@ -261,3 +275,110 @@ class Backend:
         out = np.zeros((n, 4), dtype=np.uint64)
         self._check(self.L.zl_groth16_last_h(self._ctx, _p64(out), n), "zl_groth16_last_h")
         return out
+
+
+# ---- host mirror (openzl::R1CS / poseidon / Groth16<E>, csrc/zl_host.h) through its C hooks ---------------------------
+def poseidon_permute(curve: int, state: np.ndarray) -> np.ndarray:
+    """native width-3 Poseidon permutation on canonical (3,4) uint64 limbs (host code, no GPU)."""
+    st = np.ascontiguousarray(state.copy(), dtype=np.uint64)
+    rc = load_library().zl_poseidon_permute(curve, _p64(st))
+    if rc:
+        raise BackendError(rc, "zl_poseidon_permute")
+    return st
+
+
+class Circuit:
+    """R1CS<F> compiler in proof mode holding the config-5 Poseidon-chain circuit (host code, no GPU)."""
+
+    def __init__(self, curve: int, k: int, x0: int = 1, x1: int = 2):
+        self.L = load_library()
+        self.curve = curve
+        self._c = C.c_void_p()
+        a = np.array([[(x0 >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64)
+        b = np.array([[(x1 >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64)
+        rc = self.L.zl_circuit_poseidon_chain(curve, k, _p64(a), _p64(b), C.byref(self._c))
+        if rc:
+            raise BackendError(rc, "zl_circuit_poseidon_chain")
+        self._view = R1csC()
+        zp = u64p()
+        self.L.zl_circuit_export(self._c, C.byref(self._view), C.byref(zp))
+        self._zp = zp
+
+    @property
+    def shape(self):
+        return self._view.n_constraints, self._view.n_instance, self._view.n_witness
+
+    def is_satisfied(self) -> bool:
+        return self.L.zl_circuit_is_satisfied(self._c) == 1
+
+    def arrays(self) -> dict:
+        """copy the CSR view + assignment into numpy (same dict layout Backend.groth16_prove takes)"""
+        v = self._view
+        out = {"n_constraints": v.n_constraints, "n_instance": v.n_instance, "n_witness": v.n_witness}
+        for m, key in enumerate("ABC"):
+            ptr = np.ctypeslib.as_array(v.row_ptr[m], shape=(v.n_constraints + 1,)).copy()
+            nnz = int(ptr[-1])
+            col = np.ctypeslib.as_array(v.col[m], shape=(max(nnz, 1),))[:nnz].copy()
+            val = np.ctypeslib.as_array(v.val[m], shape=(max(nnz, 1) * 4,))[: nnz * 4].copy().reshape(nnz, 4)
+            out[key] = (ptr, col, val)
+        nv = v.n_instance + v.n_witness
+        out["assignment"] = np.ctypeslib.as_array(self._zp, shape=(nv * 4,)).copy().reshape(nv, 4)
+        return out
+
+    def close(self):
+        if self._c:
+            self.L.zl_circuit_free(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Groth16Keys:
+    """Groth16<E>::compile result (ProvingContext on the device)."""
+
+    def __init__(self, backend: Backend, circuit: Circuit, seed: int):
+        self.L = backend.L
+        self.backend = backend
+        self.circuit = circuit
+        self._k = C.c_void_p()
+        backend._check(self.L.zl_groth16_compile(backend._ctx, circuit._c, seed, C.byref(self._k)), "zl_groth16_compile")
+        self.pk = G16PkC()
+        self.L.zl_groth16_keys_pk(self._k, C.byref(self.pk))
+        n_c, n_i, n_w = circuit.shape
+        nv = n_i + n_w
+        log_n = max(1, (n_c + n_i - 1).bit_length())
+        for name, cnt, grp in (("a_query", nv, ZL_G1), ("b_g1_query", nv, ZL_G1), ("h_query", (1 << log_n) - 1, ZL_G1), ("l_query", n_w, ZL_G1),
+                               ("b_g2_query", nv, ZL_G2)):
+            backend._bases[getattr(self.pk, name)] = (circuit.curve, grp, cnt)  # so Backend.bases_download works on them
+
+    def trapdoor(self):
+        out = np.zeros((5, 4), dtype=np.uint64)
+        self.L.zl_groth16_keys_trapdoor(self._k, _p64(out))
+        return [sum(int(v) << (64 * j) for j, v in enumerate(row)) for row in out]
+
+    def pk_dict(self) -> dict:
+        nq = FQ_LIMBS[self.circuit.curve]
+        d = {k: getattr(self.pk, k) for k in ("a_query", "b_g1_query", "h_query", "l_query", "b_g2_query")}
+        for k, n in (("alpha_g1", 2 * nq), ("beta_g1", 2 * nq), ("delta_g1", 2 * nq), ("beta_g2", 4 * nq), ("delta_g2", 4 * nq)):
+            d[k] = np.ctypeslib.as_array(getattr(self.pk, k), shape=(n,)).copy()
+        return d
+
+    def prove(self, seed: int):
+        """Groth16::prove(context, compiler, rng=SplitMix64(seed)) -> ((a, a_inf, b, b_inf, c, c_inf), r, s)"""
+        proof = G16ProofC()
+        r = np.zeros(4, dtype=np.uint64)
+        s = np.zeros(4, dtype=np.uint64)
+        self.backend._check(self.L.zl_groth16_prove_circuit(self.backend._ctx, self._k, self.circuit._c, seed, C.byref(proof), _p64(r), _p64(s)),
+                            "zl_groth16_prove_circuit")
+        nq = FQ_LIMBS[self.circuit.curve]
+        return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,
+                np.array(proof.c[: 2 * nq], dtype=np.uint64), proof.c_inf), r, s
+
+    def close(self):
+        if self._k:
+            self.L.zl_groth16_keys_free(self._k)
+            self._k = C.c_void_p()

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libzl_backend.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
-HEADERS = ["zl_field.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_ctx.h", os.path.join("..", "..", "include", "zl_backend.h")]
+HEADERS = ["zl_field.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_ctx.h", "zl_host.h", os.path.join("..", "..", "include", "zl_backend.h")]
 
 
 def _hipcc() -> str:
@@ -34,7 +34,7 @@ def _digest(paths, extra="") -> str:
 
 
 def _units():
-    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", []), ("zl_groth16", "zl_groth16.hip", [])]
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", []), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
     for g in GROUPS:
         units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"]))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]

@@ -1,0 +1,353 @@
+// zl_host.h -- host-side mirror (C++) of the reference's plugin interface for the Groth16 path, above the C ABI.
+//
+// The reference is Rust; this image has no Rust toolchain, so the operator/plugin surface that sits on top of the
+// accelerated path is restated in C++ with the reference's names and argument meaning:
+//   openzl::R1CS<F>            plugins/arkworks/src/constraint/mod.rs:64-108 (compiler wrapping a constraint system;
+//                              for_contexts :84-90, for_proofs :94-99, Measure :147-177, allocation :210-338)
+//   openzl::FpVar<F>           ark-r1cs-std FpVar as the plugin uses it: linear ops cost no constraint, mul costs one
+//   openzl::poseidon::*        openzl-crypto/src/poseidon (lfsr.rs:14-100, round_constants.rs:10-59, mds.rs:84-102,
+//                              mod.rs:193-282, hash.rs:93-135) + plugin Spec ops plugins/arkworks/src/poseidon/mod.rs:225-298
+//   openzl::Groth16<E>         plugins/arkworks/src/groth16.rs:399-467: context_compiler / proof_compiler / compile /
+//                              prove / verify with ProvingContext / VerifyingContext / Proof / Error
+// Only what config 5 (Poseidon-hash circuit) needs is built; everything else of the gadget stack is out of scope.
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
+#include "zl_ctx.h"
+
+namespace openzl {
+
+// ---- deterministic rng handed to compile / prove (the reference passes `&mut R: CryptoRng + RngCore`) ----------------
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+};
+// uniform field element: fill limbs, mask to MODULUS_BITS, reject >= p (ark UniformRand for Fp; canonical here)
+template <class FrP>
+Fp<FrP> sample_canonical(SplitMix64& rng) {
+    for (;;) {
+        Fp<FrP> v;
+        for (int i = 0; i < FrP::N; i += 2) {
+            uint64_t w = rng.next();
+            v.l[i] = (uint32_t)w;
+            v.l[i + 1] = (uint32_t)(w >> 32);
+        }
+        const int top_bits = FrP::BITS - 32 * (FrP::N - 1);
+        if (top_bits < 32) v.l[FrP::N - 1] &= (1u << top_bits) - 1;
+        bool lt = false;
+        for (int i = FrP::N - 1; i >= 0; i--) {
+            if (v.l[i] < FrP::mod(i)) { lt = true; break; }
+            if (v.l[i] > FrP::mod(i)) break;
+        }
+        if (lt) return v;
+    }
+}
+
+// ---- linear combinations / variables ----------------------------------------------------------------------------------
+// variable key: bit 31 = witness block, low bits = index inside the block; instance index 0 is the constant ONE
+static constexpr uint32_t kWitnessBit = 0x80000000u;
+static constexpr uint32_t kOne = 0;
+
+template <class FrP>
+struct LinearCombination {
+    using F = Fp<FrP>;
+    std::vector<std::pair<uint32_t, F>> terms;  // sorted by key, no zero coefficients
+    static LinearCombination constant(const F& c) {
+        LinearCombination r;
+        if (!c.is_zero()) r.terms.push_back({kOne, c});
+        return r;
+    }
+    static LinearCombination variable(uint32_t key) {
+        LinearCombination r;
+        r.terms.push_back({key, F::one()});
+        return r;
+    }
+    bool is_constant() const { return terms.empty() || (terms.size() == 1 && terms[0].first == kOne); }
+    LinearCombination add(const LinearCombination& o) const {
+        LinearCombination r;
+        r.terms.reserve(terms.size() + o.terms.size());
+        size_t i = 0, j = 0;
+        while (i < terms.size() || j < o.terms.size()) {
+            if (j == o.terms.size() || (i < terms.size() && terms[i].first < o.terms[j].first)) r.terms.push_back(terms[i++]);
+            else if (i == terms.size() || o.terms[j].first < terms[i].first) r.terms.push_back(o.terms[j++]);
+            else {
+                F s = zl::add(terms[i].second, o.terms[j].second);
+                if (!s.is_zero()) r.terms.push_back({terms[i].first, s});
+                i++;
+                j++;
+            }
+        }
+        return r;
+    }
+    LinearCombination scale(const F& c) const {
+        LinearCombination r;
+        if (c.is_zero()) return r;
+        r.terms.reserve(terms.size());
+        for (auto& t : terms) r.terms.push_back({t.first, zl::mul(t.second, c)});
+        return r;
+    }
+};
+
+template <class FrP>
+struct FpVar {
+    using F = Fp<FrP>;
+    LinearCombination<FrP> lc;
+    F value;  // Montgomery; meaningful in proof mode only
+};
+
+// ---- R1CS<F>: the plugin's compiler (constraint/mod.rs:64-108) -----------------------------------------------------------
+template <class FrP>
+class R1CS {
+public:
+    using F = Fp<FrP>;
+    using LC = LinearCombination<FrP>;
+    enum class Mode { Setup, Prove };
+    static R1CS for_contexts() { return R1CS(Mode::Setup); }  // SynthesisMode::Setup (constraint/mod.rs:84-90)
+    static R1CS for_proofs() { return R1CS(Mode::Prove); }    // SynthesisMode::Prove (constraint/mod.rs:94-99)
+
+    // allocation: Public -> instance variable (new_input), Secret -> witness (new_witness) (constraint/mod.rs:302-338)
+    FpVar<FrP> new_input(const F& value_mont) {
+        instance_.push_back(value_mont);
+        return FpVar<FrP>{LC::variable((uint32_t)instance_.size() - 1), value_mont};
+    }
+    FpVar<FrP> new_witness(const F& value_mont) {
+        witness_.push_back(value_mont);
+        return FpVar<FrP>{LC::variable(kWitnessBit | ((uint32_t)witness_.size() - 1)), value_mont};
+    }
+    FpVar<FrP> constant(const F& c_mont) const { return FpVar<FrP>{LC::constant(c_mont), c_mont}; }
+    // linear operations: no constraints (plugins/arkworks/src/poseidon/mod.rs:225-274)
+    FpVar<FrP> add(const FpVar<FrP>& a, const FpVar<FrP>& b) const { return FpVar<FrP>{a.lc.add(b.lc), zl::add(a.value, b.value)}; }
+    FpVar<FrP> add_const(const FpVar<FrP>& a, const F& c) const { return FpVar<FrP>{a.lc.add(LC::constant(c)), zl::add(a.value, c)}; }
+    FpVar<FrP> mul_const(const FpVar<FrP>& a, const F& c) const { return FpVar<FrP>{a.lc.scale(c), zl::mul(a.value, c)}; }
+    // multiplication: one constraint a * b = out with a fresh witness; constants fold
+    FpVar<FrP> mul(const FpVar<FrP>& a, const FpVar<FrP>& b) {
+        if (a.lc.is_constant()) return mul_const(b, a.value);
+        if (b.lc.is_constant()) return mul_const(a, b.value);
+        FpVar<FrP> out = new_witness(zl::mul(a.value, b.value));
+        A_.push_back(a.lc);
+        B_.push_back(b.lc);
+        C_.push_back(out.lc);
+        return out;
+    }
+    void enforce_equal(const FpVar<FrP>& a, const FpVar<FrP>& b) {  // a * 1 = b
+        A_.push_back(a.lc);
+        B_.push_back(LC::constant(F::one()));
+        C_.push_back(b.lc);
+    }
+    // Measure (openzl-crypto/src/constraint.rs:151-188; plugin impl constraint/mod.rs:169-177)
+    size_t constraint_count() const { return A_.size(); }
+    size_t public_variable_count() const { return instance_.size() - 1; }
+    size_t secret_variable_count() const { return witness_.size(); }
+    size_t num_instance_variables() const { return instance_.size(); }  // ark: includes the constant ONE
+    Mode mode() const { return mode_; }
+
+    F eval(const LC& lc) const {
+        F acc = F::zero();
+        for (auto& t : lc.terms) {
+            const F& v = (t.first & kWitnessBit) ? witness_[t.first & ~kWitnessBit] : instance_[t.first];
+            acc = zl::add(acc, zl::mul(t.second, v));
+        }
+        return acc;
+    }
+    bool is_satisfied() const {
+        for (size_t i = 0; i < A_.size(); i++)
+            if (zl::mul(eval(A_[i]), eval(B_[i])) != eval(C_[i])) return false;
+        return true;
+    }
+    uint32_t var_index(uint32_t key) const { return (key & kWitnessBit) ? (uint32_t)instance_.size() + (key & ~kWitnessBit) : key; }
+    const std::vector<LC>& rows(int m) const { return m == 0 ? A_ : m == 1 ? B_ : C_; }
+    const std::vector<F>& instance_assignment() const { return instance_; }
+    const std::vector<F>& witness_assignment() const { return witness_; }
+
+private:
+    explicit R1CS(Mode m) : mode_(m) { instance_.push_back(F::one()); }
+    Mode mode_;
+    std::vector<F> instance_, witness_;
+    std::vector<LC> A_, B_, C_;
+};
+
+// ---- Poseidon (config 5) ------------------------------------------------------------------------------------------------------
+namespace poseidon {
+// 80-bit Grain LFSR in self-shrinking mode (openzl-crypto/src/poseidon/lfsr.rs:14-100)
+class GrainLFSR {
+public:
+    GrainLFSR(unsigned modulus_bits, unsigned width, unsigned rf, unsigned rp) {
+        for (auto& b : state_) b = false;
+        head_ = 0;
+        append(2, 1);
+        append(4, 0);
+        append(12, modulus_bits);
+        append(12, width);
+        append(10, rf);
+        append(10, rp);
+        append(30, (1u << 30) - 1);
+        for (int i = 0; i < 160; i++) update();
+    }
+    bool next() {
+        bool bit = update();
+        while (!bit) {
+            update();
+            bit = update();
+        }
+        return update();
+    }
+
+private:
+    bool state_[80];
+    unsigned head_;
+    void append(unsigned n, uint64_t bits) {
+        for (int i = (int)n - 1; i >= 0; i--) set_next((bits >> i) & 1);
+    }
+    bool set_next(bool b) {
+        state_[head_] = b;
+        head_ = (head_ + 1) % 80;
+        return b;
+    }
+    bool bit(unsigned i) const { return state_[(i + head_) % 80]; }
+    bool update() { return set_next(bit(62) ^ bit(51) ^ bit(38) ^ bit(23) ^ bit(13) ^ bit(0)); }
+};
+
+template <class FrP>
+struct Constants {
+    using F = Fp<FrP>;
+    static constexpr int WIDTH = 3, FULL_ROUNDS = 8, PARTIAL_ROUNDS = 55;  // arity 2 (plugins/arkworks/src/poseidon/mod.rs:300-304)
+    std::vector<F> round_keys;  // WIDTH * (RF + RP), Montgomery
+    F mds[WIDTH][WIDTH];
+    Constants() {
+        // generate_round_constants: MODULUS_BITS bits big-endian per candidate, rejection (round_constants.rs:10-59)
+        GrainLFSR lfsr(FrP::BITS, WIDTH, FULL_ROUNDS, PARTIAL_ROUNDS);
+        while ((int)round_keys.size() < WIDTH * (FULL_ROUNDS + PARTIAL_ROUNDS)) {
+            F v = F::zero();
+            for (int b = FrP::BITS - 1; b >= 0; b--)
+                if (lfsr.next()) v.l[b >> 5] |= 1u << (b & 31);
+            bool lt = false;
+            for (int i = FrP::N - 1; i >= 0; i--) {
+                if (v.l[i] < FrP::mod(i)) { lt = true; break; }
+                if (v.l[i] > FrP::mod(i)) break;
+            }
+            if (lt) round_keys.push_back(zl::to_mont(v));
+        }
+        // generate_mds: M[i][j] = 1 / (i + (t + j)) (mds.rs:84-102)
+        for (int i = 0; i < WIDTH; i++)
+            for (int j = 0; j < WIDTH; j++) mds[i][j] = zl::inv(zl::from_u64<FrP>((uint64_t)(i + WIDTH + j)));
+    }
+};
+// native permutation (openzl-tutorials/src/poseidon.rs:165-222 schedule; COM = ())
+template <class FrP>
+void permute_native(const Constants<FrP>& c, Fp<FrP> state[3]) {
+    using F = Fp<FrP>;
+    const int half = c.FULL_ROUNDS / 2;
+    for (int rnd = 0; rnd < c.FULL_ROUNDS + c.PARTIAL_ROUNDS; rnd++) {
+        for (int i = 0; i < 3; i++) state[i] = zl::add(state[i], c.round_keys[3 * rnd + i]);
+        const int lanes = (rnd < half || rnd >= half + c.PARTIAL_ROUNDS) ? 3 : 1;
+        for (int i = 0; i < lanes; i++) {
+            F x2 = zl::sqr(state[i]), x4 = zl::sqr(x2);
+            state[i] = zl::mul(x4, state[i]);
+        }
+        F nx[3];
+        for (int i = 0; i < 3; i++) {
+            F acc = zl::mul(c.mds[i][0], state[0]);
+            acc = zl::add(acc, zl::mul(c.mds[i][1], state[1]));
+            nx[i] = zl::add(acc, zl::mul(c.mds[i][2], state[2]));
+        }
+        for (int i = 0; i < 3; i++) state[i] = nx[i];
+    }
+}
+// in-circuit arity-2 hash (Hasher::hash, hash.rs:123-135): state = (2^arity - 1, x, y), output = lane 0
+template <class FrP>
+FpVar<FrP> hash(const Constants<FrP>& c, const FpVar<FrP>& x, const FpVar<FrP>& y, R1CS<FrP>& compiler) {
+    using V = FpVar<FrP>;
+    V state[3] = {compiler.constant(zl::from_u64<FrP>(3)), x, y};
+    const int half = c.FULL_ROUNDS / 2;
+    for (int rnd = 0; rnd < c.FULL_ROUNDS + c.PARTIAL_ROUNDS; rnd++) {
+        for (int i = 0; i < 3; i++) state[i] = compiler.add_const(state[i], c.round_keys[3 * rnd + i]);
+        const int lanes = (rnd < half || rnd >= half + c.PARTIAL_ROUNDS) ? 3 : 1;
+        for (int i = 0; i < lanes; i++) {  // apply_sbox = x^5 (plugins/arkworks/src/poseidon/mod.rs:287-298)
+            V x2 = compiler.mul(state[i], state[i]);
+            V x4 = compiler.mul(x2, x2);
+            state[i] = compiler.mul(x4, state[i]);
+        }
+        V nx[3];
+        for (int i = 0; i < 3; i++) {
+            V acc = compiler.mul_const(state[0], c.mds[i][0]);
+            acc = compiler.add(acc, compiler.mul_const(state[1], c.mds[i][1]));
+            nx[i] = compiler.add(acc, compiler.mul_const(state[2], c.mds[i][2]));
+        }
+        for (int i = 0; i < 3; i++) state[i] = nx[i];
+    }
+    return state[0];
+}
+}  // namespace poseidon
+
+// ---- pairing-engine configs ---------------------------------------------------------------------------------------------------
+struct Bls12_381 {
+    using FrP = BLS12_381_Fr;
+    using G1 = BlsG1;
+    using G2 = BlsG2;
+    static constexpr zl_curve_t curve = ZL_BLS12_381;
+};
+struct Bn254 {
+    using FrP = BN254_Fr;
+    using G1 = BnG1;
+    using G2 = BnG2;
+    static constexpr zl_curve_t curve = ZL_BN254;
+};
+
+// ---- Groth16<E>: ProofSystem (groth16.rs:405-467) -------------------------------------------------------------------------------
+struct Error {
+    int code;  // the reference's Error is an opaque unit struct (groth16.rs:35-45); the code is extra, for diagnostics
+};
+template <class T>
+struct Result {
+    bool ok;
+    T value;
+    Error error;
+};
+
+template <class E>
+struct Groth16 {
+    using FrP = typename E::FrP;
+    using F = Fp<FrP>;
+    using Compiler = R1CS<FrP>;
+    struct Trapdoor { F alpha, beta, gamma, delta, tau; };  // canonical
+    struct ProvingContext {                                 // ProvingContext<E>(pub ProvingKey<E>) groth16.rs:127-140
+        zl_ctx* ctx = nullptr;
+        uint64_t a_query = 0, b_g1_query = 0, h_query = 0, l_query = 0, b_g2_query = 0;
+        std::vector<uint64_t> alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2;
+        size_t n_instance = 0, n_witness = 0, domain_size = 0;
+        Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it
+    };
+    struct VerifyingContext {  // PreparedVerifyingKey in the reference (groth16.rs:181-186); pairing verifier is row f4 (not built)
+        std::vector<F> gamma_abc_exponents;
+    };
+    using Input = std::vector<F>;
+    using Proof = zl_g16_proof;
+
+    static Compiler context_compiler() { return Compiler::for_contexts(); }  // groth16.rs:418-420
+    static Compiler proof_compiler() { return Compiler::for_proofs(); }      // groth16.rs:423-425
+    static Result<std::pair<ProvingContext, VerifyingContext>> compile(zl_ctx* ctx, const Compiler& compiler, SplitMix64& rng);
+    static Result<Proof> prove(const ProvingContext& context, const Compiler& compiler, SplitMix64& rng, F* r_out = nullptr, F* s_out = nullptr);
+    static Result<bool> verify(const VerifyingContext&, const Input&, const Proof&) { return {false, false, Error{ZL_EINVAL}}; }
+    static void release(ProvingContext& context);
+};
+
+// CSR export of a compiler (what ark hands to the prover as ConstraintMatrices + assignments)
+template <class FrP>
+struct R1csExport {
+    std::vector<uint32_t> ptr[3], col[3];
+    std::vector<uint64_t> val[3];
+    std::vector<uint64_t> assignment;
+    zl_r1cs view{};
+    void build(const R1CS<FrP>& cs);
+};
+
+}  // namespace openzl

@@ -1,0 +1,385 @@
+// zl_host.hip -- implementation of the host-side plugin mirror (zl_host.h) + its C-ABI hooks (include/zl_backend.h,
+// "host mirror" section).  Host code only; compiled by hipcc because it shares zl_field.h with the kernels.
+#include <string.h>
+#include <new>
+#include "zl_host.h"
+
+namespace openzl {
+
+template <class FrP>
+static void to_canon_words(uint64_t* out, const Fp<FrP>& mont) {
+    const Fp<FrP> c = zl::from_mont(mont);
+    memcpy(out, c.l, 32);
+}
+
+template <class FrP>
+void R1csExport<FrP>::build(const R1CS<FrP>& cs) {
+    const size_t nc = cs.constraint_count();
+    for (int m = 0; m < 3; m++) {
+        const auto& rows = cs.rows(m);
+        ptr[m].assign(1, 0);
+        col[m].clear();
+        val[m].clear();
+        size_t nnz = 0;
+        for (auto& lc : rows) nnz += lc.terms.size();
+        col[m].reserve(nnz);
+        val[m].reserve(nnz * 4);
+        for (auto& lc : rows) {
+            // variable order: instance block then witness block; keys sort the same way (witness bit is the top bit)
+            for (auto& t : lc.terms) {
+                col[m].push_back(cs.var_index(t.first));
+                uint64_t w[4];
+                to_canon_words<FrP>(w, t.second);
+                val[m].insert(val[m].end(), w, w + 4);
+            }
+            ptr[m].push_back((uint32_t)col[m].size());
+        }
+        view.row_ptr[m] = ptr[m].data();
+        view.col[m] = col[m].data();
+        view.val[m] = val[m].data();
+    }
+    const auto& inst = cs.instance_assignment();
+    const auto& wit = cs.witness_assignment();
+    assignment.resize((inst.size() + wit.size()) * 4);
+    for (size_t i = 0; i < inst.size(); i++) to_canon_words<FrP>(&assignment[4 * i], inst[i]);
+    for (size_t i = 0; i < wit.size(); i++) to_canon_words<FrP>(&assignment[4 * (inst.size() + i)], wit[i]);
+    view.n_constraints = (uint32_t)nc;
+    view.n_instance = (uint32_t)inst.size();
+    view.n_witness = (uint32_t)wit.size();
+}
+
+template <class FrP>
+static Fp<FrP> sample_nonzero_mont(SplitMix64& rng, Fp<FrP>* canon_out) {
+    for (;;) {
+        Fp<FrP> c = sample_canonical<FrP>(rng);
+        if (c.is_zero()) continue;
+        if (canon_out) *canon_out = c;
+        return zl::to_mont(c);
+    }
+}
+
+// Groth16::compile -- ark_groth16::generate_random_parameters / generate_parameters (groth16.rs:427-443):
+// evaluate the QAP at tau through the Lagrange coefficients, then fixed-base multiplications of the generators.  The
+// fixed-base part runs on the device (zl_bases_generate); the trapdoor stays in the ProvingContext for exponent checks.
+template <class E>
+Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::VerifyingContext>> Groth16<E>::compile(zl_ctx* ctx, const Compiler& cs,
+                                                                                                                  SplitMix64& rng) {
+    Result<std::pair<ProvingContext, VerifyingContext>> res{false, {}, Error{ZL_EINVAL}};
+    if (!ctx) return res;
+    const size_t nc = cs.constraint_count(), ni = cs.num_instance_variables(), nw = cs.secret_variable_count(), nv = ni + nw;
+    unsigned log_n = 1;
+    while (((size_t)1 << log_n) < nc + ni) log_n++;
+    if (log_n > (unsigned)FrP::TWO_ADICITY) return res;
+    const size_t N = (size_t)1 << log_n;
+    Trapdoor td;
+    const F alpha = sample_nonzero_mont<FrP>(rng, &td.alpha), beta = sample_nonzero_mont<FrP>(rng, &td.beta),
+            gamma = sample_nonzero_mont<FrP>(rng, &td.gamma), delta = sample_nonzero_mont<FrP>(rng, &td.delta);
+    F w;
+    for (int i = 0; i < F::N; i++) w.l[i] = FrP::two_adic_root(i);
+    for (unsigned i = log_n; i < (unsigned)FrP::TWO_ADICITY; i++) w = zl::sqr(w);
+    // tau outside the domain
+    F tau, zt;
+    for (;;) {
+        tau = sample_nonzero_mont<FrP>(rng, &td.tau);
+        zt = tau;
+        for (unsigned i = 0; i < log_n; i++) zt = zl::sqr(zt);
+        zt = zl::sub(zt, F::one());  // Z(tau) = tau^N - 1
+        if (!zt.is_zero()) break;
+    }
+    // Lagrange coefficients L_j = Z(tau)/N * w^j / (tau - w^j), batch inversion
+    std::vector<F> L(N), den(N), pref(N);
+    {
+        F wj = F::one();
+        for (size_t j = 0; j < N; j++) { den[j] = zl::sub(tau, wj); L[j] = wj; wj = zl::mul(wj, w); }
+        F acc = F::one();
+        for (size_t j = 0; j < N; j++) { pref[j] = acc; acc = zl::mul(acc, den[j]); }
+        F inv = zl::inv(acc);
+        const F scale = zl::mul(zt, zl::inv(zl::from_u64<FrP>((uint64_t)N)));
+        for (size_t j = N; j-- > 0;) {
+            const F dinv = zl::mul(inv, pref[j]);
+            inv = zl::mul(inv, den[j]);
+            L[j] = zl::mul(zl::mul(L[j], dinv), scale);
+        }
+    }
+    std::vector<F> u(nv, F::zero()), v(nv, F::zero()), ww(nv, F::zero());
+    for (size_t j = 0; j < ni; j++) u[j] = L[nc + j];
+    for (int m = 0; m < 3; m++) {
+        std::vector<F>& dst = m == 0 ? u : m == 1 ? v : ww;
+        const auto& rows = cs.rows(m);
+        for (size_t row = 0; row < rows.size(); row++)
+            for (auto& t : rows[row].terms) {
+                const uint32_t i = cs.var_index(t.first);
+                dst[i] = zl::add(dst[i], zl::mul(t.second, L[row]));
+            }
+    }
+    const F dinv = zl::inv(delta), ginv = zl::inv(gamma);
+    // exponent vectors (canonical) for the device generator
+    std::vector<uint64_t> ea(nv * 4), eb(nv * 4), eh((N - 1) * 4), el(std::max<size_t>(nw, 1) * 4), single(5 * 4);
+    VerifyingContext vk;
+    for (size_t i = 0; i < nv; i++) {
+        to_canon_words<FrP>(&ea[4 * i], u[i]);
+        to_canon_words<FrP>(&eb[4 * i], v[i]);
+        const F comb = zl::add(zl::add(zl::mul(beta, u[i]), zl::mul(alpha, v[i])), ww[i]);
+        if (i < ni) vk.gamma_abc_exponents.push_back(zl::mul(comb, ginv));
+        else to_canon_words<FrP>(&el[4 * (i - ni)], zl::mul(comb, dinv));
+    }
+    {
+        F tp = zl::mul(zt, dinv);
+        for (size_t j = 0; j + 1 < N; j++) { to_canon_words<FrP>(&eh[4 * j], tp); tp = zl::mul(tp, tau); }
+    }
+    ProvingContext pc;
+    pc.ctx = ctx;
+    pc.trapdoor = td;
+    pc.n_instance = ni;
+    pc.n_witness = nw;
+    pc.domain_size = N;
+    int rc = zl_bases_generate(ctx, E::curve, ZL_G1, ea.data(), nv, &pc.a_query);
+    if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eb.data(), nv, &pc.b_g1_query);
+    if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G2, eb.data(), nv, &pc.b_g2_query);
+    if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eh.data(), N - 1, &pc.h_query);
+    if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, el.data(), nw, &pc.l_query);
+    // alpha*G1, beta*G1, delta*G1, beta*G2, delta*G2
+    const size_t q1 = 2 * E::G1::FQ64, q2 = 4 * E::G1::FQ64;
+    pc.alpha_g1.resize(q1); pc.beta_g1.resize(q1); pc.delta_g1.resize(q1); pc.beta_g2.resize(q2); pc.delta_g2.resize(q2);
+    if (!rc) {
+        uint64_t k3[12];
+        memcpy(k3, td.alpha.l, 32); memcpy(k3 + 4, td.beta.l, 32); memcpy(k3 + 8, td.delta.l, 32);
+        uint64_t h1 = 0, h2 = 0;
+        std::vector<uint64_t> tmp(3 * q2);
+        rc = zl_bases_generate(ctx, E::curve, ZL_G1, k3, 3, &h1);
+        if (!rc) rc = zl_bases_download(ctx, h1, 0, 3, tmp.data());
+        if (!rc) {
+            memcpy(pc.alpha_g1.data(), &tmp[0], q1 * 8);
+            memcpy(pc.beta_g1.data(), &tmp[q1], q1 * 8);
+            memcpy(pc.delta_g1.data(), &tmp[2 * q1], q1 * 8);
+        }
+        if (h1) (void)zl_bases_free(ctx, h1);
+        if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G2, k3 + 4, 2, &h2);
+        if (!rc) rc = zl_bases_download(ctx, h2, 0, 2, tmp.data());
+        if (!rc) {
+            memcpy(pc.beta_g2.data(), &tmp[0], q2 * 8);
+            memcpy(pc.delta_g2.data(), &tmp[q2], q2 * 8);
+        }
+        if (h2) (void)zl_bases_free(ctx, h2);
+    }
+    if (rc) {
+        release(pc);
+        res.error = Error{rc};
+        return res;
+    }
+    res.ok = true;
+    res.value = {pc, vk};
+    return res;
+}
+
+template <class E>
+void Groth16<E>::release(ProvingContext& pc) {
+    if (!pc.ctx) return;
+    for (uint64_t* h : {&pc.a_query, &pc.b_g1_query, &pc.b_g2_query, &pc.h_query, &pc.l_query})
+        if (*h) { (void)zl_bases_free(pc.ctx, *h); *h = 0; }
+}
+
+// Groth16::prove (groth16.rs:445-457): r, s <- rng; create_proof_with_assignment on the device
+template <class E>
+Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, const Compiler& cs, SplitMix64& rng, F* r_out, F* s_out) {
+    Result<Proof> res{false, {}, Error{ZL_EINVAL}};
+    if (cs.mode() != Compiler::Mode::Prove) return res;  // the reference panics when a setup-mode compiler reaches prove
+    if (cs.num_instance_variables() != pc.n_instance || cs.secret_variable_count() != pc.n_witness) return res;
+    const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
+    if (r_out) *r_out = r;
+    if (s_out) *s_out = s;
+    R1csExport<FrP> ex;
+    ex.build(cs);
+    zl_g16_pk pk{};
+    pk.curve = E::curve;
+    pk.a_query = pc.a_query; pk.b_g1_query = pc.b_g1_query; pk.h_query = pc.h_query; pk.l_query = pc.l_query; pk.b_g2_query = pc.b_g2_query;
+    pk.alpha_g1 = pc.alpha_g1.data(); pk.beta_g1 = pc.beta_g1.data(); pk.delta_g1 = pc.delta_g1.data();
+    pk.beta_g2 = pc.beta_g2.data(); pk.delta_g2 = pc.delta_g2.data();
+    uint64_t rw[4], sw[4];
+    memcpy(rw, r.l, 32);
+    memcpy(sw, s.l, 32);
+    const int rc = zl_groth16_prove(pc.ctx, &pk, &ex.view, ex.assignment.data(), rw, sw, &res.value);
+    if (rc) { res.error = Error{rc}; return res; }  // .map_err(|_| Error) groth16.rs:456
+    res.ok = true;
+    return res;
+}
+
+template struct Groth16<Bls12_381>;
+template struct Groth16<Bn254>;
+template struct R1csExport<BLS12_381_Fr>;
+template struct R1csExport<BN254_Fr>;
+
+// config 5 circuit: h_1 = H(x0, x1), h_{j+1} = H(h_j, x1), public input h_k  
+template <class FrP>
+static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<FrP>& x1_canon) {
+    using F = Fp<FrP>;
+    static const poseidon::Constants<FrP> consts;
+    R1CS<FrP> cs = R1CS<FrP>::for_proofs();
+    // expected output natively (public input is allocated first so that the instance block precedes the witnesses)
+    F h = zl::to_mont(x0_canon);
+    const F x1 = zl::to_mont(x1_canon);
+    for (uint32_t j = 0; j < k; j++) {
+        F st[3] = {zl::from_u64<FrP>(3), h, x1};
+        poseidon::permute_native(consts, st);
+        h = st[0];
+    }
+    FpVar<FrP> out_pub = cs.new_input(h);
+    FpVar<FrP> a = cs.new_witness(zl::to_mont(x0_canon));
+    FpVar<FrP> b = cs.new_witness(x1);
+    FpVar<FrP> cur = a;
+    for (uint32_t j = 0; j < k; j++) cur = poseidon::hash(consts, cur, b, cs);
+    cs.enforce_equal(cur, out_pub);
+    return cs;
+}
+
+}  // namespace openzl
+
+// ------------------------------------------------------------------------------------------------ C-ABI hooks
+using namespace openzl;
+struct zl_circuit {
+    zl_curve_t curve;
+    R1CS<BLS12_381_Fr>* bls = nullptr;
+    R1CS<BN254_Fr>* bn = nullptr;
+    R1csExport<BLS12_381_Fr> ex_bls;
+    R1csExport<BN254_Fr> ex_bn;
+};
+struct zl_g16_keys {
+    zl_curve_t curve;
+    Groth16<Bls12_381>::ProvingContext pc_bls;
+    Groth16<Bn254>::ProvingContext pc_bn;
+    std::vector<uint64_t> gamma_abc;  // exponents, canonical
+};
+
+extern "C" {
+
+int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out) {
+    if (!out || !x0 || !x1 || k == 0 || (curve != ZL_BLS12_381 && curve != ZL_BN254)) return ZL_EINVAL;
+    zl_circuit* c = new (std::nothrow) zl_circuit();
+    if (!c) return ZL_ENOMEM;
+    c->curve = curve;
+    if (curve == ZL_BLS12_381) {
+        Fp<BLS12_381_Fr> a, b;
+        memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
+        c->bls = new R1CS<BLS12_381_Fr>(poseidon_chain<BLS12_381_Fr>(k, a, b));
+        c->ex_bls.build(*c->bls);
+    } else {
+        Fp<BN254_Fr> a, b;
+        memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
+        c->bn = new R1CS<BN254_Fr>(poseidon_chain<BN254_Fr>(k, a, b));
+        c->ex_bn.build(*c->bn);
+    }
+    *out = c;
+    return ZL_OK;
+}
+void zl_circuit_free(zl_circuit* c) {
+    if (!c) return;
+    delete c->bls;
+    delete c->bn;
+    delete c;
+}
+int zl_circuit_export(const zl_circuit* c, zl_r1cs* view, const uint64_t** assignment) {
+    if (!c || !view) return ZL_EINVAL;
+    if (c->curve == ZL_BLS12_381) { *view = c->ex_bls.view; if (assignment) *assignment = c->ex_bls.assignment.data(); }
+    else { *view = c->ex_bn.view; if (assignment) *assignment = c->ex_bn.assignment.data(); }
+    return ZL_OK;
+}
+int zl_circuit_is_satisfied(const zl_circuit* c) {
+    if (!c) return ZL_EINVAL;
+    return c->curve == ZL_BLS12_381 ? (c->bls->is_satisfied() ? 1 : 0) : (c->bn->is_satisfied() ? 1 : 0);
+}
+int zl_poseidon_permute(zl_curve_t curve, uint64_t* state) {
+    if (!state) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) {
+        static const poseidon::Constants<BLS12_381_Fr> cst;
+        Fp<BLS12_381_Fr> st[3];
+        for (int i = 0; i < 3; i++) { memcpy(st[i].l, state + 4 * i, 32); st[i] = zl::to_mont(st[i]); }
+        poseidon::permute_native(cst, st);
+        for (int i = 0; i < 3; i++) { st[i] = zl::from_mont(st[i]); memcpy(state + 4 * i, st[i].l, 32); }
+        return ZL_OK;
+    }
+    if (curve == ZL_BN254) {
+        static const poseidon::Constants<BN254_Fr> cst;
+        Fp<BN254_Fr> st[3];
+        for (int i = 0; i < 3; i++) { memcpy(st[i].l, state + 4 * i, 32); st[i] = zl::to_mont(st[i]); }
+        poseidon::permute_native(cst, st);
+        for (int i = 0; i < 3; i++) { st[i] = zl::from_mont(st[i]); memcpy(state + 4 * i, st[i].l, 32); }
+        return ZL_OK;
+    }
+    return ZL_EINVAL;
+}
+int zl_groth16_compile(zl_ctx* ctx, const zl_circuit* c, uint64_t seed, zl_g16_keys** out) {
+    if (!ctx || !c || !out) return ZL_EINVAL;
+    zl_g16_keys* k = new (std::nothrow) zl_g16_keys();
+    if (!k) return ZL_ENOMEM;
+    k->curve = c->curve;
+    SplitMix64 rng(seed);
+    int rc = ZL_OK;
+    if (c->curve == ZL_BLS12_381) {
+        auto r = Groth16<Bls12_381>::compile(ctx, *c->bls, rng);
+        if (!r.ok) rc = r.error.code; else {
+            k->pc_bls = r.value.first;
+            for (auto& g : r.value.second.gamma_abc_exponents) { uint64_t w[4]; to_canon_words<BLS12_381_Fr>(w, g); k->gamma_abc.insert(k->gamma_abc.end(), w, w + 4); }
+        }
+    } else {
+        auto r = Groth16<Bn254>::compile(ctx, *c->bn, rng);
+        if (!r.ok) rc = r.error.code; else {
+            k->pc_bn = r.value.first;
+            for (auto& g : r.value.second.gamma_abc_exponents) { uint64_t w[4]; to_canon_words<BN254_Fr>(w, g); k->gamma_abc.insert(k->gamma_abc.end(), w, w + 4); }
+        }
+    }
+    if (rc) { delete k; return rc; }
+    *out = k;
+    return ZL_OK;
+}
+void zl_groth16_keys_free(zl_g16_keys* k) {
+    if (!k) return;
+    Groth16<Bls12_381>::release(k->pc_bls);
+    Groth16<Bn254>::release(k->pc_bn);
+    delete k;
+}
+int zl_groth16_keys_pk(const zl_g16_keys* k, zl_g16_pk* pk) {
+    if (!k || !pk) return ZL_EINVAL;
+    pk->curve = k->curve;
+#define FILL(pc)                                                                                                     \
+    pk->a_query = pc.a_query; pk->b_g1_query = pc.b_g1_query; pk->h_query = pc.h_query; pk->l_query = pc.l_query;    \
+    pk->b_g2_query = pc.b_g2_query; pk->alpha_g1 = pc.alpha_g1.data(); pk->beta_g1 = pc.beta_g1.data();              \
+    pk->delta_g1 = pc.delta_g1.data(); pk->beta_g2 = pc.beta_g2.data(); pk->delta_g2 = pc.delta_g2.data();
+    if (k->curve == ZL_BLS12_381) { FILL(k->pc_bls) } else { FILL(k->pc_bn) }
+#undef FILL
+    return ZL_OK;
+}
+int zl_groth16_keys_trapdoor(const zl_g16_keys* k, uint64_t* out20) {
+    if (!k || !out20) return ZL_EINVAL;
+    if (k->curve == ZL_BLS12_381) {
+        const auto& t = k->pc_bls.trapdoor;
+        const Fp<BLS12_381_Fr>* v[5] = {&t.alpha, &t.beta, &t.gamma, &t.delta, &t.tau};
+        for (int i = 0; i < 5; i++) memcpy(out20 + 4 * i, v[i]->l, 32);
+    } else {
+        const auto& t = k->pc_bn.trapdoor;
+        const Fp<BN254_Fr>* v[5] = {&t.alpha, &t.beta, &t.gamma, &t.delta, &t.tau};
+        for (int i = 0; i < 5; i++) memcpy(out20 + 4 * i, v[i]->l, 32);
+    }
+    return ZL_OK;
+}
+int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* c, uint64_t seed, zl_g16_proof* proof, uint64_t* r_out, uint64_t* s_out) {
+    if (!ctx || !k || !c || !proof || k->curve != c->curve) return ZL_EINVAL;
+    SplitMix64 rng(seed);
+    if (c->curve == ZL_BLS12_381) {
+        Fp<BLS12_381_Fr> r, s;
+        auto res = Groth16<Bls12_381>::prove(k->pc_bls, *c->bls, rng, &r, &s);
+        if (!res.ok) return res.error.code;
+        *proof = res.value;
+        if (r_out) memcpy(r_out, r.l, 32);
+        if (s_out) memcpy(s_out, s.l, 32);
+    } else {
+        Fp<BN254_Fr> r, s;
+        auto res = Groth16<Bn254>::prove(k->pc_bn, *c->bn, rng, &r, &s);
+        if (!res.ok) return res.error.code;
+        *proof = res.value;
+        if (r_out) memcpy(r_out, r.l, 32);
+        if (s_out) memcpy(s_out, s.l, 32);
+    }
+    return ZL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""The C++ host mirror of the plugin interface (openzl::poseidon / R1CS<F> / Groth16<E>, csrc/zl_host.h).
+CPU tests: the product's native Poseidon reproduces the reference's own KAT, and its R1CS compiler builds exactly the
+circuit the independent Python builder (oracle) builds.  gpu test: Groth16::compile + prove end to end."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import groth16_util as gu
+import oracle_lib as ol
+from oracle_lib import po
+from openzl_amd import Circuit, Groth16Keys, poseidon_permute
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FX = json.load(open(os.path.join(HERE, "golden", "ref_poseidon_fixtures.json")))
+
+
+def test_native_poseidon_matches_reference_kat():
+    """mirrors openzl-tutorials/src/poseidon.rs:364-405 `poseidon_arity_2` (same input, same three expected values)"""
+    out = poseidon_permute(po.BLS12_381.cid, ol.ints_to_limbs([3, 1, 2], 4))
+    assert [str(v) for v in ol.limbs_to_ints(out)] == FX["permutation_width3"]["output"]
+
+
+def test_native_poseidon_bn254_matches_python_model():
+    out = poseidon_permute(po.BN254.cid, ol.ints_to_limbs([3, 1, 2], 4))
+    assert ol.limbs_to_ints(out) == po.poseidon_permute(po.BN254_FR, [3, 1, 2])
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("k", [1, 3])
+def test_r1cs_compiler_builds_the_same_circuit_as_the_python_builder(curve, k):
+    c = Circuit(curve.cid, k)
+    cs = po.poseidon_chain_circuit(curve.fr, k)
+    assert c.shape == (cs.n_constraints, cs.n_instance, cs.n_witness) == (234 * k + 1, 2, 234 * k + 2)
+    assert c.is_satisfied() and cs.is_satisfied()
+    got, exp = c.arrays(), gu.r1cs_arrays(cs)
+    for key in "ABC":
+        for g, e in zip(got[key], exp[key]):
+            assert np.array_equal(g, e)
+    assert np.array_equal(got["assignment"], ol.ints_to_limbs(cs.assignment(), 4))
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,k", [(po.BLS12_381, 2), (po.BN254, 1)], ids=["bls-k2", "bn254-k1"])
+def test_groth16_compile_and_prove_end_to_end(backend, curve, k):
+    circ = Circuit(curve.cid, k)
+    keys = Groth16Keys(backend, circ, seed=0xC0FFEE)
+    try:
+        (a, ai, b, bi, c, ci), r, s = keys.prove(seed=0xBEEF)
+        arrays = circ.arrays()
+        n = 1 << max(1, (arrays["n_constraints"] + arrays["n_instance"] - 1).bit_length())
+        h_gpu = backend.groth16_last_h(n)
+        # (1) the setup: proving key = exponents * generator, recomputed independently from the trapdoor
+        td = po.Groth16Trapdoor(*keys.trapdoor())
+        cs = po.poseidon_chain_circuit(curve.fr, k)
+        ex = po.groth16_setup_exponents(curve, cs, td)
+        pkd = keys.pk_dict()
+        assert (backend.bases_download(pkd["a_query"]) == ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs(ex["a_query"], 4))).all()
+        assert (backend.bases_download(pkd["l_query"]) == ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs(ex["l_query"], 4))).all()
+        assert (backend.bases_download(pkd["h_query"]) == ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs(ex["h_query"], 4))).all()
+        assert (backend.bases_download(pkd["b_g2_query"]) == gu.g2_mul_gen(curve, ex["b_query"])).all()
+        # (2) the proof: recomputed in the exponent and checked against the Groth16 verification equation
+        h_py = po.qap_witness_map(curve, cs)
+        assert ol.limbs_to_ints(h_gpu) == h_py
+        A, B, Cx = po.groth16_prove_exponents(curve, cs, td, ex, h_py, ol.limbs_to_ints(r.reshape(1, 4))[0], ol.limbs_to_ints(s.reshape(1, 4))[0])
+        assert po.groth16_check_exponents(curve, cs, td, ex, A, B, Cx)
+        assert not (ai or bi or ci)
+        assert (a == ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs([A], 4))[0]).all()
+        assert (b == gu.g2_mul_gen(curve, [B])[0]).all()
+        assert (c == ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs([Cx], 4))[0]).all()
+    finally:
+        keys.close()
+        circ.close()
