@@ -45,6 +45,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->bases) if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
+    for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
     zl_ntt_free(ctx);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);

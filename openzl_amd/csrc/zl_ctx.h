@@ -77,6 +77,12 @@ struct zl_twiddles {
     void* d_small = nullptr;  // per-radix tables
     unsigned lo_bits = 0;
 };
+struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Montgomery form)
+    void* d_base = nullptr;
+    size_t off_ptr[3] = {0, 0, 0}, off_col[3] = {0, 0, 0}, off_val[3] = {0, 0, 0};
+    uint32_t n_constraints = 0, n_instance = 0, n_witness = 0;
+    int curve = 0;
+};
 struct zl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use
@@ -87,6 +93,7 @@ struct zl_ctx {
     zl_timing timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<uint64_t, zl_bases> bases;
+    std::map<uint64_t, zl_r1cs_dev> r1cs;
     uint64_t next_handle = 1;
     zl_scratch scratch[10];
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse

@@ -74,8 +74,47 @@ static XYZZ<F> from_partial(const uint64_t* partial) {
     return p;
 }
 
+// R1CS matrices -> device (CSR, coefficients converted to Montgomery once).  Static per circuit, like the proving key.
+template <class FrP>
+static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
+    using Fr = Fp<FrP>;
+    const uint32_t nc = cs->n_constraints;
+    size_t bytes = 0;
+    auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) / 256 * 256; return o; };
+    size_t nnz[3];
+    for (int m = 0; m < 3; m++) {
+        nnz[m] = cs->row_ptr[m][nc];
+        out->off_ptr[m] = take((size_t)(nc + 1) * 4);
+        out->off_col[m] = take(nnz[m] * 4);
+        out->off_val[m] = take(nnz[m] * 32);
+    }
+    void* base = nullptr;
+    ZL_HIP(ctx, hipMalloc(&base, bytes ? bytes : 256));
+    unsigned char* d = reinterpret_cast<unsigned char*>(base);
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    for (int m = 0; m < 3 && e == hipSuccess; m++) {
+        e = hipMemcpyAsync(d + out->off_ptr[m], cs->row_ptr[m], (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nnz[m]) {
+            e = hipMemcpyAsync(d + out->off_col[m], cs->col[m], nnz[m] * 4, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + out->off_val[m], cs->val[m], nnz[m] * 32, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((uint32_t)((nnz[m] + 255) / 256)), dim3(256), 0, st, (Fr*)(d + out->off_val[m]), (uint32_t)nnz[m]);
+                e = hipGetLastError();
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(base); return ZL_EHIP; }
+    out->d_base = base;
+    out->n_constraints = nc;
+    out->n_instance = cs->n_instance;
+    out->n_witness = cs->n_witness;
+    return ZL_OK;
+}
+
 template <class G1, class G2>
-static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
+static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
                            zl_g16_proof* out) {
     using FrP = typename G1::FrP;
     using Fr = Fp<FrP>;
@@ -102,30 +141,19 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, 
 
     hipStream_t st = ctx->stream;
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    // ---- stage R1CS + assignment on the device -------------------------------------------------------------------
-    size_t nnz[3], off_ptr[3], off_col[3], off_val[3];
+    // ---- assignment + work vectors on the device (the matrices are already resident, zl_r1cs_upload) ------------------
     size_t bytes = 0;
     auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) / 256 * 256; return o; };
-    for (int m = 0; m < 3; m++) {
-        nnz[m] = cs->row_ptr[m][nc];
-        off_ptr[m] = take((size_t)(nc + 1) * 4);
-        off_col[m] = take(nnz[m] * 4);
-        off_val[m] = take(nnz[m] * 32);
-    }
     const size_t off_zc = take((size_t)nv * 32), off_zm = take((size_t)nv * 32);
     const size_t off_a = take((size_t)N * 32), off_b = take((size_t)N * 32), off_c = take((size_t)N * 32), off_h = take((size_t)N * 32);
     void* base;
     int rc;
     if ((rc = zl_scratch_get(ctx, 8, bytes, &base))) return rc;  // slots 0-7 belong to the MSM / NTT / staging paths
     unsigned char* d = reinterpret_cast<unsigned char*>(base);
-    for (int m = 0; m < 3; m++) {
-        ZL_HIP(ctx, hipMemcpyAsync(d + off_ptr[m], cs->row_ptr[m], (size_t)(nc + 1) * 4, hipMemcpyHostToDevice, st));
-        if (nnz[m]) {
-            ZL_HIP(ctx, hipMemcpyAsync(d + off_col[m], cs->col[m], nnz[m] * 4, hipMemcpyHostToDevice, st));
-            ZL_HIP(ctx, hipMemcpyAsync(d + off_val[m], cs->val[m], nnz[m] * 32, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((uint32_t)((nnz[m] + 255) / 256)), dim3(256), 0, st, (Fr*)(d + off_val[m]), (uint32_t)nnz[m]);
-        }
-    }
+    const unsigned char* dm = reinterpret_cast<const unsigned char*>(cs->d_base);
+    const size_t* off_ptr = cs->off_ptr;
+    const size_t* off_col = cs->off_col;
+    const size_t* off_val = cs->off_val;
     Fr* d_zc = (Fr*)(d + off_zc);
     Fr* d_zm = (Fr*)(d + off_zm);
     ZL_HIP(ctx, hipMemcpyAsync(d_zc, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
@@ -134,8 +162,8 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, 
     Fr *d_a = (Fr*)(d + off_a), *d_b = (Fr*)(d + off_b), *d_c = (Fr*)(d + off_c), *d_h = (Fr*)(d + off_h);
     Fr* dv[3] = {d_a, d_b, d_c};
     for (int m = 0; m < 3; m++)
-        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, (const uint32_t*)(d + off_ptr[m]), (const uint32_t*)(d + off_col[m]),
-                           (const Fr*)(d + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
+                           (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
     ZL_HIP(ctx, hipGetLastError());
     // ---- witness map: 3 x (ifft, coset fft), pointwise, coset ifft --------------------------------------------------
     const int timing_saved = ctx->timing_on;
@@ -209,15 +237,54 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, 
     return ZL_OK;
 }
 
+static bool r1cs_view_ok(const zl_r1cs* cs) {
+    if (!cs || cs->n_instance < 1) return false;
+    for (int m = 0; m < 3; m++)
+        if (!cs->row_ptr[m] || (cs->row_ptr[m][cs->n_constraints] && (!cs->col[m] || !cs->val[m]))) return false;
+    return true;
+}
+extern "C" int zl_r1cs_upload(zl_ctx* ctx, zl_curve_t curve, const zl_r1cs* cs, uint64_t* handle_out) {
+    if (!ctx || !handle_out || !r1cs_view_ok(cs)) return ZL_EINVAL;
+    if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    zl_r1cs_dev dev{};
+    dev.curve = curve;
+    const int rc = curve == ZL_BLS12_381 ? r1cs_upload_t<BLS12_381_Fr>(ctx, cs, &dev) : r1cs_upload_t<BN254_Fr>(ctx, cs, &dev);
+    if (rc) return rc;
+    const uint64_t h = ctx->next_handle++;
+    ctx->r1cs[h] = dev;
+    *handle_out = h;
+    return ZL_OK;
+}
+extern "C" int zl_r1cs_free(zl_ctx* ctx, uint64_t handle) {
+    if (!ctx) return ZL_EINVAL;
+    auto it = ctx->r1cs.find(handle);
+    if (it == ctx->r1cs.end()) return ZL_EHANDLE;
+    ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (it->second.d_base) (void)hipFree(it->second.d_base);
+    ctx->r1cs.erase(it);
+    return ZL_OK;
+}
+extern "C" int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, const uint64_t* r,
+                                         const uint64_t* s, zl_g16_proof* out) {
+    if (!ctx || !pk || !assignment || !r || !s || !out) return ZL_EINVAL;
+    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
+    auto it = ctx->r1cs.find(r1cs_handle);
+    if (it == ctx->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, assignment, r, s, out);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, assignment, r, s, out);
+    return ZL_EINVAL;
+}
 extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
                                 zl_g16_proof* out) {
-    if (!ctx || !pk || !cs || !assignment || !r || !s || !out) return ZL_EINVAL;
-    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
-    for (int m = 0; m < 3; m++) if (!cs->row_ptr[m] || (cs->row_ptr[m][cs->n_constraints] && (!cs->col[m] || !cs->val[m]))) return ZL_EINVAL;
-    ZL_HIP(ctx, hipSetDevice(ctx->device));
-    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, cs, assignment, r, s, out);
-    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, cs, assignment, r, s, out);
-    return ZL_EINVAL;
+    if (!ctx || !pk || !r1cs_view_ok(cs)) return ZL_EINVAL;
+    uint64_t h = 0;
+    int rc = zl_r1cs_upload(ctx, pk->curve, cs, &h);
+    if (rc) return rc;
+    rc = zl_groth16_prove_resident(ctx, pk, h, assignment, r, s, out);
+    (void)zl_r1cs_free(ctx, h);
+    return rc;
 }
 extern "C" int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n) {
     if (!ctx || !out || !ctx->g16_h || n > ctx->g16_h_n) return ZL_EINVAL;

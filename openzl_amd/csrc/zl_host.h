@@ -322,6 +322,8 @@ struct Groth16 {
     struct ProvingContext {                                 // ProvingContext<E>(pub ProvingKey<E>) groth16.rs:127-140
         zl_ctx* ctx = nullptr;
         uint64_t a_query = 0, b_g1_query = 0, h_query = 0, l_query = 0, b_g2_query = 0;
+        uint64_t r1cs = 0;  // device-resident constraint matrices (static per circuit, uploaded by compile)
+        size_t n_constraints = 0;
         std::vector<uint64_t> alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2;
         size_t n_instance = 0, n_witness = 0, domain_size = 0;
         Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it

@@ -138,6 +138,12 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G2, eb.data(), nv, &pc.b_g2_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eh.data(), N - 1, &pc.h_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, el.data(), nw, &pc.l_query);
+    if (!rc) {
+        R1csExport<FrP> ex;
+        ex.build(cs);
+        rc = zl_r1cs_upload(ctx, E::curve, &ex.view, &pc.r1cs);
+        pc.n_constraints = nc;
+    }
     // alpha*G1, beta*G1, delta*G1, beta*G2, delta*G2
     const size_t q1 = 2 * E::G1::FQ64, q2 = 4 * E::G1::FQ64;
     pc.alpha_g1.resize(q1); pc.beta_g1.resize(q1); pc.delta_g1.resize(q1); pc.beta_g2.resize(q2); pc.delta_g2.resize(q2);
@@ -177,6 +183,7 @@ void Groth16<E>::release(ProvingContext& pc) {
     if (!pc.ctx) return;
     for (uint64_t* h : {&pc.a_query, &pc.b_g1_query, &pc.b_g2_query, &pc.h_query, &pc.l_query})
         if (*h) { (void)zl_bases_free(pc.ctx, *h); *h = 0; }
+    if (pc.r1cs) { (void)zl_r1cs_free(pc.ctx, pc.r1cs); pc.r1cs = 0; }
 }
 
 // Groth16::prove (groth16.rs:445-457): r, s <- rng; create_proof_with_assignment on the device
@@ -188,8 +195,13 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
     if (r_out) *r_out = r;
     if (s_out) *s_out = s;
-    R1csExport<FrP> ex;
-    ex.build(cs);
+    if (cs.constraint_count() != pc.n_constraints) return res;
+    // only the assignment travels per proof; the matrices and the proving key are device-resident
+    const auto& inst = cs.instance_assignment();
+    const auto& wit = cs.witness_assignment();
+    std::vector<uint64_t> assignment((inst.size() + wit.size()) * 4);
+    for (size_t i = 0; i < inst.size(); i++) to_canon_words<FrP>(&assignment[4 * i], inst[i]);
+    for (size_t i = 0; i < wit.size(); i++) to_canon_words<FrP>(&assignment[4 * (inst.size() + i)], wit[i]);
     zl_g16_pk pk{};
     pk.curve = E::curve;
     pk.a_query = pc.a_query; pk.b_g1_query = pc.b_g1_query; pk.h_query = pc.h_query; pk.l_query = pc.l_query; pk.b_g2_query = pc.b_g2_query;
@@ -198,7 +210,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     uint64_t rw[4], sw[4];
     memcpy(rw, r.l, 32);
     memcpy(sw, s.l, 32);
-    const int rc = zl_groth16_prove(pc.ctx, &pk, &ex.view, ex.assignment.data(), rw, sw, &res.value);
+    const int rc = zl_groth16_prove_resident(pc.ctx, &pk, pc.r1cs, assignment.data(), rw, sw, &res.value);
     if (rc) { res.error = Error{rc}; return res; }  // .map_err(|_| Error) groth16.rs:456
     res.ok = true;
     return res;
