@@ -126,8 +126,9 @@ int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const 
 /* The matrices are static per circuit: upload them once (like the proving key) and prove many witnesses. */
 int zl_r1cs_upload(zl_ctx* ctx, zl_curve_t curve, const zl_r1cs* cs, uint64_t* handle_out);
 int zl_r1cs_free(zl_ctx* ctx, uint64_t handle);
-int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, const uint64_t* r,
-                              const uint64_t* s, zl_g16_proof* out);
+/* flags: ZL_MONT = the assignment is in arkworks' in-memory Montgomery form (no host-side into_repr pass needed) */
+int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, unsigned flags,
+                              const uint64_t* r, const uint64_t* s, zl_g16_proof* out);
 /* the quotient polynomial h of the last zl_groth16_prove call (N x 4 u64 canonical), for tests */
 int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n);
 

@@ -114,8 +114,8 @@ static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
 }
 
 template <class G1, class G2>
-static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
-                           zl_g16_proof* out) {
+static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* cs, const uint64_t* assignment, unsigned flags, const uint64_t* r,
+                           const uint64_t* s, zl_g16_proof* out) {
     using FrP = typename G1::FrP;
     using Fr = Fp<FrP>;
     using F1 = typename G1::F;
@@ -156,9 +156,14 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     const size_t* off_val = cs->off_val;
     Fr* d_zc = (Fr*)(d + off_zc);
     Fr* d_zm = (Fr*)(d + off_zm);
-    ZL_HIP(ctx, hipMemcpyAsync(d_zc, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
-    ZL_HIP(ctx, hipMemcpyAsync(d_zm, d_zc, (size_t)nv * 32, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, nv);
+    if (flags & ZL_MONT) {  // arkworks' in-memory assignment: Montgomery limbs; the canonical copy (MSM scalars) is made on the device
+        ZL_HIP(ctx, hipMemcpyAsync(d_zm, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, d_zc, nv);
+    } else {
+        ZL_HIP(ctx, hipMemcpyAsync(d_zc, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
+        ZL_HIP(ctx, hipMemcpyAsync(d_zm, d_zc, (size_t)nv * 32, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, nv);
+    }
     Fr *d_a = (Fr*)(d + off_a), *d_b = (Fr*)(d + off_b), *d_c = (Fr*)(d + off_c), *d_h = (Fr*)(d + off_h);
     Fr* dv[3] = {d_a, d_b, d_c};
     for (int m = 0; m < 3; m++)
@@ -265,15 +270,15 @@ extern "C" int zl_r1cs_free(zl_ctx* ctx, uint64_t handle) {
     ctx->r1cs.erase(it);
     return ZL_OK;
 }
-extern "C" int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, const uint64_t* r,
-                                         const uint64_t* s, zl_g16_proof* out) {
-    if (!ctx || !pk || !assignment || !r || !s || !out) return ZL_EINVAL;
+extern "C" int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, unsigned flags,
+                                         const uint64_t* r, const uint64_t* s, zl_g16_proof* out) {
+    if (!ctx || !pk || !assignment || !r || !s || !out || (flags & ~ZL_MONT)) return ZL_EINVAL;
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
     auto it = ctx->r1cs.find(r1cs_handle);
     if (it == ctx->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, assignment, r, s, out);
-    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, assignment, r, s, out);
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
     return ZL_EINVAL;
 }
 extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,
@@ -282,7 +287,7 @@ extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs*
     uint64_t h = 0;
     int rc = zl_r1cs_upload(ctx, pk->curve, cs, &h);
     if (rc) return rc;
-    rc = zl_groth16_prove_resident(ctx, pk, h, assignment, r, s, out);
+    rc = zl_groth16_prove_resident(ctx, pk, h, assignment, ZL_CANON, r, s, out);
     (void)zl_r1cs_free(ctx, h);
     return rc;
 }

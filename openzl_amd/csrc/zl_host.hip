@@ -199,9 +199,9 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     // only the assignment travels per proof; the matrices and the proving key are device-resident
     const auto& inst = cs.instance_assignment();
     const auto& wit = cs.witness_assignment();
-    std::vector<uint64_t> assignment((inst.size() + wit.size()) * 4);
-    for (size_t i = 0; i < inst.size(); i++) to_canon_words<FrP>(&assignment[4 * i], inst[i]);
-    for (size_t i = 0; i < wit.size(); i++) to_canon_words<FrP>(&assignment[4 * (inst.size() + i)], wit[i]);
+    std::vector<uint64_t> assignment((inst.size() + wit.size()) * 4);  // Montgomery limbs as held by the compiler (ZL_MONT)
+    memcpy(assignment.data(), inst.data(), inst.size() * 32);
+    memcpy(assignment.data() + 4 * inst.size(), wit.data(), wit.size() * 32);
     zl_g16_pk pk{};
     pk.curve = E::curve;
     pk.a_query = pc.a_query; pk.b_g1_query = pc.b_g1_query; pk.h_query = pc.h_query; pk.l_query = pc.l_query; pk.b_g2_query = pc.b_g2_query;
@@ -210,7 +210,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     uint64_t rw[4], sw[4];
     memcpy(rw, r.l, 32);
     memcpy(sw, s.l, 32);
-    const int rc = zl_groth16_prove_resident(pc.ctx, &pk, pc.r1cs, assignment.data(), rw, sw, &res.value);
+    const int rc = zl_groth16_prove_resident(pc.ctx, &pk, pc.r1cs, assignment.data(), ZL_MONT, rw, sw, &res.value);
     if (rc) { res.error = Error{rc}; return res; }  // .map_err(|_| Error) groth16.rs:456
     res.ok = true;
     return res;

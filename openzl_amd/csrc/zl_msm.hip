@@ -28,7 +28,7 @@
 #define ZL_GCAT(a, b) ZL_GCAT_(a, b)
 #define ZL_GNAME(f) ZL_GCAT(f, ZL_G)
 
-#define ZL_CHUNK 64        // entries per lane in msm_accumulate
+#define ZL_CHUNK_MAX 64    // entries per lane in msm_accumulate (smaller for small inputs: more lanes, shorter chains)
 #define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
 #define ZL_SEG 16          // buckets per lane in msm_reduce
 
@@ -225,7 +225,7 @@ template <class G>
 __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums,
-                                                        XYZZ<typename G::F>* __restrict__ partials) {
+                                                        XYZZ<typename G::F>* __restrict__ partials, uint32_t ZL_CHUNK) {
     using F = typename G::F;
     const uint32_t E = offsets[NB];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t* __restric
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
-                                                   uint32_t* __restrict__ big_count) {
+                                                   uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
     using F = typename G::F;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
 template <class G>
 __global__ void __launch_bounds__(256) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
-                                                        const uint32_t* __restrict__ big_count) {
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -423,12 +423,13 @@ __global__ void __launch_bounds__(64) k_bases_generate(const uint32_t* __restric
 
 // ------------------------------------------------------------------------------------------------ host driver
 static int zl_pick_window(size_t n, int sc_bits) {
-    // minimise accumulate adds (n per window) + per-bucket overhead (merge + reduce, ~16 add-equivalents)
+    // accumulate: n mixed adds per window; per-bucket overhead (merge + segmented reduce) measured at ~2 add-equivalents
+    // (tools/msm_sweep.py: c = 16 wins from 2^18 up, c = 13 at 2^16).  c <= 16 keeps the LDS counting sort.
     double best = 1e300;
     int best_c = 2;
-    for (int c = 2; c <= 20; c++) {
+    for (int c = 2; c <= 16; c++) {
         int W = (sc_bits + 1 + c - 1) / c;
-        double cost = (double)n * W + 16.0 * W * (double)(1u << (c - 1));
+        double cost = (double)n * W + 2.0 * W * (double)(1u << (c - 1));
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
@@ -450,6 +451,9 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         const uint64_t maxE = (uint64_t)n * W;
         if (n >= (1ull << 31) || maxE >= (1ull << 32) || NB64 >= (1ull << 31)) return ZL_EINVAL;
         const uint32_t NB = (uint32_t)NB64;
+        // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
+        uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
+        while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         const uint32_t segs_per_window = (H + ZL_SEG - 1) / ZL_SEG;
         const uint32_t total_segs = segs_per_window * W;
@@ -521,11 +525,11 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries);
         }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials);
+        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count);
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(256), 256 * sizeof(X), st, d_offsets, d_buckets,
-                           d_partials, d_big_list, d_big_count);
+                           d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_window, total_segs, d_segs);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(W), dim3(256), 256 * sizeof(X), st, d_segs, segs_per_window, d_windows);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""MSM size / window sweep on the GPU (device-resident inputs): prints ms and points/s per (log_n, c)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import random_scalars_lt_r
+from openzl_amd import Backend, ZL_BLS12_381, ZL_G2
+
+be = Backend(0); be.enable_timing(True)
+dev = torch.device("cuda", 0)
+group = ZL_G2 if "--g2" in sys.argv else 1
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [16, 18, 20, 22, 24]
+nmax = 1 << max(sizes)
+k = random_scalars_lt_r(nmax, 1); h = be.bases_generate(ZL_BLS12_381, k, group=group)
+s = torch.from_numpy(random_scalars_lt_r(nmax, 2).view(np.int64)).to(dev)
+for ln in sizes:
+    n = 1 << ln
+    for c in [0] + ([int(x) for x in os.environ.get("CS", "").split(",") if x]):
+        be.set_msm_window(c)
+        be.msm_dev(h, s.data_ptr(), n)
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); be.msm_dev(h, s.data_ptr(), n); ts.append(time.perf_counter() - t0)
+        tm = be.last_timing()
+        print(f"2^{ln} c={tm.window_bits:2d}: wall {min(ts)*1e3:8.3f} ms  dev {tm.total_ms:8.3f} ms  acc {tm.dominant_ms:8.3f} ms  {n/min(ts)/1e6:8.1f} Mpts/s", flush=True)
