@@ -119,11 +119,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    if os.environ.get("ZL_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()  # test mode: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # nccl = RCCL over xGMI.  ZL_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a single-GPU box.
+        backend = os.environ.get("ZL_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     be = Backend(local_rank)
     be.enable_timing(True)
@@ -153,7 +160,8 @@ def main():
 
     def step():
         # local Pippenger -> 1 partial sum; N > 1: all_gather over RCCL + fold on every rank (openzl_amd/sharded.py)
-        return sharded_msm(lambda: be.msm_partial_dev(h, d_scalars.data_ptr(), n), ZL_BLS12_381, device=dev)
+        gather_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
+        return sharded_msm(lambda: be.msm_partial_dev(h, d_scalars.data_ptr(), n), ZL_BLS12_381, device=gather_dev)
 
     def barrier():
         if world > 1:
@@ -174,7 +182,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = be.last_timing()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -254,6 +262,15 @@ def main():
         value = pts / elapsed
         dom = float(np.mean(dom_ms))
         achieved = 128.0 * n / (dom * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.log_n == 24 and int(tm.window_bits) == 16:
+                traffic = pmc["k_msm_accumulate_traffic_bytes"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "MSM points/sec (BLS12-381 G1)",
             "value": value,
@@ -272,7 +289,8 @@ def main():
                        "window_bits": int(tm.window_bits), "parallelism": f"shard{world}" if world > 1 else "single",
                        "result_check": "known-discrete-log prefix check passed; bit-exact parity in tests/"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_msm_accumulate",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
