@@ -178,8 +178,11 @@ __device__ __forceinline__ Fp<P> mul_dev(const Fp<P>& a, const Fp<P>& b) {
 #else
 #define ZL_NOINLINE_HD __attribute__((noinline))
 #endif
+// Operands are passed as scalar u32 arguments so that the AMDGPU calling convention keeps all of them in VGPRs
+// (v0..v23): passing two 48-byte structs by value sent the second one through scratch memory (3 x 16-B stores + loads
+// + an s_waitcnt vmcnt(0) per call; 14.8 GB of scratch writes per 2^24 MSM in the first PMC pass).
 template <class P>
-ZL_NOINLINE_HD Fp<P> mul_call(Fp<P> a, Fp<P> b) {
+ZL_HD Fp<P> mul_impl(const Fp<P>& a, const Fp<P>& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_PORTABLE_MUL)
     return mul_dev(a, b);
 #else
@@ -187,27 +190,47 @@ ZL_NOINLINE_HD Fp<P> mul_call(Fp<P> a, Fp<P> b) {
 #endif
 }
 template <class P>
-ZL_NOINLINE_HD Fp<P> sqr_call(Fp<P> a) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_PORTABLE_MUL)
-    return mul_dev(a, a);
-#else
-    return mul_body(a, a);
-#endif
+ZL_NOINLINE_HD Fp<P> mul_call8(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7) {
+    Fp<P> a, b;
+    a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7;
+    b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7;
+    return mul_impl(a, b);
+}
+template <class P>
+ZL_NOINLINE_HD Fp<P> sqr_call8(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7) {
+    Fp<P> a;
+    a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7;
+    return mul_impl(a, a);
+}
+template <class P>
+ZL_NOINLINE_HD Fp<P> mul_call12(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
+    Fp<P> a, b;
+    a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11;
+    b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11;
+    return mul_impl(a, b);
+}
+template <class P>
+ZL_NOINLINE_HD Fp<P> sqr_call12(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11) {
+    Fp<P> a;
+    a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11;
+    return mul_impl(a, a);
 }
 template <class P>
 ZL_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
 #if !defined(ZL_INLINE_MUL)
-    return mul_call<P>(a, b);
+    if constexpr (P::N == 8) return mul_call8<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7]);
+    else return mul_call12<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
 #else
-    return mul_body(a, b);
+    return mul_impl(a, b);
 #endif
 }
 template <class P>
 ZL_HD Fp<P> sqr(const Fp<P>& a) {
 #if !defined(ZL_INLINE_MUL)
-    return sqr_call<P>(a);
+    if constexpr (P::N == 8) return sqr_call8<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7]);
+    else return sqr_call12<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11]);
 #else
-    return mul_body(a, a);
+    return mul_impl(a, a);
 #endif
 }
 

@@ -221,8 +221,11 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
     return lo;
 }
 
+#ifndef ZL_ACC_WAVES
+#define ZL_ACC_WAVES 2  // waves per SIMD the accumulate kernel is register-budgeted for
+#endif
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+__global__ void __launch_bounds__(64, ZL_ACC_WAVES) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         XYZZ<typename G::F>* __restrict__ partials, uint32_t ZL_CHUNK) {
