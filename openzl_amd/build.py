@@ -35,7 +35,7 @@ def _digest(paths, extra="") -> str:
 
 
 def _units():
-    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", []), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
     for g in GROUPS:
         units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"]))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]

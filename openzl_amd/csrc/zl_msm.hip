@@ -146,6 +146,45 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_lds(const uint16_t*
     }
 }
 
+// block (range, w): owns buckets [range*RB, (range+1)*RB) of window w, streams ALL digits of the window (coalesced u16) and
+// scatters the matching entries through LDS cursors.  One block writes one contiguous, L2-resident slice of the entry list,
+// so partial-sector writes merge in L2 (the slice-owned variant measured 8.5 GB of HBM writes for 1 GB of entries).
+static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t RB,
+                                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t range = blockIdx.x, w = blockIdx.y;
+    const uint32_t b0 = range * RB;
+    const uint32_t* os = offsets + (size_t)w * H + b0;
+    for (uint32_t b = threadIdx.x; b < RB; b += blockDim.x) cur[b] = (b0 + b < H) ? os[b] : 0;
+    __syncthreads();
+    const uint16_t* dw = digits + (size_t)w * n;
+    // 16-byte loads: 8 digits per lane per iteration (the window's digit row is 16-B aligned when n % 8 == 0)
+    const uint32_t n8 = ((((size_t)w * n) & 7) == 0) ? (n & ~7u) : 0;
+    const uint4* dv = reinterpret_cast<const uint4*>(dw);
+    for (uint32_t i8 = threadIdx.x; i8 < n8 / 8; i8 += blockDim.x) {
+        const uint4 v = dv[i8];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t code = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const uint32_t bucket = code & 0x7FFFu;
+            if (code != 0xFFFFu && bucket - b0 < RB) {
+                const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
+                entries[pos] = (i8 * 8 + k) | ((code >> 15) << 31);
+            }
+        }
+    }
+    for (uint32_t i = n8 + threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t code = dw[i];
+        const uint32_t bucket = code & 0x7FFFu;
+        if (code != 0xFFFFu && bucket - b0 < RB) {
+            const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
+            entries[pos] = i | ((code >> 15) << 31);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan of `count` u32 values, 3 launches; out[count] = total
 #define SCAN_ITEMS 16
@@ -517,8 +556,11 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            hipLaunchKernelGGL(k_msm_scatter_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts,
-                               d_offsets, d_entries);
+            // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
+            uint32_t ranges = 1;
+            while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
+            const uint32_t RB = (H + ranges - 1) / ranges;
+            hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {
             // wide windows: histogram / scatter with global atomics
             hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);

@@ -17,7 +17,7 @@
 #include <vector>
 #include "zl_ctx.h"
 
-#define NTT_THREADS 256
+#define NTT_THREADS 512
 #define NTT_TILE 2048   // elements per workgroup tile (64 KiB of LDS)
 #define NTT_MAX_S 10
 
