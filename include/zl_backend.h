@@ -74,6 +74,10 @@ int zl_bases_upload(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const void*
 /* bases[i] = k[i] * generator, computed on the device (k: n x 4 u64 canonical, host memory).  Input generator
  * for tests and benches: gives MSM inputs with known discrete logs. */
 int zl_bases_generate(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const uint64_t* k, size_t n, uint64_t* handle_out);
+/* Optional, MI355X-sized trade of HBM for work: store 2^(c w) P_i for every window w next to the bases (W x the memory:
+ * 19 GB for 2^24 BLS12-381 G1 points at c = 22) so that all windows share ONE bucket set and c can grow to 22: 12 instead of
+ * 16 mixed additions per point.  c = 0 picks c from n.  MSMs on the handle then use the table; results are unchanged. */
+int zl_bases_precompute(zl_ctx* ctx, uint64_t handle, int c);
 /* copy bases back as canonical affine x||y (tests) */
 int zl_bases_download(zl_ctx* ctx, uint64_t handle, size_t first, size_t count, uint64_t* out_xy);
 int zl_bases_free(zl_ctx* ctx, uint64_t handle);

@@ -23,7 +23,7 @@ u8p = C.POINTER(C.c_uint8)
 # every symbol include/zl_backend.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
-    "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_free", "zl_msm",
+    "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
     "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit",
@@ -83,6 +83,7 @@ def load_library(path: Optional[str] = None):
     L.zl_bases_generate.argtypes = [vp, C.c_int, C.c_int, u64p, C.c_size_t, u64p]
     L.zl_bases_download.argtypes = [vp, C.c_uint64, C.c_size_t, C.c_size_t, u64p]
     L.zl_bases_free.argtypes = [vp, C.c_uint64]
+    L.zl_bases_precompute.argtypes = [vp, C.c_uint64, C.c_int]
     L.zl_msm.argtypes = [vp, C.c_uint64, C.c_size_t, u64p, C.c_size_t, u64p, u8p]
     L.zl_msm_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p, u8p]
     L.zl_msm_partial_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p]
@@ -186,6 +187,10 @@ class Backend:
         out = np.zeros((count, 2 * group * FQ_LIMBS[curve]), dtype=np.uint64)
         self._check(self.L.zl_bases_download(self._ctx, handle, first, count, _p64(out)), "zl_bases_download")
         return out
+
+    def bases_precompute(self, handle: int, c: int = 0):
+        """build the table of 2^(c w) P_i (W x memory) so that all windows share one bucket set"""
+        self._check(self.L.zl_bases_precompute(self._ctx, handle, c), "zl_bases_precompute")
 
     def bases_free(self, handle: int):
         self._check(self.L.zl_bases_free(self._ctx, handle), "zl_bases_free")

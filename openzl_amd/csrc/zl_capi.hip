@@ -44,7 +44,10 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->bases) if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
+    for (auto& kv : ctx->bases) {
+        if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
+        if (kv.second.d_table) (void)hipFree(kv.second.d_table);
+    }
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
     zl_ntt_free(ctx);
@@ -128,12 +131,20 @@ int zl_bases_download(zl_ctx* ctx, uint64_t handle, size_t first, size_t count, 
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     return ZL_DISPATCH(it->second.curve, it->second.group, zl_bases_download, ctx, it->second, first, count, out_xy);
 }
+int zl_bases_precompute(zl_ctx* ctx, uint64_t handle, int c) {
+    if (!ctx || c < 0) return ZL_EINVAL;
+    auto it = ctx->bases.find(handle);
+    if (it == ctx->bases.end()) return ZL_EHANDLE;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return ZL_DISPATCH(it->second.curve, it->second.group, zl_bases_precompute, ctx, it->second, c);
+}
 int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     if (!ctx) return ZL_EINVAL;
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ZL_EHANDLE;
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_pts) (void)hipFree(it->second.d_pts);
+    if (it->second.d_table) (void)hipFree(it->second.d_table);
     ctx->bases.erase(it);
     return ZL_OK;
 }

@@ -64,6 +64,8 @@ using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, 254, 4>;
 // ---- context ----------------------------------------------------------------------------------------------
 struct zl_bases {
     void* d_pts = nullptr;  // Affine<F>[n], Montgomery
+    void* d_table = nullptr;  // optional Affine<F>[W][n]: 2^(c w) P_i (zl_bases_precompute)
+    int precomp_c = 0;
     size_t n = 0;
     int curve = 0, group = 0;
 };
@@ -128,7 +130,8 @@ inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
     int zl_partials_fold_##G(const uint64_t* partials, size_t count, uint64_t* out_partial);                                \
     int zl_bases_upload_##G(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out); \
     int zl_bases_generate_##G(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out);                                     \
-    int zl_bases_download_##G(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy);
+    int zl_bases_download_##G(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy);                \
+    int zl_bases_precompute_##G(zl_ctx* ctx, zl_bases& b, int c);
 ZL_DECL_GROUP(BlsG1)
 ZL_DECL_GROUP(BnG1)
 ZL_DECL_GROUP(BlsG2)

@@ -15,6 +15,7 @@
 //   6. msm_reduce    sum_k k*B_k per window by segmented running sums, then a block tree per window
 //   7. host          Horner over the W window sums (a few hundred field ops), returned as an XYZZ partial
 // The result does not depend on c, on the digit signs or on the order entries land in a bucket (group law).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -183,6 +184,137 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
             entries[pos] = i | ((code >> 15) << 31);
         }
     }
+}
+
+// ---- wide windows over precomputed multiples (zl_bases_precompute): ONE bucket set of 2^(c-1) buckets, c up to 24 ----------
+// Every (scalar i, window w) digit d contributes d * (2^(c w) P_i), and 2^(c w) P_i is a table entry, so all windows
+// share the buckets: n*W mixed adds into 2^(c-1) buckets and a single bucket reduction.  The bucket index has up to 23
+// bits, so the counting sort is two-level: partition by the high bits (group = bucket >> 15), then the LDS sort per group.
+static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                                                  uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 lo = sp[0], hi = sp[1];
+    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const uint32_t H = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        const int pos = w * c;
+        const int word = pos >> 5, sh = pos & 31;
+        uint64_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k == word) v |= s[k];
+            if (k == word + 1) v |= (uint64_t)s[k] << 32;
+        }
+        uint32_t d = ((uint32_t)(v >> sh) & ((1u << c) - 1)) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
+        const uint32_t b = d - 1;  // bucket (d != 0)
+        lo16[(size_t)w * n + i] = (uint16_t)((b & 0x7FFFu) | (neg << 15));
+        hi8[(size_t)w * n + i] = d == 0 ? (uint8_t)0xFF : (uint8_t)(b >> 15);
+    }
+}
+// block (slice, w): histogram of the group ids of window w over a slice of scalars -> counts[(g*W + w)*nslices + slice]
+static __global__ void __launch_bounds__(256) k_msm_part_hist(const uint8_t* __restrict__ hi8, uint32_t n, uint32_t W, uint32_t G, uint32_t per_slice,
+                                                                uint32_t nslices, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[256];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
+    const uint8_t* hw = hi8 + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t g = hw[i];
+        if (g != 0xFFu) atomicAdd(&hist[g], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) counts[((size_t)threadIdx.x * W + w) * nslices + slice] = hist[threadIdx.x];
+}
+// block (slice, w): scatter (fine code, table index) into the group-partitioned lists
+static __global__ void __launch_bounds__(256) k_msm_part_scatter(const uint16_t* __restrict__ lo16, const uint8_t* __restrict__ hi8, uint32_t n, uint32_t W,
+                                                                   uint32_t G, uint32_t per_slice, uint32_t nslices, const uint32_t* __restrict__ part_off,
+                                                                   uint32_t table_stride, uint32_t first, uint16_t* __restrict__ out_lo,
+                                                                   uint32_t* __restrict__ out_idx) {
+    __shared__ uint32_t cur[256];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    if (threadIdx.x < G) cur[threadIdx.x] = part_off[((size_t)threadIdx.x * W + w) * nslices + slice];
+    __syncthreads();
+    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
+    const uint8_t* hw = hi8 + (size_t)w * n;
+    const uint16_t* lw = lo16 + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t g = hw[i];
+        if (g != 0xFFu) {
+            const uint32_t pos = atomicAdd(&cur[g], 1u);
+            out_lo[pos] = lw[i];
+            out_idx[pos] = w * table_stride + first + i;
+        }
+    }
+}
+// group range [s, e) from the scanned partition counters
+__device__ __forceinline__ void zl_group_range(const uint32_t* __restrict__ part_off, uint32_t g, uint32_t G, uint32_t stride, uint32_t E, uint32_t& s,
+                                               uint32_t& e) {
+    s = part_off[(size_t)g * stride];
+    e = (g + 1 < G) ? part_off[(size_t)(g + 1) * stride] : E;
+}
+// block (slice, g): LDS histogram of the 15-bit fine bucket over a slice of group g's list -> counts[slice][g*32768 + bin]
+static __global__ void __launch_bounds__(1024) k_msm_hist_group(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_off, uint32_t G,
+                                                                 uint32_t stride, const uint32_t* __restrict__ total, uint32_t nslices, uint32_t NB,
+                                                                 uint32_t* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t slice = blockIdx.x, g = blockIdx.y;
+    for (uint32_t b = threadIdx.x; b < 32768; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    uint32_t s, e;
+    zl_group_range(part_off, g, G, stride, *total, s, e);
+    const uint32_t per = (e - s + nslices - 1) / nslices;
+    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[part_lo[j] & 0x7FFFu], 1u);
+    __syncthreads();
+    uint32_t* out = counts + (size_t)slice * NB + (size_t)g * 32768;
+    for (uint32_t b = threadIdx.x; b < 32768; b += blockDim.x) out[b] = hist[b];
+}
+// block (range, g): owns fine buckets [range*RB, (range+1)*RB) of group g; streams the group's list, LDS cursors
+static __global__ void __launch_bounds__(1024) k_msm_scatter_group(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_idx,
+                                                                    const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
+                                                                    const uint32_t* __restrict__ total, uint32_t RB, const uint32_t* __restrict__ offsets,
+                                                                    uint32_t* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t range = blockIdx.x, g = blockIdx.y;
+    const uint32_t b0 = range * RB;
+    const uint32_t* os = offsets + (size_t)g * 32768 + b0;
+    for (uint32_t b = threadIdx.x; b < RB; b += blockDim.x) cur[b] = os[b];
+    __syncthreads();
+    uint32_t s, e;
+    zl_group_range(part_off, g, G, stride, *total, s, e);
+    // scalar head up to a 16-B boundary, 8 codes per 16-B load in the body, scalar tail
+    const uint32_t body0 = min(e, (s + 7u) & ~7u), body1 = max(body0, e & ~7u);
+    auto emit = [&](uint32_t idx, uint32_t code) {
+        const uint32_t bucket = code & 0x7FFFu;
+        if (bucket - b0 < RB) {
+            const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
+            entries[pos] = idx | ((code >> 15) << 31);
+        }
+    };
+    for (uint32_t j = s + threadIdx.x; j < body0; j += blockDim.x) emit(part_idx[j], part_lo[j]);
+    const uint4* dv = reinterpret_cast<const uint4*>(part_lo);
+    const uint4* iv = reinterpret_cast<const uint4*>(part_idx);
+    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
+        // 8 codes (16 B) + their 8 table indices (2 x 16 B) per lane, loaded unconditionally: per-match 4-B gathers made
+        // this kernel 27 ms (8 divergent loads per iteration, 16 cache lines each)
+        const uint4 v = dv[j8];
+        const uint4 i0 = iv[2 * (size_t)j8], i1 = iv[2 * (size_t)j8 + 1];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t idxs[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) emit(idxs[k], (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+    }
+    for (uint32_t j = body1 + threadIdx.x; j < e; j += blockDim.x) emit(part_idx[j], part_lo[j]);
 }
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -382,17 +514,20 @@ __global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>
     }
     seg_out[t] = acc;
 }
-// block per window: tree-sum the segment results
+// tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
+// set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
+// two-stage sum for sets with many segments.
 template <class G>
-__global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t segs_per_window,
-                                                         XYZZ<typename G::F>* __restrict__ window_sums) {
+__global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
+                                                         uint32_t parts, XYZZ<typename G::F>* __restrict__ out) {
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-    const uint32_t w = blockIdx.x;
+    const uint32_t set = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint32_t lo = part * count, hi = min(set_stride, lo + count);
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t s = threadIdx.x; s < segs_per_window; s += blockDim.x) {
-        const XYZZ<F> p = seg_out[(size_t)w * segs_per_window + s];
+    for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) {
+        const XYZZ<F> p = seg_out[(size_t)set * set_stride + s];
         zl::add_full(acc, p);
     }
     sh[threadIdx.x] = acc;
@@ -406,7 +541,7 @@ __global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) window_sums[w] = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
 // ------------------------------------------------------------------------------------------------ bases kernels
@@ -463,6 +598,25 @@ __global__ void __launch_bounds__(64) k_bases_generate(const uint32_t* __restric
     out[i] = zl::to_affine(acc);
 }
 
+// table[w][i] = 2^(c w) * P_i (affine), w < W: c doublings per level, one inversion per level (upload-time, untimed)
+template <class G>
+__global__ void __launch_bounds__(64) k_bases_precompute(const Affine<typename G::F>* __restrict__ in, uint32_t n, int c, int W,
+                                                          Affine<typename G::F>* __restrict__ table) {
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = in[i];
+    table[i] = p;
+    for (int w = 1; w < W; w++) {
+        if (!p.is_inf()) {
+            XYZZ<F> q = zl::dbl_affine(p.x, p.y);
+            for (int k = 1; k < c; k++) zl::dbl_inplace(q);
+            p = zl::to_affine(q);
+        }
+        table[(size_t)w * n + i] = p;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host driver
 static int zl_pick_window(size_t n, int sc_bits) {
     // accumulate: n mixed adds per window; per-bucket overhead (merge + segmented reduce) measured at ~2 add-equivalents
@@ -477,6 +631,18 @@ static int zl_pick_window(size_t n, int sc_bits) {
     return best_c;
 }
 
+static int zl_pick_window_precomp(size_t n, int sc_bits) {
+    // merged windows: n*W mixed adds + ONE bucket set of 2^(c-1) buckets (merge + reduce ~6 add-equivalents per bucket)
+    double best = 1e300;
+    int best_c = 16;
+    for (int c = 16; c <= 23; c++) {
+        int W = (sc_bits + 1 + c - 1) / c;
+        double cost = (double)n * W + 6.0 * (double)(1u << (c - 1));
+        if (cost < best) { best = cost; best_c = c; }
+    }
+    return best_c;
+}
+
 template <class G>
 static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     using F = typename G::F;
@@ -484,23 +650,29 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
     X total = X::inf();
     ctx->timing = zl_timing{};
     if (n > 0) {
-        int c = ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS);
+        const bool pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
+        int c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS));
         if (c < 2) c = 2;
-        if (c > 22) c = 22;
+        if (c > 24) c = 24;
         const int W = (G::SC_BITS + 1 + c - 1) / c;
         const uint32_t H = 1u << (c - 1);
-        const uint64_t NB64 = (uint64_t)W * H;
+        const uint32_t SETS = pre ? 1u : (uint32_t)W;  // bucket sets
+        const uint64_t NB64 = (uint64_t)SETS * H;
         const uint64_t maxE = (uint64_t)n * W;
         if (n >= (1ull << 31) || maxE >= (1ull << 32) || NB64 >= (1ull << 31)) return ZL_EINVAL;
+        if (pre && (uint64_t)W * bs.n >= (1ull << 31)) return ZL_EINVAL;
         const uint32_t NB = (uint32_t)NB64;
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
-        const uint32_t segs_per_window = (H + ZL_SEG - 1) / ZL_SEG;
-        const uint32_t total_segs = segs_per_window * W;
+        const uint32_t segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
+        const uint32_t total_segs = segs_per_set * SETS;
         const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
         const uint32_t max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
+        // tree over the segment results: sets with many segments are summed in two stages
+        const uint32_t SUMW = 2048;
+        const uint32_t stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
 
         uint32_t *d_counts, *d_offsets, *d_cursor, *d_entries, *d_small;
         X *d_buckets, *d_partials, *d_segs;
@@ -522,19 +694,77 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         d_buckets = (X*)p;
         if ((rc = zl_scratch_get(ctx, 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
         d_partials = (X*)p;
-        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + W) * sizeof(X), &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + (size_t)SETS * (stage1 + 1) + 1) * sizeof(X), &p))) return rc;
         d_segs = (X*)p;
-        X* d_windows = d_segs + total_segs;
+        X* d_stage1 = d_segs + total_segs;
+        X* d_sets = d_stage1 + (size_t)SETS * stage1;
 
         hipStream_t st = ctx->stream;
-        const Affine<F>* d_bases = reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
+        const Affine<F>* d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 4, st));
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
-        if (c <= 16) {
-            // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, LDS-cursor scatter
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_done = true;
+        }
+        if (pre) {
+            // ---- two-level counting sort over the merged bucket set ------------------------------------------------------
+            if (c < 16) return ZL_EINVAL;
+            const uint32_t Gn = H >> 15;  // groups of 32768 fine buckets
+            if (Gn < 1 || Gn > 256) return ZL_EINVAL;
+            uint32_t nslices = 64;
+            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+            if (nslices > max_slices) nslices = max_slices;
+            const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
+            const uint32_t P = Gn * W * nslices;  // partition counters, order (group, window, slice)
+            const uint32_t pscan_blocks = (P + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            uint32_t fslices = (256 + Gn - 1) / Gn;  // fine-histogram slices per group
+            const size_t b_lo = (((size_t)n * W * 2 + 255) / 256) * 256, b_hi = (((size_t)n * W + 255) / 256) * 256;
+            const size_t b_plo = b_lo, b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
+            const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256, b_fc = (size_t)fslices * NB * 4;
+            void* pd;
+            if ((rc = zl_scratch_get(ctx, 5, b_lo + b_hi + b_plo + b_pidx + b_pc + b_fc + 256, &pd))) return rc;
+            unsigned char* q = (unsigned char*)pd;
+            uint16_t* d_lo16 = (uint16_t*)q; q += b_lo;
+            uint8_t* d_hi8 = (uint8_t*)q; q += b_hi;
+            uint16_t* d_part_lo = (uint16_t*)q; q += b_plo;
+            uint32_t* d_part_idx = (uint32_t*)q; q += b_pidx;
+            uint32_t* d_pcounts = (uint32_t*)q;
+            uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
+            uint32_t* d_pblock = d_poff + P + 1;
+            q += b_pc;
+            uint32_t* d_fcounts = (uint32_t*)q;
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_lo16, d_hi8);
+            hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
+            hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
+            hipLaunchKernelGGL(k_msm_part_scatter, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
+                               (uint32_t)bs.n, (uint32_t)first, d_part_lo, d_part_idx);
+            const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
+            hipLaunchKernelGGL(k_msm_hist_group, dim3(fslices, Gn), dim3(1024), (size_t)32768 * 4, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fslices, NB,
+                               d_fcounts);
+            hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_fcounts, NB, fslices, d_counts);
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+            // small write slices win (measured at 2^24, c = 22: ranges 4 -> 16.0 ms, 64 -> ~7 ms): 512 buckets per block
+            uint32_t ranges = 64;
+            while (ranges * Gn < 256 && ranges < 256) ranges *= 2;
+            if (getenv("ZL_TUNE_RANGES_WIDE")) ranges = (uint32_t)atoi(getenv("ZL_TUNE_RANGES_WIDE"));
+            if (ranges < 1 || ranges > 32768 || (32768 % ranges)) return ZL_EINVAL;
+            const uint32_t RB = 32768 / ranges;
+            hipLaunchKernelGGL(k_msm_scatter_group, dim3(ranges, Gn), dim3(1024), (size_t)RB * 4, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, RB,
+                               d_offsets, d_entries);
+        } else if (c <= 16) {
+            // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
             uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
@@ -544,12 +774,6 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                attr_done = true;
-            }
             hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
@@ -559,10 +783,11 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
             uint32_t ranges = 1;
             while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
+            if (getenv("ZL_TUNE_RANGES")) ranges = std::max(1, atoi(getenv("ZL_TUNE_RANGES")));
             const uint32_t RB = (H + ranges - 1) / ranges;
             hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {
-            // wide windows: histogram / scatter with global atomics
+            // wide windows without a table: histogram / scatter with global atomics
             hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
@@ -575,13 +800,19 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(256), 256 * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
-        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_window, total_segs, d_segs);
-        hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(W), dim3(256), 256 * sizeof(X), st, d_segs, segs_per_window, d_windows);
+        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs);
+        if (stage1) {
+            // (set, part) partial sums of SUMW segment results each, then one block per set over the partials
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS * stage1), dim3(256), 256 * sizeof(X), st, d_segs, SUMW, segs_per_set, stage1, d_stage1);
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(256), 256 * sizeof(X), st, d_stage1, stage1, stage1, 1u, d_sets);
+        } else {
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(256), 256 * sizeof(X), st, d_segs, segs_per_set, segs_per_set, 1u, d_sets);
+        }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
         ZL_HIP(ctx, hipGetLastError());
-        std::vector<X> hw(W);
+        std::vector<X> hw(SETS);
         uint32_t hE = 0;
-        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_windows, sizeof(X) * W, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_sets, sizeof(X) * SETS, hipMemcpyDeviceToHost, st));
         ZL_HIP(ctx, hipMemcpyAsync(&hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
         ZL_HIP(ctx, hipStreamSynchronize(st));
         if (ctx->timing_on) {
@@ -591,10 +822,14 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         ctx->timing.launches = 1;
         ctx->timing.window_bits = (uint32_t)c;
         ctx->timing.entries = hE;
-        // Horner over windows, high to low: total = sum 2^(c*w) * window[w]
-        for (int w = W - 1; w >= 0; w--) {
-            if (w != W - 1) for (int k = 0; k < c; k++) zl::dbl_inplace(total);
-            zl::add_full(total, hw[w]);
+        if (pre) {
+            total = hw[0];  // the table already carries the 2^(c w) factors
+        } else {
+            // Horner over windows, high to low: total = sum 2^(c*w) * window[w]
+            for (int w = W - 1; w >= 0; w--) {
+                if (w != W - 1) for (int k = 0; k < c; k++) zl::dbl_inplace(total);
+                zl::add_full(total, hw[w]);
+            }
         }
     }
     static_assert(sizeof(X) <= ZL_PARTIAL_WORDS * 8, "partial too small");
@@ -602,6 +837,30 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
     memcpy(out_partial, &total, sizeof(X));
     return ZL_OK;
 }
+
+// table[w][i] = 2^(c w) P_i for every base of the handle (one-time, at upload)
+template <class G>
+static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
+    using F = typename G::F;
+    if (c == 0) c = zl_pick_window_precomp(bs.n, G::SC_BITS);
+    if (c < 16 || c > 23) return ZL_EINVAL;
+    const int W = (G::SC_BITS + 1 + c - 1) / c;
+    if ((uint64_t)W * bs.n >= (1ull << 31)) return ZL_EINVAL;
+    if (bs.d_table) { ZL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(bs.d_table); bs.d_table = nullptr; bs.precomp_c = 0; }
+    void* t = nullptr;
+    ZL_HIP(ctx, hipMalloc(&t, std::max<size_t>(bs.n, 1) * W * sizeof(Affine<F>)));
+    if (bs.n) {
+        hipLaunchKernelGGL((k_bases_precompute<G>), dim3((uint32_t)((bs.n + 63) / 64)), dim3(64), 0, ctx->stream, reinterpret_cast<const Affine<F>*>(bs.d_pts),
+                           (uint32_t)bs.n, c, W, reinterpret_cast<Affine<F>*>(t));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(t); return ZL_EHIP; }
+    }
+    bs.d_table = t;
+    bs.precomp_c = c;
+    return ZL_OK;
+}
+int ZL_GNAME(zl_bases_precompute)(zl_ctx* ctx, zl_bases& b, int c) { return bases_precompute_t<ZL_G>(ctx, b, c); }
 
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);

@@ -155,3 +155,42 @@ def test_msm_skewed_scalars_bls(backend):
     r = curve.fr.p
     dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % r
     assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("c", [16, 17, 19, 21])
+def test_msm_precomputed_table_matches_plain(backend, curve, c):
+    """zl_bases_precompute (table of 2^(c w) P_i, merged bucket set, two-level sort) must not change any result."""
+    n = 5000
+    k, B = _bases(curve, n, 71)
+    S = ol.random_scalars(curve, n, 72)
+    S[0] = 0
+    S[1] = ol.ints_to_limbs([1], 4)[0]
+    S[2] = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]
+    S[100:400] = S[100]
+    B[5] = 0
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=8)
+    h = backend.bases_upload(curve.cid, B)
+    plain = backend.msm(h, S)
+    backend.bases_precompute(h, c)
+    got, inf = backend.msm(h, S)
+    sub, sinf = backend.msm(h, S[1000:3000], first=1000)  # sub-range of a precomputed handle
+    backend.bases_free(h)
+    assert inf == einf and (got == exp).all() and (plain[0] == exp).all()
+    e2, e2inf = ol.oracle_msm_g1(curve, B[1000:3000], S[1000:3000], algo=0, threads=8)
+    assert sinf == e2inf and (sub == e2).all()
+
+
+def test_msm_precomputed_known_discrete_log_2_20(backend):
+    curve = po.BLS12_381
+    n = 1 << 20
+    k = ol.random_scalars(curve, n, 81)
+    S = ol.random_scalars(curve, n, 82)
+    S[: n // 4] = 0
+    S[n // 4: n // 2] = ol.ints_to_limbs([1], 4)[0]  # skewed: one giant bucket
+    h = backend.bases_generate(curve.cid, k)
+    backend.bases_precompute(h, 0)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % curve.fr.p
+    assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))

@@ -13,6 +13,26 @@ sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [16, 18, 20, 22, 24]
 nmax = 1 << max(sizes)
 k = random_scalars_lt_r(nmax, 1); h = be.bases_generate(ZL_BLS12_381, k, group=group)
 s = torch.from_numpy(random_scalars_lt_r(nmax, 2).view(np.int64)).to(dev)
+pre = [int(x) for x in os.environ.get("PRE", "").split(",") if x]
+if pre:
+    # precomputed tables: one handle per size (the table covers exactly the points used), c from PRE
+    be.bases_free(h)
+    for ln in sizes:
+        n = 1 << ln
+        for c in pre:
+            t0 = time.perf_counter()
+            hh = be.bases_generate(ZL_BLS12_381, k[:n], group=group)
+            t1 = time.perf_counter()
+            be.bases_precompute(hh, c)
+            t2 = time.perf_counter()
+            be.msm_dev(hh, s.data_ptr(), n)
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); be.msm_dev(hh, s.data_ptr(), n); ts.append(time.perf_counter() - t0)
+            tm = be.last_timing()
+            print(f"2^{ln} PRE c={tm.window_bits:2d}: wall {min(ts)*1e3:8.3f} ms  dev {tm.total_ms:8.3f} ms  acc {tm.dominant_ms:8.3f} ms  {n/min(ts)/1e6:8.1f} Mpts/s   (generate {t1-t0:.2f}s precompute {t2-t1:.2f}s)", flush=True)
+            be.bases_free(hh)
+    sys.exit(0)
 for ln in sizes:
     n = 1 << ln
     for c in [0] + ([int(x) for x in os.environ.get("CS", "").split(",") if x]):
