@@ -37,7 +37,8 @@ def _digest(paths, extra="") -> str:
 def _units():
     units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
     for g in GROUPS:
-        units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"]))
+        extra = ["-DZL_ACC_WAVES=1"] if g.endswith("G2") else []  # Fq2 accumulators: 1 wave/SIMD budget avoids scratch spills
+        units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"] + extra))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
 
 

@@ -4,16 +4,19 @@
 // /root/reference/plugins/arkworks/src/groth16.rs:454 through ark-groth16's create_proof).
 // arkworks walks the windows serially with unsigned c-bit digits and 2^c - 1 Jacobian buckets per window.  This
 // backend is organised for a 256-CU / wave64 machine instead:
-//   1. msm_count     signed-digit recoding of every scalar (2^(c-1) buckets per window), global histogram
-//   2. scan          exclusive prefix sum over all W * 2^(c-1) bucket counters
-//   3. msm_scatter   counting sort of (point index, sign) entries by bucket (all windows in one pass)
-//   4. msm_accumulate  the hot kernel: the sorted entry array is cut into fixed chunks of ZL_CHUNK entries, one lane
-//                    per chunk, XYZZ mixed additions; a bucket that lies inside one chunk is written directly,
-//                    buckets cut by chunk boundaries leave <= 2 partial sums per lane -> perfect load balance
-//                    whatever the scalar distribution (Groth16 witnesses are full of 0/1)
-//   5. msm_merge     one lane per bucket folds the partials of cut buckets (block-wide tree for giant buckets)
-//   6. msm_reduce    sum_k k*B_k per window by segmented running sums, then a block tree per window
-//   7. host          Horner over the W window sums (a few hundred field ops), returned as an XYZZ partial
+//   1. msm_recode     signed-digit recoding of every scalar, once (u16 per digit; 2^(c-1) buckets per window)
+//   2. msm_hist_lds   per-(slice, window) histograms in LDS (no global atomics), slice prefix, 3-kernel exclusive scan
+//   3. msm_scatter_range  counting-sort scatter of (point index, sign) entries: one block owns a bucket range of one
+//                    window (LDS cursors), streams that window's digits with 16-B loads
+//   4. msm_accumulate  the hot kernel: the sorted entry array is cut into fixed chunks of <= 64 entries, one lane per
+//                    chunk, XYZZ mixed additions in ONE flat loop; a bucket inside one chunk is written directly, buckets
+//                    cut by chunk boundaries leave <= 2 partial sums per lane -> perfect load balance whatever the scalar
+//                    distribution (Groth16 witnesses are full of 0/1)
+//   5. msm_merge      one lane per bucket folds the partials of cut buckets (block-wide tree for giant buckets)
+//   6. msm_reduce_seg / msm_window_sum   sum_k k*B_k per bucket set by segmented running sums + block trees
+//   7. host           Horner over the W window sums (a few hundred field ops), returned as an XYZZ partial
+// With zl_bases_precompute (table of 2^(c w) P_i, W x the memory) all windows share ONE bucket set, c grows to 22 (12
+// instead of 16 additions per point) and the sort becomes two-level (partition by bucket >> 15, then the LDS sort).
 // The result does not depend on c, on the digit signs or on the order entries land in a bucket (group law).
 #include <stdlib.h>
 #include <string.h>
@@ -125,28 +128,6 @@ static __global__ void __launch_bounds__(256) k_msm_slice_prefix(uint32_t* __res
     }
     tot[b] = run;
 }
-// block (slice, w): LDS cursors = bucket offset + this slice's prefix; scatter (index | sign << 31)
-static __global__ void __launch_bounds__(1024) k_msm_scatter_lds(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t per_slice, uint32_t NB,
-                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ entries) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t slice = blockIdx.x, w = blockIdx.y;
-    const uint32_t* cs = counts + (size_t)slice * NB + (size_t)w * H;
-    const uint32_t* os = offsets + (size_t)w * H;
-    for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) cur[b] = os[b] + cs[b];
-    __syncthreads();
-    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
-    const uint16_t* dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t code = dw[i];
-        if (code != 0xFFFFu) {
-            const uint32_t pos = atomicAdd(&cur[code & 0x7FFFu], 1u);
-            entries[pos] = i | ((code >> 15) << 31);
-        }
-    }
-}
-
 // block (range, w): owns buckets [range*RB, (range+1)*RB) of window w, streams ALL digits of the window (coalesced u16) and
 // scatters the matching entries through LDS cursors.  One block writes one contiguous, L2-resident slice of the entry list,
 // so partial-sector writes merge in L2 (the slice-owned variant measured 8.5 GB of HBM writes for 1 GB of entries).
