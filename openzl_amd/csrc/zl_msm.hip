@@ -298,6 +298,108 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_group(const uint16_
     for (uint32_t j = body1 + threadIdx.x; j < e; j += blockDim.x) emit(part_idx[j], part_lo[j]);
 }
 
+// ---- levels 2 and 3 of the wide sort: 128 sub-groups of 256 buckets per group, then an LDS-staged bucket sort -----------------
+// Measured on gfx950: a scattered 4-byte store costs about one 64-B L2 write transaction (~25 ps each at 2^24*12 entries), while
+// a partition into <= 128 streams writes long runs and an LDS-staged sort writes fully coalesced.  So: group (32768 buckets) ->
+// sub-group (256 buckets, ~25k entries) by one more partition pass, then one block per sub-group sorts its entries by bucket in
+// LDS and copies them out linearly.
+// block (slice, g): histogram of the sub-group id ((lo >> 8) & 127) over a slice of group g -> counts[(g*128 + sub)*fslices + slice]
+static __global__ void __launch_bounds__(256) k_msm_sub_hist(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_off, uint32_t G,
+                                                               uint32_t stride, const uint32_t* __restrict__ total, uint32_t fslices,
+                                                               uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[128];
+    const uint32_t slice = blockIdx.x, g = blockIdx.y;
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t s, e;
+    zl_group_range(part_off, g, G, stride, *total, s, e);
+    const uint32_t per = (e - s + fslices - 1) / fslices;
+    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
+    // 16-B loads (8 codes per lane) over the aligned body, scalar head / tail: the kernel is latency bound otherwise
+    const uint32_t body0 = min(hi, (lo + 7u) & ~7u), body1 = max(body0, hi & ~7u);
+    for (uint32_t j = lo + threadIdx.x; j < body0; j += blockDim.x) atomicAdd(&hist[(part_lo[j] >> 8) & 127u], 1u);
+    const uint4* dv = reinterpret_cast<const uint4*>(part_lo);
+    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
+        const uint4 v = dv[j8];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) atomicAdd(&hist[((words[k >> 1] >> ((k & 1) * 16)) >> 8) & 127u], 1u);
+    }
+    for (uint32_t j = body1 + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[(part_lo[j] >> 8) & 127u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 128) counts[((size_t)g * 128 + threadIdx.x) * fslices + slice] = hist[threadIdx.x];
+}
+static __global__ void __launch_bounds__(256) k_msm_sub_scatter(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_idx,
+                                                                  const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
+                                                                  const uint32_t* __restrict__ total, uint32_t fslices, const uint32_t* __restrict__ sub_off,
+                                                                  uint16_t* __restrict__ out_lo, uint32_t* __restrict__ out_idx) {
+    __shared__ uint32_t cur[128];
+    const uint32_t slice = blockIdx.x, g = blockIdx.y;
+    if (threadIdx.x < 128) cur[threadIdx.x] = sub_off[((size_t)g * 128 + threadIdx.x) * fslices + slice];
+    __syncthreads();
+    uint32_t s, e;
+    zl_group_range(part_off, g, G, stride, *total, s, e);
+    const uint32_t per = (e - s + fslices - 1) / fslices;
+    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
+    auto emit = [&](uint32_t code, uint32_t idx) {
+        const uint32_t pos = atomicAdd(&cur[(code >> 8) & 127u], 1u);
+        out_lo[pos] = (uint16_t)((code & 0xFFu) | (code & 0x8000u));  // fine bucket (8 bits) + sign
+        out_idx[pos] = idx;
+    };
+    const uint32_t body0 = min(hi, (lo + 7u) & ~7u), body1 = max(body0, hi & ~7u);
+    for (uint32_t j = lo + threadIdx.x; j < body0; j += blockDim.x) emit(part_lo[j], part_idx[j]);
+    const uint4* dv = reinterpret_cast<const uint4*>(part_lo);
+    const uint4* iv = reinterpret_cast<const uint4*>(part_idx);
+    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
+        const uint4 v = dv[j8];
+        const uint4 i0 = iv[2 * (size_t)j8], i1 = iv[2 * (size_t)j8 + 1];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t idxs[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) emit((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, idxs[k]);
+    }
+    for (uint32_t j = body1 + threadIdx.x; j < hi; j += blockDim.x) emit(part_lo[j], part_idx[j]);
+}
+// block per sub-group: histogram of its 256 buckets -> counts[sg*256 + bin]  (sg*256 + bin IS the bucket index)
+static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ sub_off, uint32_t SG,
+                                                                uint32_t fslices, const uint32_t* __restrict__ total, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[256];
+    const uint32_t sg = blockIdx.x;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t s = sub_off[(size_t)sg * fslices], e = (sg + 1 < SG) ? sub_off[(size_t)(sg + 1) * fslices] : *total;
+    for (uint32_t j = s + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[lo2[j] & 0xFFu], 1u);
+    __syncthreads();
+    counts[(size_t)sg * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+// block per sub-group: sort the sub-group's entries by bucket inside LDS (cursors = bucket offsets relative to the sub-group),
+// then copy the staged run to the entry list with consecutive lanes writing consecutive words.  Oversized sub-groups (skewed
+// scalars) fall back to direct scattered stores.
+static __global__ void __launch_bounds__(512) k_msm_fine_sort(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ idx2,
+                                                                const uint32_t* __restrict__ sub_off, uint32_t SG, uint32_t fslices,
+                                                                const uint32_t* __restrict__ total, const uint32_t* __restrict__ offsets, uint32_t cap,
+                                                                uint32_t* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [256]
+    uint32_t* stage = cur + 256;                        // [cap]
+    const uint32_t sg = blockIdx.x;
+    const uint32_t s = sub_off[(size_t)sg * fslices], e = (sg + 1 < SG) ? sub_off[(size_t)(sg + 1) * fslices] : *total;
+    const uint32_t base = offsets[(size_t)sg * 256];  // first entry slot of this sub-group (= s: same count, same order of groups)
+    const uint32_t len = e - s;
+    const bool staged = len <= cap;
+    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) cur[b] = offsets[(size_t)sg * 256 + b] - (staged ? base : 0u);
+    __syncthreads();
+    for (uint32_t j = s + threadIdx.x; j < e; j += blockDim.x) {
+        const uint32_t code = lo2[j];
+        const uint32_t pos = atomicAdd(&cur[code & 0xFFu], 1u);
+        const uint32_t v = idx2[j] | ((code >> 15) << 31);
+        if (staged) stage[pos] = v; else entries[pos] = v;
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) entries[base + k] = stage[k];
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan of `count` u32 values, 3 launches; out[count] = total
 #define SCAN_ITEMS 16
@@ -730,20 +832,39 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_msm_part_scatter, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
                                (uint32_t)bs.n, (uint32_t)first, d_part_lo, d_part_idx);
             const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
-            hipLaunchKernelGGL(k_msm_hist_group, dim3(fslices, Gn), dim3(1024), (size_t)32768 * 4, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fslices, NB,
-                               d_fcounts);
-            hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_fcounts, NB, fslices, d_counts);
+            // level 2: 128 sub-groups (256 buckets each) per group; level 3: LDS-staged sort per sub-group
+            const uint32_t SG = Gn * 128;
+            uint32_t fsl = 16;
+            while (fsl * Gn < 2048 && fsl < 128) fsl *= 2;
+            const uint32_t P2 = SG * fsl;
+            const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            void* pd2;
+            const size_t b2_lo = b_plo, b2_idx = b_pidx, b2_c = (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256;
+            if ((rc = zl_scratch_get(ctx, 6, b2_lo + b2_idx + b2_c + 256, &pd2))) return rc;  // slot 6 is otherwise the NTT's scratch vector
+            unsigned char* q2 = (unsigned char*)pd2;
+            uint16_t* d_lo2 = (uint16_t*)q2; q2 += b2_lo;
+            uint32_t* d_idx2 = (uint32_t*)q2; q2 += b2_idx;
+            uint32_t* d_c2 = (uint32_t*)q2;
+            uint32_t* d_off2 = d_c2 + P2;  // P2 + 1
+            uint32_t* d_blk2 = d_off2 + P2 + 1;
+            hipLaunchKernelGGL(k_msm_sub_hist, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fsl, d_c2);
+            hipLaunchKernelGGL(k_scan_block_sums, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2);
+            hipLaunchKernelGGL(k_scan_apply, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2, d_off2, d_c2);
+            hipLaunchKernelGGL(k_msm_sub_scatter, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
+                               d_idx2);
+            hipLaunchKernelGGL(k_msm_fine_hist, dim3(SG), dim3(256), 0, st, d_lo2, d_off2, SG, fsl, d_off2 + P2, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            // small write slices win (measured at 2^24, c = 22: ranges 4 -> 16.0 ms, 64 -> ~7 ms): 512 buckets per block
-            uint32_t ranges = 64;
-            while (ranges * Gn < 256 && ranges < 256) ranges *= 2;
-            if (getenv("ZL_TUNE_RANGES_WIDE")) ranges = (uint32_t)atoi(getenv("ZL_TUNE_RANGES_WIDE"));
-            if (ranges < 1 || ranges > 32768 || (32768 % ranges)) return ZL_EINVAL;
-            const uint32_t RB = 32768 / ranges;
-            hipLaunchKernelGGL(k_msm_scatter_group, dim3(ranges, Gn), dim3(1024), (size_t)RB * 4, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, RB,
-                               d_offsets, d_entries);
+            const uint32_t cap = 36 * 1024;  // staged entries per block: 144 KiB + 1 KiB of cursors (1 block per CU); typical sub-group: n*W/SG
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+            }
+            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(512), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
+                               d_entries);
         } else if (c <= 16) {
             // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
             uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
