@@ -207,7 +207,20 @@ static __global__ void __launch_bounds__(256) k_msm_part_hist(const uint8_t* __r
     __syncthreads();
     const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
     const uint8_t* hw = hi8 + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    // 16 group ids per 16-B load over the aligned body (row base w*n and lo are multiples of 16 for the usual power-of-two n)
+    const bool al = ((((size_t)w * n) | lo) & 15) == 0;
+    const uint32_t body1 = al ? lo + ((hi - lo) & ~15u) : lo;
+    const uint4* hv = reinterpret_cast<const uint4*>(hw);
+    for (uint32_t i16 = lo / 16 + threadIdx.x; i16 < body1 / 16; i16 += blockDim.x) {
+        const uint4 v = hv[i16];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t g = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            if (g != 0xFFu) atomicAdd(&hist[g], 1u);
+        }
+    }
+    for (uint32_t i = body1 + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t g = hw[i];
         if (g != 0xFFu) atomicAdd(&hist[g], 1u);
     }
@@ -226,12 +239,32 @@ static __global__ void __launch_bounds__(256) k_msm_part_scatter(const uint16_t*
     const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
     const uint8_t* hw = hi8 + (size_t)w * n;
     const uint16_t* lw = lo16 + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const uint32_t add = w * table_stride + first;
+    const bool al = ((((size_t)w * n) | lo) & 15) == 0;
+    const uint32_t body1 = al ? lo + ((hi - lo) & ~15u) : lo;
+    const uint4* hv = reinterpret_cast<const uint4*>(hw);
+    const uint4* lv = reinterpret_cast<const uint4*>(lw);
+    for (uint32_t i16 = lo / 16 + threadIdx.x; i16 < body1 / 16; i16 += blockDim.x) {
+        const uint4 v = hv[i16];
+        const uint4 l0 = lv[2 * (size_t)i16], l1 = lv[2 * (size_t)i16 + 1];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t lws[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t g = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            if (g != 0xFFu) {
+                const uint32_t pos = atomicAdd(&cur[g], 1u);
+                out_lo[pos] = (uint16_t)(lws[k >> 1] >> ((k & 1) * 16));
+                out_idx[pos] = add + i16 * 16 + k;
+            }
+        }
+    }
+    for (uint32_t i = body1 + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t g = hw[i];
         if (g != 0xFFu) {
             const uint32_t pos = atomicAdd(&cur[g], 1u);
             out_lo[pos] = lw[i];
-            out_idx[pos] = w * table_stride + first + i;
+            out_idx[pos] = add + i;
         }
     }
 }
@@ -368,7 +401,16 @@ static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t s = sub_off[(size_t)sg * fslices], e = (sg + 1 < SG) ? sub_off[(size_t)(sg + 1) * fslices] : *total;
-    for (uint32_t j = s + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[lo2[j] & 0xFFu], 1u);
+    const uint32_t body0 = min(e, (s + 7u) & ~7u), body1 = max(body0, e & ~7u);
+    for (uint32_t j = s + threadIdx.x; j < body0; j += blockDim.x) atomicAdd(&hist[lo2[j] & 0xFFu], 1u);
+    const uint4* dv = reinterpret_cast<const uint4*>(lo2);
+    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
+        const uint4 v = dv[j8];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) atomicAdd(&hist[(words[k >> 1] >> ((k & 1) * 16)) & 0xFFu], 1u);
+    }
+    for (uint32_t j = body1 + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&hist[lo2[j] & 0xFFu], 1u);
     __syncthreads();
     counts[(size_t)sg * 256 + threadIdx.x] = hist[threadIdx.x];
 }
