@@ -270,12 +270,12 @@ def main():
         value = pts / elapsed
         dom = float(np.mean(dom_ms))
         achieved = 128.0 * n / (dom * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
+        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic_final.json: rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if args.log_n == 24 and int(tm.window_bits) == 16:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")))
+            if args.log_n == 24 and int(tm.window_bits) == int(pmc["window_bits"]) and pre_c >= 0:
                 traffic = pmc["k_msm_accumulate_traffic_bytes"]
         except Exception:
             traffic = None
@@ -300,7 +300,7 @@ def main():
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "result_check": "known-discrete-log prefix check passed; bit-exact parity in tests/"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_final.json)",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
