@@ -578,9 +578,12 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
     }
     bucket_sums[b] = acc;
 }
-// one 256-lane block per giant bucket
+// lanes of the block-tree kernels: 256 for G1, 128 for G2 (384-B points: a 256-lane block is capped at 256 VGPRs and spills)
 template <class G>
-__global__ void __launch_bounds__(256) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
+struct TreeLanes { static constexpr int N = sizeof(XYZZ<typename G::F>) > 256 ? 128 : 256; };
+// one block per giant bucket
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
                                                         const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
     using F = typename G::F;
@@ -597,7 +600,7 @@ __global__ void __launch_bounds__(256) k_msm_merge_big(const uint32_t* __restric
         }
         sh[threadIdx.x] = acc;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
+        for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
             if ((int)threadIdx.x < off) {
                 XYZZ<F> a = sh[threadIdx.x];
                 const XYZZ<F> o = sh[threadIdx.x + off];
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>
 // set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
 // two-stage sum for sets with many segments.
 template <class G>
-__global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
                                                          uint32_t parts, XYZZ<typename G::F>* __restrict__ out) {
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(256) k_msm_window_sum(const XYZZ<typename G::F
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             XYZZ<F> a = sh[threadIdx.x];
             const XYZZ<F> o = sh[threadIdx.x + off];
@@ -942,15 +945,15 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, ZL_CHUNK);
-        hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(256), 256 * sizeof(X), st, d_offsets, d_buckets,
+        hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs);
         if (stage1) {
             // (set, part) partial sums of SUMW segment results each, then one block per set over the partials
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS * stage1), dim3(256), 256 * sizeof(X), st, d_segs, SUMW, segs_per_set, stage1, d_stage1);
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(256), 256 * sizeof(X), st, d_stage1, stage1, stage1, 1u, d_sets);
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS * stage1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, SUMW, segs_per_set, stage1, d_stage1);
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_stage1, stage1, stage1, 1u, d_sets);
         } else {
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(256), 256 * sizeof(X), st, d_segs, segs_per_set, segs_per_set, 1u, d_sets);
+            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, segs_per_set, segs_per_set, 1u, d_sets);
         }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
         ZL_HIP(ctx, hipGetLastError());

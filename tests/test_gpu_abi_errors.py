@@ -1,0 +1,75 @@
+"""Error behaviour of the C ABI on a live ctx: every failure is a return code, nothing aborts (the reference collapses every
+upstream failure into an opaque Error, plugins/arkworks/src/groth16.rs:438-465; the codes here are the extra diagnostics)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import po
+from openzl_amd import BackendError, ZL_G2
+
+pytestmark = pytest.mark.gpu
+EINVAL, EHANDLE = -1, -5
+
+
+def test_handle_and_range_errors(backend):
+    curve = po.BLS12_381
+    k = ol.random_scalars(curve, 16, 1)
+    S = ol.random_scalars(curve, 16, 2)
+    h = backend.bases_generate(curve.cid, k)
+    with pytest.raises(BackendError) as e:
+        backend.msm(h, np.concatenate([S, S]))  # more scalars than bases
+    assert e.value.code == EINVAL
+    with pytest.raises(BackendError) as e:
+        backend.msm(h, S, first=8)  # range runs past the end
+    assert e.value.code == EINVAL
+    got = backend.msm(h, S[:8], first=8)  # sub-range is fine
+    exp = ol.oracle_msm_g1(curve, ol.oracle_g1_mul_gen(curve, k)[8:], S[:8])
+    assert (got[0] == exp[0]).all()
+    backend.bases_free(h)
+    backend._bases[h] = (curve.cid, 1, 16)  # pretend the handle is still alive
+    with pytest.raises(BackendError) as e:
+        backend.msm(h, S)
+    assert e.value.code == EHANDLE
+    with pytest.raises(BackendError) as e:
+        backend.bases_free(h)
+    assert e.value.code == EHANDLE
+    assert backend.L.zl_bases_precompute(backend._ctx, 123456, 0) == EHANDLE
+    assert backend.L.zl_ctx_set_msm_window(backend._ctx, 1) == EINVAL
+    assert backend.L.zl_ctx_set_msm_window(backend._ctx, 99) == EINVAL
+
+
+def test_ntt_argument_errors(backend):
+    L = backend.L
+    buf = np.zeros((4, 4), dtype=np.uint64)
+    assert L.zl_ntt(backend._ctx, 7, ol.p64(buf), 2, 0) == EINVAL       # unknown curve
+    assert L.zl_ntt(backend._ctx, po.BN254.cid, ol.p64(buf), 29, 0) == EINVAL  # log_n above BN254's two-adicity (28)
+    assert L.zl_ntt(backend._ctx, po.BLS12_381.cid, None, 2, 0) == EINVAL
+    assert L.zl_ntt_dev(backend._ctx, po.BLS12_381.cid, C.c_void_p(1), 2, 64) == EINVAL  # unknown flag bit
+
+
+def test_groth16_rejects_mismatched_handles(backend):
+    curve = po.BLS12_381
+    import groth16_util as gu
+
+    cs = po.poseidon_chain_circuit(curve.fr, 1)
+    td = po.Groth16Trapdoor(3, 5, 7, 11, 13)
+    pk = gu.setup_with_trapdoor(curve, cs, td)
+    dpk = gu.upload_pk(backend, curve, pk)
+    z = ol.ints_to_limbs(cs.assignment(), 4)
+    r = ol.ints_to_limbs([1], 4)[0]
+    try:
+        bad = dict(dpk)
+        bad["b_g2_query"] = dpk["a_query"]  # a G1 handle where the G2 query is expected
+        with pytest.raises(BackendError) as e:
+            backend.groth16_prove(curve.cid, bad, gu.r1cs_arrays(cs), z, r, r)
+        assert e.value.code == EHANDLE
+        short = dict(dpk)
+        short["h_query"] = backend.bases_upload(curve.cid, pk["h_query"][:10])  # too few points for the domain
+        with pytest.raises(BackendError) as e:
+            backend.groth16_prove(curve.cid, short, gu.r1cs_arrays(cs), z, r, r)
+        assert e.value.code == EINVAL
+        backend.bases_free(short["h_query"])
+    finally:
+        gu.free_pk(backend, dpk)
