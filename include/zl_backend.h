@@ -158,6 +158,12 @@ int zl_groth16_keys_trapdoor(const zl_g16_keys* k, uint64_t* out20); /* alpha, b
 int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* c, uint64_t seed, zl_g16_proof* proof,
                              uint64_t* r_out, uint64_t* s_out);
 
+/* Groth16::verify (host pairing; public_inputs: n x 4 u64 canonical, without the leading ONE): *ok = 1 accepted, 0 rejected */
+int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_t n, const zl_g16_proof* proof, int* ok);
+/* e(P, Q) in GT after the final exponentiation: 12 canonical Fq coefficients (BLS12-381: 12 x 6 u64, BN254: 12 x 4 u64) of the
+ * polynomial in w, Fq12 = Fq[w]/(w^12 - 2 w^6 + 2) (BLS12-381) or (w^12 - 18 w^6 + 82) (BN254) */
+int zl_pairing(zl_curve_t curve, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out12);
+
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
 typedef struct zl_timing {
     float total_ms;      /* first kernel start -> last kernel end of the last zl_msm* / zl_ntt* call */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
     "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
-    "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit",
+    "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
 ]
 
 
@@ -106,6 +106,8 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_keys_pk.argtypes = [vp, C.POINTER(G16PkC)]
     L.zl_groth16_keys_trapdoor.argtypes = [vp, u64p]
     L.zl_groth16_prove_circuit.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(G16ProofC), u64p, u64p]
+    L.zl_groth16_verify.argtypes = [vp, u64p, C.c_size_t, C.POINTER(G16ProofC), C.POINTER(C.c_int)]
+    L.zl_pairing.argtypes = [C.c_int, u64p, u64p, u64p]
     if path is None:
         _lib = L
     return L
@@ -292,6 +294,15 @@ def poseidon_permute(curve: int, state: np.ndarray) -> np.ndarray:
     return st
 
 
+def pairing(curve: int, p_xy: np.ndarray, q_xy: np.ndarray) -> np.ndarray:
+    """e(P, Q) as 12 canonical Fq coefficients (host pairing, no GPU)"""
+    out = np.zeros((12, FQ_LIMBS[curve]), dtype=np.uint64)
+    rc = load_library().zl_pairing(curve, _p64(np.ascontiguousarray(p_xy, dtype=np.uint64)), _p64(np.ascontiguousarray(q_xy, dtype=np.uint64)), _p64(out))
+    if rc:
+        raise BackendError(rc, "zl_pairing")
+    return out
+
+
 class Circuit:
     """R1CS<F> compiler in proof mode holding the config-5 Poseidon-chain circuit (host code, no GPU)."""
 
@@ -382,6 +393,22 @@ class Groth16Keys:
         nq = FQ_LIMBS[self.circuit.curve]
         return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,
                 np.array(proof.c[: 2 * nq], dtype=np.uint64), proof.c_inf), r, s
+
+    def verify(self, proof, public_inputs: np.ndarray) -> bool:
+        """Groth16::verify(vk, input, proof) with the host pairing; proof = (a, a_inf, b, b_inf, c, c_inf)"""
+        pc = G16ProofC()
+        a, ai, b, bi, c, ci = proof
+        for i, v in enumerate(a):
+            pc.a[i] = int(v)
+        for i, v in enumerate(b):
+            pc.b[i] = int(v)
+        for i, v in enumerate(c):
+            pc.c[i] = int(v)
+        pc.a_inf, pc.b_inf, pc.c_inf = int(ai), int(bi), int(ci)
+        pub = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+        ok = C.c_int(0)
+        self.backend._check(self.L.zl_groth16_verify(self._k, _p64(pub), pub.shape[0], C.byref(pc), C.byref(ok)), "zl_groth16_verify")
+        return bool(ok.value)
 
     def close(self):
         if self._k:

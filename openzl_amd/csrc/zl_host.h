@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 #include "zl_ctx.h"
+#include "zl_pairing.h"
 
 namespace openzl {
 
@@ -293,12 +294,14 @@ struct Bls12_381 {
     using FrP = BLS12_381_Fr;
     using G1 = BlsG1;
     using G2 = BlsG2;
+    using PairingP = BLS12_381_Pairing;
     static constexpr zl_curve_t curve = ZL_BLS12_381;
 };
 struct Bn254 {
     using FrP = BN254_Fr;
     using G1 = BnG1;
     using G2 = BnG2;
+    using PairingP = BN254_Pairing;
     static constexpr zl_curve_t curve = ZL_BN254;
 };
 
@@ -328,8 +331,10 @@ struct Groth16 {
         size_t n_instance = 0, n_witness = 0, domain_size = 0;
         Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it
     };
-    struct VerifyingContext {  // PreparedVerifyingKey in the reference (groth16.rs:181-186); pairing verifier is row f4 (not built)
-        std::vector<F> gamma_abc_exponents;
+    struct VerifyingContext {  // ark_groth16::VerifyingKey (the reference holds it prepared, groth16.rs:181-186); canonical affine points
+        std::vector<uint64_t> alpha_g1, beta_g2, gamma_g2, delta_g2;
+        std::vector<uint64_t> gamma_abc_g1;  // n_instance points, index 0 pairs with the constant ONE
+        std::vector<F> gamma_abc_exponents;  // discrete logs, kept for exponent checks in tests
     };
     using Input = std::vector<F>;
     using Proof = zl_g16_proof;
@@ -338,7 +343,8 @@ struct Groth16 {
     static Compiler proof_compiler() { return Compiler::for_proofs(); }      // groth16.rs:423-425
     static Result<std::pair<ProvingContext, VerifyingContext>> compile(zl_ctx* ctx, const Compiler& compiler, SplitMix64& rng);
     static Result<Proof> prove(const ProvingContext& context, const Compiler& compiler, SplitMix64& rng, F* r_out = nullptr, F* s_out = nullptr);
-    static Result<bool> verify(const VerifyingContext&, const Input&, const Proof&) { return {false, false, Error{ZL_EINVAL}}; }
+    // verify (groth16.rs:459-466): e(A, B) == e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta); input = public inputs (canonical)
+    static Result<bool> verify(const VerifyingContext& vk, const Input& input, const Proof& proof);
     static void release(ProvingContext& context);
 };
 

@@ -168,6 +168,26 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         }
         if (h2) (void)zl_bases_free(ctx, h2);
     }
+    // verifying key: alpha G1, beta G2, gamma G2, delta G2, gamma_abc_i G1 (device fixed-base, then copied back)
+    if (!rc) {
+        vk.alpha_g1 = pc.alpha_g1;
+        vk.beta_g2 = pc.beta_g2;
+        vk.delta_g2 = pc.delta_g2;
+        vk.gamma_g2.resize(q2);
+        vk.gamma_abc_g1.resize(ni * q1);
+        uint64_t kg[4];
+        memcpy(kg, td.gamma.l, 32);
+        uint64_t h = 0;
+        rc = zl_bases_generate(ctx, E::curve, ZL_G2, kg, 1, &h);
+        if (!rc) rc = zl_bases_download(ctx, h, 0, 1, vk.gamma_g2.data());
+        if (h) (void)zl_bases_free(ctx, h);
+        std::vector<uint64_t> eg(ni * 4);
+        for (size_t i = 0; i < ni; i++) to_canon_words<FrP>(&eg[4 * i], vk.gamma_abc_exponents[i]);
+        h = 0;
+        if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eg.data(), ni, &h);
+        if (!rc) rc = zl_bases_download(ctx, h, 0, ni, vk.gamma_abc_g1.data());
+        if (h) (void)zl_bases_free(ctx, h);
+    }
     if (rc) {
         release(pc);
         res.error = Error{rc};
@@ -175,6 +195,53 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     }
     res.ok = true;
     res.value = {pc, vk};
+    return res;
+}
+
+template <class E>
+Result<bool> Groth16<E>::verify(const VerifyingContext& vk, const Input& input, const Proof& proof) {
+    using G1 = typename E::G1;
+    using F1 = typename G1::F;
+    using Eng = openzl::pairing::Engine<typename G1::FqP, typename E::PairingP>;
+    Result<bool> res{false, false, Error{ZL_EINVAL}};
+    const size_t q1 = 2 * G1::FQ64;
+    const size_t ni = vk.gamma_abc_g1.size() / q1;
+    if (ni == 0 || input.size() + 1 != ni) return res;  // ark: wrong number of public inputs -> Err(MalformedVerifyingKey)
+    auto load = [&](const uint64_t* xy) {
+        Affine<F1> a;
+        memcpy(&a.x, xy, sizeof(F1));
+        memcpy(&a.y, reinterpret_cast<const unsigned char*>(xy) + sizeof(F1), sizeof(F1));
+        if (a.is_inf()) return XYZZ<F1>::inf();
+        a.x = zl::to_mont(a.x);
+        a.y = zl::to_mont(a.y);
+        return XYZZ<F1>::from_affine(a);
+    };
+    // prepare_inputs: g_ic = gamma_abc[0] + sum_i x_i gamma_abc[i + 1]
+    XYZZ<F1> acc = load(vk.gamma_abc_g1.data());
+    for (size_t i = 0; i < input.size(); i++) {
+        uint32_t k[8];
+        memcpy(k, input[i].l, 32);
+        zl::add_full(acc, zl::mul_scalar(load(vk.gamma_abc_g1.data() + (i + 1) * q1), k));
+    }
+    auto neg_canon = [&](const XYZZ<F1>& p, std::vector<uint64_t>& out) {  // canonical affine of -p
+        out.assign(q1, 0);
+        if (p.is_inf()) return;
+        Affine<F1> a = zl::to_affine(p);
+        a.y = zl::neg(a.y);
+        a.x = zl::from_mont(a.x);
+        a.y = zl::from_mont(a.y);
+        memcpy(out.data(), &a.x, sizeof(F1));
+        memcpy(reinterpret_cast<unsigned char*>(out.data()) + sizeof(F1), &a.y, sizeof(F1));
+    };
+    std::vector<uint64_t> n_alpha, n_acc, n_c;
+    neg_canon(load(vk.alpha_g1.data()), n_alpha);
+    neg_canon(acc, n_acc);
+    neg_canon(load(proof.c), n_c);
+    // e(A, B) e(-alpha, beta) e(-g_ic, gamma) e(-C, delta) == 1, one final exponentiation
+    const auto gt = Eng::multi_pairing({proof.a, n_alpha.data(), n_acc.data(), n_c.data()},
+                                       {proof.b, vk.beta_g2.data(), vk.gamma_g2.data(), vk.delta_g2.data()});
+    res.ok = true;
+    res.value = !proof.a_inf && !proof.b_inf && Eng::eq(gt, Eng::one());
     return res;
 }
 
@@ -260,6 +327,8 @@ struct zl_g16_keys {
     Groth16<Bls12_381>::ProvingContext pc_bls;
     Groth16<Bn254>::ProvingContext pc_bn;
     std::vector<uint64_t> gamma_abc;  // exponents, canonical
+    Groth16<Bls12_381>::VerifyingContext vk_bls;
+    Groth16<Bn254>::VerifyingContext vk_bn;
 };
 
 extern "C" {
@@ -330,12 +399,14 @@ int zl_groth16_compile(zl_ctx* ctx, const zl_circuit* c, uint64_t seed, zl_g16_k
         auto r = Groth16<Bls12_381>::compile(ctx, *c->bls, rng);
         if (!r.ok) rc = r.error.code; else {
             k->pc_bls = r.value.first;
+            k->vk_bls = r.value.second;
             for (auto& g : r.value.second.gamma_abc_exponents) { uint64_t w[4]; to_canon_words<BLS12_381_Fr>(w, g); k->gamma_abc.insert(k->gamma_abc.end(), w, w + 4); }
         }
     } else {
         auto r = Groth16<Bn254>::compile(ctx, *c->bn, rng);
         if (!r.ok) rc = r.error.code; else {
             k->pc_bn = r.value.first;
+            k->vk_bn = r.value.second;
             for (auto& g : r.value.second.gamma_abc_exponents) { uint64_t w[4]; to_canon_words<BN254_Fr>(w, g); k->gamma_abc.insert(k->gamma_abc.end(), w, w + 4); }
         }
     }
@@ -390,6 +461,32 @@ int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit
         *proof = res.value;
         if (r_out) memcpy(r_out, r.l, 32);
         if (s_out) memcpy(s_out, s.l, 32);
+    }
+    return ZL_OK;
+}
+
+// e(P, Q) after the final exponentiation: 12 canonical Fq coefficients of the w-polynomial (tests vs the oracle)
+int zl_pairing(zl_curve_t curve, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out12) {
+    if (!p_xy || !q_xy || !out12) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) { pairing::BlsEngine::store(out12, pairing::BlsEngine::multi_pairing({p_xy}, {q_xy})); return ZL_OK; }
+    if (curve == ZL_BN254) { pairing::BnEngine::store(out12, pairing::BnEngine::multi_pairing({p_xy}, {q_xy})); return ZL_OK; }
+    return ZL_EINVAL;
+}
+// Groth16::verify: public_inputs = n x 4 u64 canonical (without the leading ONE); *ok = 1 / 0
+int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_t n, const zl_g16_proof* proof, int* ok) {
+    if (!k || !proof || !ok || (!public_inputs && n)) return ZL_EINVAL;
+    if (k->curve == ZL_BLS12_381) {
+        std::vector<Fp<BLS12_381_Fr>> in(n);
+        for (size_t i = 0; i < n; i++) memcpy(in[i].l, public_inputs + 4 * i, 32);
+        auto r = Groth16<Bls12_381>::verify(k->vk_bls, in, *proof);
+        if (!r.ok) return r.error.code;
+        *ok = r.value ? 1 : 0;
+    } else {
+        std::vector<Fp<BN254_Fr>> in(n);
+        for (size_t i = 0; i < n; i++) memcpy(in[i].l, public_inputs + 4 * i, 32);
+        auto r = Groth16<Bn254>::verify(k->vk_bn, in, *proof);
+        if (!r.ok) return r.error.code;
+        *ok = r.value ? 1 : 0;
     }
     return ZL_OK;
 }

@@ -1,0 +1,216 @@
+// zl_pairing.h -- host-side pairing for Groth16::verify (row f4; ms-scale CPU work, not on the accelerated path).
+//
+// Replaces what `Groth16::<E>::verify` (/root/reference/plugins/arkworks/src/groth16.rs:459-466) delegates to
+// ark_groth16::verify_proof_with_prepared_inputs -> E::miller_loop + E::final_exponentiation, and what the plugin's
+// PairingEngineExt helpers use (plugins/arkworks/src/pairing.rs:47-90; its tests check bilinearity, :116-129).
+// Tower-free formulation: Fq12 = Fq[w]/(w^12 - M6 w^6 + M0_NEG) as 12 Fq coefficients; G2 arithmetic stays on the twist
+// in affine Fq2 coordinates (one Fq inversion per step); the line through the untwisted points evaluated at P = (xP, yP) is
+//     BN254      (X = x' w^2, Y = y' w^3):  l = -yP + (m' xP) w + (y1' - m' x1') w^3
+//     BLS12-381  (X = x'/w^2, Y = y'/w^3):  l * w^3 = (y1' - m' x1') + (m' xP) w^2 - yP w^3
+// with m' the Fq2 slope on the twist; the factor w^3 lies in the proper subfield Fq4 and is annihilated by the final
+// exponentiation (q^12 - 1)/r, taken as one big power.  Any non-degenerate bilinear pairing decides Groth16 verification the
+// same way; values after the final exponentiation are unique and are compared coefficient-wise with oracle/pyoracle.py.
+#pragma once
+#include <vector>
+#include "zl_curve.h"
+
+namespace openzl {
+namespace pairing {
+
+template <class FqP, class PP>
+struct Engine {
+    using F = Fp<FqP>;
+    using F2 = Fp2<FqP>;
+    struct Fq12 { F c[12]; };
+
+    static F small(int v) {  // small non-negative integer -> Montgomery
+        return zl::from_u64<FqP>((uint64_t)v);
+    }
+    static Fq12 one() {
+        Fq12 r;
+        for (auto& x : r.c) x = F::zero();
+        r.c[0] = F::one();
+        return r;
+    }
+    static Fq12 mul(const Fq12& a, const Fq12& b) {
+        F t[23];
+        for (auto& x : t) x = F::zero();
+        for (int i = 0; i < 12; i++) {
+            if (a.c[i].is_zero()) continue;
+            for (int j = 0; j < 12; j++) {
+                if (b.c[j].is_zero()) continue;
+                t[i + j] = zl::add(t[i + j], zl::mul(a.c[i], b.c[j]));
+            }
+        }
+        static const F m6 = small(PP::M6), m0 = small(PP::M0_NEG);
+        for (int k = 22; k >= 12; k--) {  // w^k = w^(k-12) (M6 w^6 - M0_NEG)
+            if (t[k].is_zero()) continue;
+            t[k - 6] = zl::add(t[k - 6], zl::mul(t[k], m6));
+            t[k - 12] = zl::sub(t[k - 12], zl::mul(t[k], m0));
+        }
+        Fq12 r;
+        for (int i = 0; i < 12; i++) r.c[i] = t[i];
+        return r;
+    }
+    static bool eq(const Fq12& a, const Fq12& b) {
+        for (int i = 0; i < 12; i++) if (a.c[i] != b.c[i]) return false;
+        return true;
+    }
+    // a0 + a1 i placed at w^k (i = w^6 - ISHIFT): coefficient k gets a0 - ISHIFT a1, coefficient k+6 gets a1
+    static void put_fq2(Fq12& l, int k, const F2& a) {
+        static const F sh = small(PP::ISHIFT);
+        l.c[k] = zl::add(l.c[k], zl::sub(a.c0, zl::mul(sh, a.c1)));
+        l.c[k + 6] = zl::add(l.c[k + 6], a.c1);
+    }
+    static F2 f2_scale(const F2& a, const F& s) { return F2{zl::mul(a.c0, s), zl::mul(a.c1, s)}; }
+
+    struct G2Aff { F2 x, y; bool inf; };
+    // line through R and S (R == S: tangent) evaluated at P, and R <- R + S on the twist
+    static Fq12 line_and_add(G2Aff& R, const G2Aff& S, const F& xP, const F& yP) {
+        Fq12 l;
+        for (auto& x : l.c) x = F::zero();
+        F2 m;
+        bool vertical = false;
+        if (R.x == S.x) {
+            if (R.y == S.y && !R.y.is_zero()) {
+                F2 xx = zl::sqr(R.x);
+                m = zl::mul(zl::add(zl::dbl(xx), xx), zl::inv(zl::dbl(R.y)));
+            } else {
+                vertical = true;
+            }
+        } else {
+            m = zl::mul(zl::sub(S.y, R.y), zl::inv(zl::sub(S.x, R.x)));
+        }
+        if (vertical) {
+            // l = xP - X1 (does not occur for points of prime order r inside the loop; kept for completeness)
+            F2 nx = zl::neg(R.x);
+            if (PP::TWIST_DIV) { l.c[2] = xP; put_fq2(l, 0, nx); }  // (xP - x1'/w^2) * w^2
+            else { l.c[0] = xP; put_fq2(l, 2, nx); }
+            R.inf = true;
+            return l;
+        }
+        const F2 mx = f2_scale(m, xP);                    // m' xP
+        const F2 c0 = zl::sub(R.y, zl::mul(m, R.x));      // y1' - m' x1'
+        if (PP::TWIST_DIV) {
+            put_fq2(l, 0, c0);
+            put_fq2(l, 2, mx);
+            l.c[3] = zl::sub(l.c[3], yP);
+        } else {
+            l.c[0] = zl::neg(yP);
+            put_fq2(l, 1, mx);
+            put_fq2(l, 3, c0);
+        }
+        const F2 x3 = zl::sub(zl::sub(zl::sqr(m), R.x), S.x);
+        const F2 y3 = zl::sub(zl::mul(m, zl::sub(R.x, x3)), R.y);
+        R.x = x3;
+        R.y = y3;
+        return l;
+    }
+    static F2 f2_pow(const F2& a, const uint32_t* e, int nbits) {
+        F2 acc = F2::one();
+        for (int i = nbits - 1; i >= 0; i--) {
+            acc = zl::sqr(acc);
+            if ((e[i >> 5] >> (i & 31)) & 1) acc = zl::mul(acc, a);
+        }
+        return acc;
+    }
+    static F2 conj(const F2& a) { return F2{a.c0, zl::neg(a.c1)}; }
+    // q-power Frobenius of the untwisted point expressed on the twist (BN tail): (conj(x) xi^((q-1)/3), conj(y) xi^((q-1)/2))
+    static G2Aff frob(const G2Aff& Q) {
+        static bool init = false;
+        static F2 g2, g3;
+        if (!init) {
+            const F2 xi{small(PP::ISHIFT), F::one()};  // w^6 = i + ISHIFT
+            uint32_t e[FqP::N];
+            // (q - 1) / 3 and (q - 1) / 2 by long division on 32-bit words
+            for (int d : {3, 2}) {
+                uint64_t rem = 0;
+                uint32_t qm1[FqP::N];
+                for (int i = 0; i < FqP::N; i++) qm1[i] = FqP::mod(i);
+                qm1[0] -= 1;  // q is odd: no borrow
+                for (int i = FqP::N - 1; i >= 0; i--) {
+                    uint64_t cur = (rem << 32) | qm1[i];
+                    e[i] = (uint32_t)(cur / d);
+                    rem = cur % d;
+                }
+                (d == 3 ? g2 : g3) = f2_pow(xi, e, 32 * FqP::N);
+            }
+            init = true;
+        }
+        return G2Aff{zl::mul(conj(Q.x), g2), zl::mul(conj(Q.y), g3), Q.inf};
+    }
+    // Miller loop value f_{loop,Q}(P) (times subfield factors); P, Q affine Montgomery, neither at infinity
+    static Fq12 miller(const F& xP, const F& yP, const G2Aff& Q) {
+        Fq12 f = one();
+        G2Aff R = Q;
+        for (int i = PP::LOOP_BITS - 2; i >= 0; i--) {
+            f = mul(mul(f, f), line_and_add(R, R, xP, yP));
+            if (PP::loop_bit(i)) f = mul(f, line_and_add(R, Q, xP, yP));
+        }
+        if (PP::BN_TAIL) {
+            const G2Aff Q1 = frob(Q);
+            G2Aff nQ2 = frob(Q1);
+            nQ2.y = zl::neg(nQ2.y);
+            f = mul(f, line_and_add(R, Q1, xP, yP));
+            f = mul(f, line_and_add(R, nQ2, xP, yP));
+        }
+        return f;
+    }
+    static Fq12 final_exp(const Fq12& f) {
+        const uint32_t* e = PP::final_exp();
+        Fq12 acc = one();
+        bool started = false;
+        for (int i = PP::FINAL_EXP_WORDS * 32 - 1; i >= 0; i--) {
+            if (started) acc = mul(acc, acc);
+            if ((e[i >> 5] >> (i & 31)) & 1) {
+                acc = started ? mul(acc, f) : f;
+                started = true;
+            }
+        }
+        return acc;
+    }
+    // canonical affine words (x||y, and x.c0||x.c1||y.c0||y.c1) -> internal points; all-zero = infinity
+    static bool load_g1(const uint64_t* xy, F& x, F& y) {
+        memcpy(&x, xy, sizeof(F));
+        memcpy(&y, reinterpret_cast<const unsigned char*>(xy) + sizeof(F), sizeof(F));
+        if (x.is_zero() && y.is_zero()) return false;
+        x = zl::to_mont(x);
+        y = zl::to_mont(y);
+        return true;
+    }
+    static bool load_g2(const uint64_t* xy, G2Aff& q) {
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(xy);
+        memcpy(&q.x.c0, p, sizeof(F));
+        memcpy(&q.x.c1, p + sizeof(F), sizeof(F));
+        memcpy(&q.y.c0, p + 2 * sizeof(F), sizeof(F));
+        memcpy(&q.y.c1, p + 3 * sizeof(F), sizeof(F));
+        q.inf = q.x.is_zero() && q.y.is_zero();
+        if (q.inf) return false;
+        q.x = zl::to_mont(q.x);
+        q.y = zl::to_mont(q.y);
+        return true;
+    }
+    // product of pairings prod_i e(P_i, Q_i) with ONE final exponentiation
+    static Fq12 multi_pairing(const std::vector<const uint64_t*>& ps, const std::vector<const uint64_t*>& qs) {
+        Fq12 f = one();
+        for (size_t i = 0; i < ps.size(); i++) {
+            F x, y;
+            G2Aff q;
+            if (!load_g1(ps[i], x, y) || !load_g2(qs[i], q)) continue;  // e(O, Q) = e(P, O) = 1
+            f = mul(f, miller(x, y, q));
+        }
+        return final_exp(f);
+    }
+    static void store(uint64_t* out, const Fq12& a) {  // 12 canonical coefficients
+        for (int i = 0; i < 12; i++) {
+            const F c = zl::from_mont(a.c[i]);
+            memcpy(reinterpret_cast<unsigned char*>(out) + i * sizeof(F), &c, sizeof(F));
+        }
+    }
+};
+
+using BlsEngine = Engine<BLS12_381_Fq, BLS12_381_Pairing>;
+using BnEngine = Engine<BN254_Fq, BN254_Pairing>;
+
+}  // namespace pairing
+}  // namespace openzl

@@ -823,3 +823,187 @@ def groth16_check_exponents(c: CurveParams, cs: R1CS, td: Groth16Trapdoor, ex, A
     z = cs.assignment()
     pub = sum(z[i] * ex["gamma_abc"][i] for i in range(cs.n_instance)) % r
     return (A * B - td.alpha * td.beta - pub * td.gamma - C * td.delta) % r == 0
+
+
+# --------------------------------------------------------------------------------------------
+# Pairing (row f4: Groth16::verify, plugins/arkworks/src/groth16.rs:459-466 -> ark_groth16::verify_proof ->
+# E::miller_loop + final_exponentiation; the plugin's own pairing helpers and bilinearity tests are
+# plugins/arkworks/src/pairing.rs:47-90,116-129).  Definition-level model: Fq12 = Fq[w]/(w^12 - a w^6 - b) as plain
+# polynomials, G2 points mapped into E(Fq12) by the untwist, generic affine line functions, and the final
+# exponentiation as one big power (p^12 - 1)/r.  Slow and simple on purpose: it is the uniqueness anchor for the
+# tower-free C++ verifier.  Any non-degenerate bilinear pairing decides Groth16 verification identically.
+# --------------------------------------------------------------------------------------------
+
+PAIRING = {
+    # w^12 = 2 w^6 - 2 (i = w^6 - 1, i^2 = -1); ate loop |x| = 0xd201000000010000
+    "bls12_381": {"mod6": 2, "mod0": -2, "loop": 15132376222941642752, "i_shift": 1, "twist_div": True, "bn_tail": False},
+    # w^12 = 18 w^6 - 82 (i = w^6 - 9); ate loop 6x + 2 with x = 4965661367192848881
+    "bn254": {"mod6": 18, "mod0": -82, "loop": 29793968203157093288, "i_shift": 9, "twist_div": False, "bn_tail": True},
+}
+
+
+class Fq12Ctx:
+    def __init__(self, c: CurveParams):
+        self.c = c
+        self.p = c.fq.p
+        self.cfg = PAIRING[c.name]
+
+    def mul(self, a, b):
+        p = self.p
+        t = [0] * 23
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    t[i + j] += x * y
+        for k in range(22, 11, -1):  # w^k = w^(k-12) * (mod6 w^6 + mod0)
+            v = t[k]
+            if v:
+                t[k - 6] += v * self.cfg["mod6"]
+                t[k - 12] += v * self.cfg["mod0"]
+        return [v % p for v in t[:12]]
+
+    def one(self):
+        return [1] + [0] * 11
+
+    def scalar(self, v):
+        return [v % self.p] + [0] * 11
+
+    def add(self, a, b):
+        return [(x + y) % self.p for x, y in zip(a, b)]
+
+    def sub(self, a, b):
+        return [(x - y) % self.p for x, y in zip(a, b)]
+
+    def pow(self, a, e):
+        r = self.one()
+        base = a
+        while e:
+            if e & 1:
+                r = self.mul(r, base)
+            base = self.mul(base, base)
+            e >>= 1
+        return r
+
+    def inv(self, a):
+        """polynomial extended Euclid modulo the degree-12 modulus"""
+        p = self.p
+        mod = [(-self.cfg["mod0"]) % p, 0, 0, 0, 0, 0, (-self.cfg["mod6"]) % p, 0, 0, 0, 0, 0, 1]
+        lm, hm = [1] + [0] * 12, [0] * 13
+        low, high = list(a) + [0], mod
+
+        def deg(q):
+            d = len(q) - 1
+            while d and q[d] == 0:
+                d -= 1
+            return d
+
+        def poly_div(aa, bb):
+            da, db = deg(aa), deg(bb)
+            temp = list(aa)
+            o = [0] * len(aa)
+            binv = pow(bb[db], -1, p)
+            for i in range(da - db, -1, -1):
+                o[i] = (o[i] + temp[db + i] * binv) % p
+                for cidx in range(db + 1):
+                    temp[cidx + i] = (temp[cidx + i] - o[i] * bb[cidx]) % p  # noqa
+            return o[: deg(o) + 1]
+
+        while deg(low):
+            r = poly_div(high, low)
+            r += [0] * (13 - len(r))
+            nm, new = list(hm), list(high)
+            for i in range(13):
+                for j in range(13 - i):
+                    nm[i + j] = (nm[i + j] - lm[i] * r[j]) % p
+                    new[i + j] = (new[i + j] - low[i] * r[j]) % p
+            lm, low, hm, high = nm, new, lm, low
+        inv0 = pow(low[0], -1, p)
+        return [v * inv0 % p for v in lm[:12]]
+
+
+def _embed_fq2(ctx: Fq12Ctx, a: F2):
+    """a0 + a1 i with i = w^6 - i_shift"""
+    s = ctx.cfg["i_shift"]
+    out = [0] * 12
+    out[0] = (a[0] - s * a[1]) % ctx.p
+    out[6] = a[1] % ctx.p
+    return out
+
+
+def pairing_untwist(c: CurveParams, Q: Point2):
+    """G2 (twist, Fq2 coordinates) -> E(Fq12)"""
+    ctx = Fq12Ctx(c)
+    x, y = _embed_fq2(ctx, Q[0]), _embed_fq2(ctx, Q[1])
+    w = [0, 1] + [0] * 10
+    w2, w3 = ctx.mul(w, w), ctx.mul(ctx.mul(w, w), w)
+    if ctx.cfg["twist_div"]:
+        return ctx.mul(x, ctx.inv(w2)), ctx.mul(y, ctx.inv(w3))
+    return ctx.mul(x, w2), ctx.mul(y, w3)
+
+
+def _e12_double(ctx, P):
+    x, y = P
+    m = ctx.mul(ctx.mul(ctx.scalar(3), ctx.mul(x, x)), ctx.inv(ctx.mul(ctx.scalar(2), y)))
+    nx = ctx.sub(ctx.mul(m, m), ctx.mul(ctx.scalar(2), x))
+    ny = ctx.sub(ctx.mul(m, ctx.sub(x, nx)), y)
+    return nx, ny
+
+
+def _e12_add(ctx, P, Q):
+    if P[0] == Q[0] and P[1] == Q[1]:
+        return _e12_double(ctx, P)
+    m = ctx.mul(ctx.sub(Q[1], P[1]), ctx.inv(ctx.sub(Q[0], P[0])))
+    nx = ctx.sub(ctx.sub(ctx.mul(m, m), P[0]), Q[0])
+    ny = ctx.sub(ctx.mul(m, ctx.sub(P[0], nx)), P[1])
+    return nx, ny
+
+
+def _linefunc(ctx, P1, P2, T):
+    x1, y1 = P1
+    x2, y2 = P2
+    xt, yt = T
+    if x1 != x2:
+        m = ctx.mul(ctx.sub(y2, y1), ctx.inv(ctx.sub(x2, x1)))
+        return ctx.sub(ctx.mul(m, ctx.sub(xt, x1)), ctx.sub(yt, y1))
+    if y1 == y2:
+        m = ctx.mul(ctx.mul(ctx.scalar(3), ctx.mul(x1, x1)), ctx.inv(ctx.mul(ctx.scalar(2), y1)))
+        return ctx.sub(ctx.mul(m, ctx.sub(xt, x1)), ctx.sub(yt, y1))
+    return ctx.sub(xt, x1)
+
+
+def pairing(c: CurveParams, P: Point, Q: Point2) -> List[int]:
+    """e(P, Q) in Fq12 (12 coefficients); P in G1, Q in G2; the 1 for an infinity argument."""
+    ctx = Fq12Ctx(c)
+    if P is None or Q is None:
+        return ctx.one()
+    Q12 = pairing_untwist(c, Q)
+    P12 = (ctx.scalar(P[0]), ctx.scalar(P[1]))
+    R = Q12
+    f = ctx.one()
+    loop = ctx.cfg["loop"]
+    for i in range(loop.bit_length() - 2, -1, -1):
+        f = ctx.mul(ctx.mul(f, f), _linefunc(ctx, R, R, P12))
+        R = _e12_double(ctx, R)
+        if (loop >> i) & 1:
+            f = ctx.mul(f, _linefunc(ctx, R, Q12, P12))
+            R = _e12_add(ctx, R, Q12)
+    if ctx.cfg["bn_tail"]:
+        p = ctx.p
+        Q1 = (ctx.pow(Q12[0], p), ctx.pow(Q12[1], p))
+        nQ2 = (ctx.pow(Q1[0], p), ctx.sub([0] * 12, ctx.pow(Q1[1], p)))
+        f = ctx.mul(f, _linefunc(ctx, R, Q1, P12))
+        R = _e12_add(ctx, R, Q1)
+        f = ctx.mul(f, _linefunc(ctx, R, nQ2, P12))
+    return ctx.pow(f, (ctx.p ** 12 - 1) // c.fr.p)
+
+
+def groth16_verify_pairing(c: CurveParams, vk: dict, public_inputs: Sequence[int], A: Point, B: Point2, C_: Point) -> bool:
+    """ark_groth16::verify_proof: e(A, B) == e(alpha, beta) * e(sum_i x_i gamma_abc_i, gamma) * e(C, delta).
+    vk: alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (list, index 0 pairs with the constant ONE)."""
+    ctx = Fq12Ctx(c)
+    acc = vk["gamma_abc_g1"][0]
+    for x, pt in zip(public_inputs, vk["gamma_abc_g1"][1:]):
+        acc = g1_add(c, acc, g1_mul(c, x, pt))
+    lhs = pairing(c, A, B)
+    rhs = ctx.mul(ctx.mul(pairing(c, vk["alpha_g1"], vk["beta_g2"]), pairing(c, acc, vk["gamma_g2"])), pairing(c, C_, vk["delta_g2"]))
+    return lhs == rhs
