@@ -274,63 +274,6 @@ __device__ __forceinline__ void zl_group_range(const uint32_t* __restrict__ part
     s = part_off[(size_t)g * stride];
     e = (g + 1 < G) ? part_off[(size_t)(g + 1) * stride] : E;
 }
-// block (slice, g): LDS histogram of the 15-bit fine bucket over a slice of group g's list -> counts[slice][g*32768 + bin]
-static __global__ void __launch_bounds__(1024) k_msm_hist_group(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_off, uint32_t G,
-                                                                 uint32_t stride, const uint32_t* __restrict__ total, uint32_t nslices, uint32_t NB,
-                                                                 uint32_t* __restrict__ counts) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t slice = blockIdx.x, g = blockIdx.y;
-    for (uint32_t b = threadIdx.x; b < 32768; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    uint32_t s, e;
-    zl_group_range(part_off, g, G, stride, *total, s, e);
-    const uint32_t per = (e - s + nslices - 1) / nslices;
-    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[part_lo[j] & 0x7FFFu], 1u);
-    __syncthreads();
-    uint32_t* out = counts + (size_t)slice * NB + (size_t)g * 32768;
-    for (uint32_t b = threadIdx.x; b < 32768; b += blockDim.x) out[b] = hist[b];
-}
-// block (range, g): owns fine buckets [range*RB, (range+1)*RB) of group g; streams the group's list, LDS cursors
-static __global__ void __launch_bounds__(1024) k_msm_scatter_group(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_idx,
-                                                                    const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
-                                                                    const uint32_t* __restrict__ total, uint32_t RB, const uint32_t* __restrict__ offsets,
-                                                                    uint32_t* __restrict__ entries) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t range = blockIdx.x, g = blockIdx.y;
-    const uint32_t b0 = range * RB;
-    const uint32_t* os = offsets + (size_t)g * 32768 + b0;
-    for (uint32_t b = threadIdx.x; b < RB; b += blockDim.x) cur[b] = os[b];
-    __syncthreads();
-    uint32_t s, e;
-    zl_group_range(part_off, g, G, stride, *total, s, e);
-    // scalar head up to a 16-B boundary, 8 codes per 16-B load in the body, scalar tail
-    const uint32_t body0 = min(e, (s + 7u) & ~7u), body1 = max(body0, e & ~7u);
-    auto emit = [&](uint32_t idx, uint32_t code) {
-        const uint32_t bucket = code & 0x7FFFu;
-        if (bucket - b0 < RB) {
-            const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
-            entries[pos] = idx | ((code >> 15) << 31);
-        }
-    };
-    for (uint32_t j = s + threadIdx.x; j < body0; j += blockDim.x) emit(part_idx[j], part_lo[j]);
-    const uint4* dv = reinterpret_cast<const uint4*>(part_lo);
-    const uint4* iv = reinterpret_cast<const uint4*>(part_idx);
-    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
-        // 8 codes (16 B) + their 8 table indices (2 x 16 B) per lane, loaded unconditionally: per-match 4-B gathers made
-        // this kernel 27 ms (8 divergent loads per iteration, 16 cache lines each)
-        const uint4 v = dv[j8];
-        const uint4 i0 = iv[2 * (size_t)j8], i1 = iv[2 * (size_t)j8 + 1];
-        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t idxs[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-#pragma unroll
-        for (int k = 0; k < 8; k++) emit(idxs[k], (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-    }
-    for (uint32_t j = body1 + threadIdx.x; j < e; j += blockDim.x) emit(part_idx[j], part_lo[j]);
-}
-
 // ---- levels 2 and 3 of the wide sort: 128 sub-groups of 256 buckets per group, then an LDS-staged bucket sort -----------------
 // Measured on gfx950: a scattered 4-byte store costs about one 64-B L2 write transaction (~25 ps each at 2^24*12 entries), while
 // a partition into <= 128 streams writes long runs and an LDS-staged sort writes fully coalesced.  So: group (32768 buckets) ->
@@ -837,8 +780,6 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr_done = true;
         }
@@ -853,12 +794,11 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
             const uint32_t P = Gn * W * nslices;  // partition counters, order (group, window, slice)
             const uint32_t pscan_blocks = (P + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-            uint32_t fslices = (256 + Gn - 1) / Gn;  // fine-histogram slices per group
             const size_t b_lo = (((size_t)n * W * 2 + 255) / 256) * 256, b_hi = (((size_t)n * W + 255) / 256) * 256;
             const size_t b_plo = b_lo, b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
-            const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256, b_fc = (size_t)fslices * NB * 4;
+            const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256;
             void* pd;
-            if ((rc = zl_scratch_get(ctx, 5, b_lo + b_hi + b_plo + b_pidx + b_pc + b_fc + 256, &pd))) return rc;
+            if ((rc = zl_scratch_get(ctx, 5, b_lo + b_hi + b_plo + b_pidx + b_pc + 256, &pd))) return rc;
             unsigned char* q = (unsigned char*)pd;
             uint16_t* d_lo16 = (uint16_t*)q; q += b_lo;
             uint8_t* d_hi8 = (uint8_t*)q; q += b_hi;
@@ -867,8 +807,6 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            q += b_pc;
-            uint32_t* d_fcounts = (uint32_t*)q;
             hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_lo16, d_hi8);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
