@@ -195,7 +195,7 @@ def main():
         elapsed = float(tt.item())
 
     ntt_info = None
-    if not args.no_ntt and rank == 0:
+    if not args.no_ntt and rank == 0 and world == 1:  # the extra legs are 1-GPU measurements (N > 1 runs report the MSM line only)
         ln = args.ntt_log_n
         x = random_scalars_lt_r(1 << ln, 3000)
         dx = torch.from_numpy(x.view(np.int64)).to(dev)
@@ -226,7 +226,7 @@ def main():
         del dx
 
     g16_info = None
-    if args.groth16_k > 0 and rank == 0:
+    if args.groth16_k > 0 and rank == 0 and world == 1:
         # config 5: Groth16 prove of the Poseidon-hash chain circuit through the C++ host mirror (Groth16<E>::compile /
         # prove, csrc/zl_host.h): matrices + proving key device-resident, only the assignment travels per proof.
         from openzl_amd import Circuit, Groth16Keys
@@ -271,7 +271,7 @@ def main():
         circ.close()
 
     cpu = None
-    if not args.no_cpu and rank == 0:
+    if not args.no_cpu and rank == 0 and world == 1:
         cpu, _ = cpu_baseline(args.cpu_log_n, args.cpu_threads)
 
     if rank == 0:

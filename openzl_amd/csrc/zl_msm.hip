@@ -34,7 +34,7 @@
 
 #define ZL_CHUNK_MAX 64    // entries per lane in msm_accumulate (smaller for small inputs: more lanes, shorter chains)
 #define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
-#define ZL_SEG 16          // buckets per lane in msm_reduce
+#define ZL_SEG_DEFAULT 16  // buckets per lane in msm_reduce (32 for the big merged bucket set: fewer k0 multiples per bucket)
 
 // ------------------------------------------------------------------------------------------------ digits
 __device__ __forceinline__ uint32_t zl_get_bits(const uint32_t* __restrict__ s, int pos, int c) {
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_
 // lane (w, seg): buckets k = k0+1 .. k0+ZL_SEG of window w (bucket index k-1).  sum k*B_k = sum (k-k0) B_k + k0 * sum B_k
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>* __restrict__ bucket_sums, uint32_t H, uint32_t segs_per_window,
-                                                        uint32_t total_segs, XYZZ<typename G::F>* __restrict__ seg_out) {
+                                                        uint32_t total_segs, XYZZ<typename G::F>* __restrict__ seg_out, uint32_t ZL_SEG) {
     using F = typename G::F;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_segs) return;
@@ -737,6 +737,8 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
+        uint32_t ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (uint32_t)ZL_SEG_DEFAULT;
+        if (getenv("ZL_TUNE_SEG")) ZL_SEG = (uint32_t)std::max(1, atoi(getenv("ZL_TUNE_SEG")));
         const uint32_t segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
         const uint32_t total_segs = segs_per_set * SETS;
         const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
@@ -885,7 +887,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
-        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs);
+        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs, ZL_SEG);
         if (stage1) {
             // (set, part) partial sums of SUMW segment results each, then one block per set over the partials
             hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS * stage1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, SUMW, segs_per_set, stage1, d_stage1);
