@@ -51,6 +51,14 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
     zl_ntt_free(ctx);
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux->stream);
+        for (auto& sc : ctx->aux->scratch) if (sc.p) (void)hipFree(sc.p);
+        for (auto& ev : ctx->aux->ev) if (ev) (void)hipEventDestroy(ev);
+        if (ctx->aux->own_stream) (void)hipStreamDestroy(ctx->aux->own_stream);
+        delete ctx->aux;
+        ctx->aux = nullptr;
+    }
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -99,6 +99,7 @@ struct zl_ctx {
     uint64_t next_handle = 1;
     zl_scratch scratch[10];
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
+    zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 7)
     size_t g16_h_n = 0;
 };

@@ -116,28 +116,28 @@ struct Engine {
     }
     static F2 conj(const F2& a) { return F2{a.c0, zl::neg(a.c1)}; }
     // q-power Frobenius of the untwisted point expressed on the twist (BN tail): (conj(x) xi^((q-1)/3), conj(y) xi^((q-1)/2))
-    static G2Aff frob(const G2Aff& Q) {
-        static bool init = false;
-        static F2 g2, g3;
-        if (!init) {
-            const F2 xi{small(PP::ISHIFT), F::one()};  // w^6 = i + ISHIFT
-            uint32_t e[FqP::N];
-            // (q - 1) / 3 and (q - 1) / 2 by long division on 32-bit words
-            for (int d : {3, 2}) {
-                uint64_t rem = 0;
-                uint32_t qm1[FqP::N];
-                for (int i = 0; i < FqP::N; i++) qm1[i] = FqP::mod(i);
-                qm1[0] -= 1;  // q is odd: no borrow
-                for (int i = FqP::N - 1; i >= 0; i--) {
-                    uint64_t cur = (rem << 32) | qm1[i];
-                    e[i] = (uint32_t)(cur / d);
-                    rem = cur % d;
-                }
-                (d == 3 ? g2 : g3) = f2_pow(xi, e, 32 * FqP::N);
+    struct FrobConsts { F2 g2, g3; };
+    static FrobConsts make_frob_consts() {
+        FrobConsts k;
+        const F2 xi{small(PP::ISHIFT), F::one()};  // w^6 = i + ISHIFT
+        uint32_t e[FqP::N];
+        for (int d : {3, 2}) {  // (q - 1) / 3 and (q - 1) / 2 by long division on 32-bit words
+            uint64_t rem = 0;
+            uint32_t qm1[FqP::N];
+            for (int i = 0; i < FqP::N; i++) qm1[i] = FqP::mod(i);
+            qm1[0] -= 1;  // q is odd: no borrow
+            for (int i = FqP::N - 1; i >= 0; i--) {
+                uint64_t cur = (rem << 32) | qm1[i];
+                e[i] = (uint32_t)(cur / d);
+                rem = cur % d;
             }
-            init = true;
+            (d == 3 ? k.g2 : k.g3) = f2_pow(xi, e, 32 * FqP::N);
         }
-        return G2Aff{zl::mul(conj(Q.x), g2), zl::mul(conj(Q.y), g3), Q.inf};
+        return k;
+    }
+    static G2Aff frob(const G2Aff& Q) {
+        static const FrobConsts k = make_frob_consts();  // thread-safe one-time initialisation (C++11 magic static)
+        return G2Aff{zl::mul(conj(Q.x), k.g2), zl::mul(conj(Q.y), k.g3), Q.inf};
     }
     // Miller loop value f_{loop,Q}(P) (times subfield factors); P, Q affine Montgomery, neither at infinity
     static Fq12 miller(const F& xP, const F& yP, const G2Aff& Q) {
