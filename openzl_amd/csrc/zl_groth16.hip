@@ -197,7 +197,11 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         ctx->aux = new (std::nothrow) zl_ctx();
         if (!ctx->aux) return ZL_ENOMEM;
         ctx->aux->device = ctx->device;
-        hipError_t e = hipStreamCreateWithFlags(&ctx->aux->own_stream, hipStreamNonBlocking);
+        // lowest priority: the long G2 accumulate kernel must not starve the short kernels of the main stream (measured: a 5 us
+        // G1 kernel waited 13 ms behind it at equal priority)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&ctx->aux->own_stream, hipStreamNonBlocking, prio_lo);
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->aux->ev[i]);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
         ctx->aux->stream = ctx->aux->own_stream;
