@@ -93,6 +93,8 @@ int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars,
 #define ZL_PARTIAL_WORDS 48
 int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial);
 int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
+/* wrap a canonical affine point (all-zero = infinity) as a partial, e.g. to fold an extra term into zl_partials_sum */
+int zl_partial_from_affine(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint64_t* out_partial);
 
 /* ---- NTT (replaces Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place) -------------------- */
 /* data: 2^log_n Fr elements x 4 u64, in place, natural order in and out; flags: ZL_MONT, ZL_COSET, ZL_INVERSE */

@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
 ]
@@ -88,6 +88,7 @@ def load_library(path: Optional[str] = None):
     L.zl_msm_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p, u8p]
     L.zl_msm_partial_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p]
     L.zl_partials_sum.argtypes = [C.c_int, C.c_int, u64p, C.c_size_t, u64p, u8p]
+    L.zl_partial_from_affine.argtypes = [C.c_int, C.c_int, u64p, u64p]
     L.zl_ntt.argtypes = [vp, C.c_int, u64p, C.c_uint, C.c_uint]
     L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
     L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]

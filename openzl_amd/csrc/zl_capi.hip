@@ -194,6 +194,11 @@ int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials
     return ZL_DISPATCH(curve, group, zl_partial_to_affine, acc, out_xy, out_inf);
 }
 
+int zl_partial_from_affine(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint64_t* out_partial) {
+    if (!xy || !out_partial || !valid_cg(curve, group)) return ZL_EINVAL;
+    return ZL_DISPATCH(curve, group, zl_partial_from_affine, xy, out_partial);
+}
+
 int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags) {
     if (!ctx || !d_data) return ZL_EINVAL;
     if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;

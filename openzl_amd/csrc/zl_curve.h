@@ -9,6 +9,7 @@
 // Formulas: EFD "xyzz" madd-2008-s / add-2008-s / dbl-2008-s-1 / mdbl-2008-s-1.
 #pragma once
 #include "zl_field.h"
+#include "zl_field28.h"
 
 // ---- Fq2 = Fq[u]/(u^2+1) (both curves), the G2 coordinate field -----------------------------------------
 template <class P>
@@ -17,6 +18,7 @@ struct Fp2 {
     ZL_HD static Fp2 zero() { return Fp2{Fp<P>::zero(), Fp<P>::zero()}; }
     ZL_HD static Fp2 one() { return Fp2{Fp<P>::one(), Fp<P>::zero()}; }
     ZL_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    ZL_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     ZL_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
     ZL_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
 };
@@ -25,6 +27,10 @@ template <class P> ZL_HD Fp2<P> add(const Fp2<P>& a, const Fp2<P>& b) { return F
 template <class P> ZL_HD Fp2<P> sub(const Fp2<P>& a, const Fp2<P>& b) { return Fp2<P>{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 template <class P> ZL_HD Fp2<P> dbl(const Fp2<P>& a) { return Fp2<P>{dbl(a.c0), dbl(a.c1)}; }
 template <class P> ZL_HD Fp2<P> neg(const Fp2<P>& a) { return Fp2<P>{neg(a.c0), neg(a.c1)}; }
+template <int J, class P> ZL_HD Fp2<P> subk(const Fp2<P>& a, const Fp2<P>& b) { return sub(a, b); }
+template <int J, class P> ZL_HD Fp2<P> negk(const Fp2<P>& a) { return neg(a); }
+template <class P> ZL_HD Fp2<P> wred(const Fp2<P>& a) { return a; }
+template <class P> ZL_HD Fp2<P> canon(const Fp2<P>& a) { return a; }
 template <class P> ZL_HD Fp2<P> mul(const Fp2<P>& a, const Fp2<P>& b) {
     // Karatsuba: 3 base multiplications
     Fp<P> v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1);
@@ -45,18 +51,28 @@ template <class P> ZL_HD Fp2<P> to_mont(const Fp2<P>& a) { return Fp2<P>{to_mont
 template <class P> ZL_HD Fp2<P> from_mont(const Fp2<P>& a) { return Fp2<P>{from_mont(a.c0), from_mont(a.c1)}; }
 }  // namespace zl
 
+template <class P>
+struct FieldIO<Fp2<P>> {
+    static constexpr int WORDS = 2 * P::N;
+    ZL_HD static Fp2<P> load_canon(const uint32_t* w) { return Fp2<P>{FieldIO<Fp<P>>::load_canon(w), FieldIO<Fp<P>>::load_canon(w + P::N)}; }
+    ZL_HD static Fp2<P> load_mont32(const uint32_t* w) { return Fp2<P>{FieldIO<Fp<P>>::load_mont32(w), FieldIO<Fp<P>>::load_mont32(w + P::N)}; }
+    ZL_HD static void store_canon(uint32_t* w, const Fp2<P>& a) { FieldIO<Fp<P>>::store_canon(w, a.c0); FieldIO<Fp<P>>::store_canon(w + P::N, a.c1); }
+};
+
 // ---- points ----------------------------------------------------------------------------------------------
 // Affine point in device memory.  Infinity is encoded as x = y = 0 ((0,0) is on neither curve: b != 0).
 template <class F>
 struct Affine {
     F x, y;
-    ZL_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZL_HD bool is_inf() const { return x.raw_zero() && y.raw_zero(); }  // stored points are canonical: all-zero limbs
     ZL_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
 };
 template <class F>
 struct XYZZ {
     F x, y, zz, zzz;
-    ZL_HD bool is_inf() const { return zz.is_zero(); }
+    // exact-zero limbs: infinity is only ever written as zero(); a computed zz is a product of non-zero factors (P == 0 and
+    // y == 0 are branched away before multiplying; both curves have odd order, so no point has y == 0)
+    ZL_HD bool is_inf() const { return zz.raw_zero(); }
     ZL_HD static XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
     ZL_HD static XYZZ from_affine(const Affine<F>& a) {
         if (a.is_inf()) return inf();
@@ -66,52 +82,56 @@ struct XYZZ {
 
 namespace zl {
 
+// Bounds in the comments are in units of q for the lazily reduced field (zl_field28.h); for the fully reduced 32-bit field the
+// subk<J> / wred spellings are plain sub / identity.  Contract of every routine: coordinates < 8q in, < 8q out.
 // 2*(x,y) for an affine, non-infinity point (mdbl-2008-s-1, a = 0)
 template <class F>
-ZL_HD XYZZ<F> dbl_affine(const F& x, const F& y) {
-    F u = dbl(y), v = sqr(u), w = mul(u, v), s = mul(x, v);
-    F xx = sqr(x);
-    F m = add(dbl(xx), xx);
+ZL_HD XYZZ<F> dbl_affine(const F& x, const F& y) {          // x, y < 8
+    const F u = dbl(y);                                       // < 16
+    const F v = sqr(u), w = mul(u, v), s = mul(x, v);         // 256, 32, 16 -> < 2
+    const F xx = sqr(x);                                      // 64 -> < 2
+    const F m = add(dbl(xx), xx);                             // < 6
     XYZZ<F> r;
-    r.x = sub(sqr(m), dbl(s));
-    r.y = sub(mul(m, sub(s, r.x)), mul(w, y));
+    r.x = subk<2>(sqr(m), dbl(s));                            // 36 -> 2; dbl(s) < 4 -> < 6
+    r.y = subk<1>(mul(m, subk<3>(s, r.x)), mul(w, y));        // s - x3 < 10; 60 -> 2; w*y: 16 -> 2 -> < 4
     r.zz = v;
     r.zzz = w;
-    return r;  // y == 0 -> zz == 0 -> infinity
+    return r;  // y == 0 -> zz == 0 -> infinity (does not occur on these curves)
 }
 // p = 2p (dbl-2008-s-1, a = 0)
 template <class F>
 ZL_HD void dbl_inplace(XYZZ<F>& p) {
     if (p.is_inf()) return;
-    F u = dbl(p.y), v = sqr(u), w = mul(u, v), s = mul(p.x, v);
-    F xx = sqr(p.x);
-    F m = add(dbl(xx), xx);
-    F x3 = sub(sqr(m), dbl(s));
-    p.y = sub(mul(m, sub(s, x3)), mul(w, p.y));
+    const F u = dbl(p.y);                                     // < 16
+    const F v = sqr(u), w = mul(u, v), s = mul(p.x, v);       // < 2
+    const F xx = sqr(p.x);
+    const F m = add(dbl(xx), xx);                             // < 6
+    const F x3 = subk<2>(sqr(m), dbl(s));                     // < 6
+    p.y = subk<1>(mul(m, subk<3>(s, x3)), mul(w, p.y));       // < 4
     p.x = x3;
-    p.zz = mul(v, p.zz);
+    p.zz = mul(v, p.zz);                                      // 16 -> < 2
     p.zzz = mul(w, p.zzz);
 }
-// p += (qx, qy) (affine, q must not be infinity); neg_q selects p -= q.   madd-2008-s
+// p += (qx, qy) (affine, canonical or < 2q, q must not be infinity); neg_q selects p -= q.   madd-2008-s
 template <class F>
 ZL_HD void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
-    F qy = neg_q ? neg(qy_in) : qy_in;
+    const F qy = neg_q ? negk<1>(qy_in) : qy_in;              // < 2
     if (p.is_inf()) {
         p.x = qx; p.y = qy; p.zz = F::one(); p.zzz = F::one();
         return;
     }
-    F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);
-    F pp_ = sub(u2, p.x), r = sub(s2, p.y);
+    const F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);          // 16 -> < 2
+    const F pp_ = subk<3>(u2, p.x), r = subk<3>(s2, p.y);     // < 10
     if (pp_.is_zero()) {
         if (r.is_zero()) { p = dbl_affine(qx, qy); return; }
         p = XYZZ<F>::inf();
         return;
     }
-    F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);
-    F x3 = sub(sub(sqr(r), ppp), dbl(q));
-    p.y = sub(mul(r, sub(q, x3)), mul(p.y, ppp));
+    const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2
+    const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q));       // (2 + 2) + 4 -> < 8
+    p.y = subk<1>(mul(r, subk<3>(q, x3)), mul(p.y, ppp));     // q - x3 < 10; 100 -> 2; 16 -> 2 -> < 4
     p.x = x3;
-    p.zz = mul(p.zz, pp);
+    p.zz = mul(p.zz, pp);                                     // < 2
     p.zzz = mul(p.zzz, ppp);
 }
 // p += q (add-2008-s)
@@ -119,28 +139,33 @@ template <class F>
 ZL_HD void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
     if (q.is_inf()) return;
     if (p.is_inf()) { p = q; return; }
-    F u1 = mul(p.x, q.zz), u2 = mul(q.x, p.zz);
-    F s1 = mul(p.y, q.zzz), s2 = mul(q.y, p.zzz);
-    F pp_ = sub(u2, u1), r = sub(s2, s1);
+    const F u1 = mul(p.x, q.zz), u2 = mul(q.x, p.zz);         // 64 -> < 2
+    const F s1 = mul(p.y, q.zzz), s2 = mul(q.y, p.zzz);
+    const F pp_ = subk<1>(u2, u1), r = subk<1>(s2, s1);       // < 4
     if (pp_.is_zero()) {
         if (r.is_zero()) { dbl_inplace(p); return; }
         p = XYZZ<F>::inf();
         return;
     }
-    F pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(u1, pp);
-    F x3 = sub(sub(sqr(r), ppp), dbl(q_));
-    p.y = sub(mul(r, sub(q_, x3)), mul(s1, ppp));
+    const F pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(u1, pp);  // < 2
+    const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q_));      // < 8
+    p.y = subk<1>(mul(r, subk<3>(q_, x3)), mul(s1, ppp));     // < 4
     p.x = x3;
     p.zz = mul(mul(p.zz, q.zz), pp);
     p.zzz = mul(mul(p.zzz, q.zzz), ppp);
 }
+// p = -p
+template <class F>
+ZL_HD void neg_inplace(XYZZ<F>& p) {
+    p.y = wred(negk<3>(p.y));                                 // y < 8 -> 8q - y -> weakly reduced < 4
+}
 template <class F>
 ZL_HD Affine<F> to_affine(const XYZZ<F>& p) {
     if (p.is_inf()) return Affine<F>::inf();
-    F izzz = inv(p.zzz);
-    F t = mul(p.zz, izzz);  // = 1/sqrt-ish: zz/zzz = 1/z
-    F izz = sqr(t);         // zz^2/zzz^2 = 1/zz  (zz^3 = zzz^2)
-    return Affine<F>{mul(p.x, izz), mul(p.y, izzz)};
+    const F izzz = inv(p.zzz);
+    const F t = mul(p.zz, izzz);  // zz/zzz = 1/z
+    const F izz = sqr(t);         // zz^2/zzz^2 = 1/zz  (zz^3 = zzz^2)
+    return Affine<F>{canon(mul(p.x, izz)), canon(mul(p.y, izzz))};  // canonical: the all-zero limb test stays exact in memory
 }
 // p = k*p for a small unsigned multiplier (double-and-add, MSB first)
 template <class F>

@@ -54,6 +54,7 @@ struct alignas(16) Fp {
         return acc == 0;
     }
     ZL_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+    ZL_HD bool raw_zero() const { return is_zero(); }  // limbs all zero (fully reduced representation)
 };
 
 namespace zl {
@@ -114,9 +115,26 @@ template <class P>
 ZL_HD Fp<P> dbl(const Fp<P>& a) {
     return add(a, a);
 }
+// bias-annotated spellings shared with the lazily reduced 28-bit field (zl_field28.h): no-ops here, every value is < p
+template <int J, class P>
+ZL_HD Fp<P> subk(const Fp<P>& a, const Fp<P>& b) {
+    return sub(a, b);
+}
+template <class P>
+ZL_HD Fp<P> wred(const Fp<P>& a) {
+    return a;
+}
+template <class P>
+ZL_HD Fp<P> canon(const Fp<P>& a) {
+    return a;
+}
 template <class P>
 ZL_HD Fp<P> neg(const Fp<P>& a) {
     return sub(Fp<P>::zero(), a);  // a == 0: no borrow, stays 0; otherwise p - a
+}
+template <int J, class P>
+ZL_HD Fp<P> negk(const Fp<P>& a) {
+    return neg(a);
 }
 
 // Montgomery product a*b*R^-1 mod p, CIOS on 32-bit limbs.  All moduli have their top bit clear, so the

@@ -1,0 +1,272 @@
+// zl_field28.h -- BLS12-381 base field on 14 unsaturated 28-bit limbs with lazy reduction (gfx950 MSM kernels).
+//
+// Why: v_mad_u64_u32 accumulates 64 bits; with 28-bit limbs a column of <= 28 products (< 2^56 each) never overflows, so the
+// Montgomery product is a pure chain of 392 mads with no carry handling at all (the 32-bit-limb multiplier needs a
+// v_addc_co_u32 after every mad).  Measured (tools/fbench28.hip): 66.8 vs 49.6 G mul/s at 2 waves/SIMD, 71.6 vs 55.3 at 4.
+// Representation: value * 2^392 mod q (Montgomery, R' = 2^392), limbs < 2^28, value only *weakly* reduced: q < 2^381 leaves 11 spare
+// bits, so sums and differences are not reduced at all between multiplications.  Contracts (B(x) = bound of x in units of q):
+//     mul(a, b)      needs B(a) * B(b) <= 2500  (a*b < 2^392 q)          -> result < 2q
+//     add(a, b)      -> B(a) + B(b);    dbl(a) -> 2 B(a)
+//     subk<J>(a, b)  needs B(b) <= 2^J                                     -> B(a) + 2^J      (a - b + 2^J q, limb-wise non-negative)
+//     wred(a)        needs B(a) <= 2000                                    -> < 4q            (top-limb quotient estimate)
+//     is_zero(a)     needs B(a) <= 2000; exact test of a == 0 (mod q)
+// Every point routine of zl_curve.h takes coordinates < 8q and returns coordinates < 8q; its comments carry the bound of every
+// intermediate.  Memory / ABI formats are unchanged: load_* / store_* convert from / to arkworks' 32-bit-word layouts.
+#pragma once
+#include "zl_field.h"
+
+template <class P28, class P32>
+struct alignas(16) Fp28 {
+    static constexpr int L = P28::L;
+    static constexpr int CANON_WORDS = P32::N;  // canonical / arkworks layouts: 32-bit words
+    uint32_t l[L];
+    uint32_t pad_[16 - L];  // 64-byte elements: an affine point is exactly one 128-B line
+
+    ZL_HD static Fp28 zero() {
+        Fp28 r;
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 16 - L; i++) r.pad_[i] = 0;
+        return r;
+    }
+    ZL_HD static Fp28 one() {
+        Fp28 r = zero();
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = P28::one(i);
+        return r;
+    }
+    ZL_HD bool raw_zero() const {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) acc |= l[i];
+        return acc == 0;
+    }
+    ZL_HD bool is_zero() const;  // == 0 mod q (value < 2000 q)
+    ZL_HD bool operator==(const Fp28& o) const;
+    ZL_HD bool operator!=(const Fp28& o) const { return !(*this == o); }
+};
+
+namespace zl {
+
+template <class A, class B>
+ZL_HD void carry28(Fp28<A, B>& r) {  // limbs < 2^32 - 2^4 -> limbs < 2^28 (value unchanged, top limb absorbs)
+    constexpr int L = A::L;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+        r.l[i + 1] += r.l[i] >> 28;
+        r.l[i] &= 0xFFFFFFFu;
+    }
+}
+template <class A, class B>
+ZL_HD Fp28<A, B> add(const Fp28<A, B>& a, const Fp28<A, B>& b) {
+    Fp28<A, B> r = a;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) r.l[i] = a.l[i] + b.l[i];
+    carry28(r);
+    return r;
+}
+template <class A, class B>
+ZL_HD Fp28<A, B> dbl(const Fp28<A, B>& a) {
+    Fp28<A, B> r = a;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) r.l[i] = a.l[i] << 1;
+    carry28(r);
+    return r;
+}
+// a - b + 2^J q, J in 1..6; needs b < 2^J q
+template <int J, class A, class B>
+ZL_HD Fp28<A, B> subk(const Fp28<A, B>& a, const Fp28<A, B>& b) {
+    static_assert(J >= 1 && J <= 6, "bias table holds 2q .. 64q");
+    Fp28<A, B> r = a;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) r.l[i] = a.l[i] + A::kq(J, i) - b.l[i];  // limbs 0..12: >= 2^28 - b_i > 0; top limb: mod 2^32
+    carry28(r);
+    return r;
+}
+template <int J, class A, class B>
+ZL_HD Fp28<A, B> negk(const Fp28<A, B>& a) {
+    return subk<J>(Fp28<A, B>::zero(), a);
+}
+// generic spellings used by code that is shared with the 32-bit field (conservative biases)
+template <class A, class B> ZL_HD Fp28<A, B> sub(const Fp28<A, B>& a, const Fp28<A, B>& b) { return subk<4>(a, b); }  // b < 16q
+template <class A, class B> ZL_HD Fp28<A, B> neg(const Fp28<A, B>& a) { return negk<4>(a); }
+
+// Montgomery product a*b/2^392 (+ multiple of q): < 2q when a*b < 2^392 q
+template <class A, class B>
+ZL_HD Fp28<A, B> mul_body28(const Fp28<A, B>& a, const Fp28<A, B>& b) {
+    constexpr int L = A::L;
+    uint32_t m[L];
+    Fp28<A, B> r = a;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        m[k] = ((uint32_t)acc * A::INV) & 0xFFFFFFFu;
+        acc += (uint64_t)m[k] * A::mod(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        r.l[k - L] = (uint32_t)acc & 0xFFFFFFFu;
+        acc >>= 28;
+    }
+    return r;
+}
+template <class A, class B>
+ZL_NOINLINE_HD Fp28<A, B> mul_call28(Fp28<A, B> a, Fp28<A, B> b) {
+    return mul_body28(a, b);
+}
+template <class A, class B>
+ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_INLINE_MUL28)
+    return mul_body28(a, b);  // device: inline (4 KB per site, a mixed addition stays inside the instruction cache)
+#else
+    return mul_call28<A, B>(a, b);
+#endif
+}
+template <class A, class B>
+ZL_HD Fp28<A, B> sqr(const Fp28<A, B>& a) {
+    return mul(a, a);
+}
+// weak reduction: value < 2000 q -> < 4q.  t = floor(top_limb * floor(2^44 / (qtop+1)) / 2^44) <= floor(a / q), short by <= 2
+template <class A, class B>
+ZL_HD Fp28<A, B> wred(const Fp28<A, B>& a) {
+    constexpr int L = A::L;
+    const uint32_t t = (uint32_t)(((uint64_t)a.l[L - 1] * A::QTOP_RECIP) >> 44);
+    Fp28<A, B> r = a;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int64_t s = (int64_t)a.l[i] - (int64_t)((uint64_t)t * A::mod(i)) + c;
+        r.l[i] = (uint32_t)s & 0xFFFFFFFu;
+        c = s >> 28;
+    }
+    return r;  // the final carry is 0: a - t q >= 0 and < 2^392
+}
+// canonical representative in [0, q)
+template <class A, class B>
+ZL_HD Fp28<A, B> canon(const Fp28<A, B>& a) {
+    constexpr int L = A::L;
+    Fp28<A, B> r = wred(a);
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {  // < 4q -> at most three subtractions
+        uint32_t t[L];
+        int64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            const int64_t s = (int64_t)r.l[i] - (int64_t)A::mod(i) + c;
+            t[i] = (uint32_t)s & 0xFFFFFFFu;
+            c = s >> 28;
+        }
+        const bool ge = c >= 0;  // no borrow out: r >= q
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = ge ? t[i] : r.l[i];
+    }
+    return r;
+}
+}  // namespace zl
+
+template <class P28, class P32>
+ZL_HD bool Fp28<P28, P32>::is_zero() const {
+    const Fp28 r = zl::wred(*this);  // < 4q: zero mod q iff r in {0, q, 2q, 3q}
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (r.l[0] != P28::mq(k, 0)) continue;  // cheap filter on the low limb
+        uint32_t diff = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) diff |= r.l[i] ^ P28::mq(k, i);
+        any = any || diff == 0;
+    }
+    return any;
+}
+template <class P28, class P32>
+ZL_HD bool Fp28<P28, P32>::operator==(const Fp28& o) const {
+    return zl::subk<6>(zl::wred(*this), zl::wred(o)).is_zero();
+}
+
+namespace zl {
+template <class A, class B>
+ZL_HD Fp28<A, B> inv(const Fp28<A, B>& a) {  // Fermat a^(q-2); exponent from the 32-bit-word modulus
+    constexpr int N = B::N;
+    uint32_t e[N];
+    uint32_t borrow = 2;
+    for (int i = 0; i < N; i++) {
+        const uint32_t m = B::mod(i);
+        e[i] = m - borrow;
+        borrow = m < borrow ? 1u : 0u;
+    }
+    Fp28<A, B> acc = Fp28<A, B>::one();
+    for (int i = 32 * N - 1; i >= 0; i--) {
+        acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, a);
+    }
+    return acc;
+}
+// ---- layout conversions (32-bit little-endian words, as in the C ABI / arkworks) ---------------------------------------------
+template <class A, class B>
+ZL_HD Fp28<A, B> pack28(const uint32_t* w) {  // plain integer, CANON_WORDS 32-bit words -> 28-bit limbs
+    Fp28<A, B> r = Fp28<A, B>::zero();
+#pragma unroll
+    for (int i = 0; i < A::L; i++) {
+        const int bit = 28 * i, word = bit >> 5, sh = bit & 31;
+        uint64_t v = word < B::N ? w[word] : 0;
+        if (word + 1 < B::N) v |= (uint64_t)w[word + 1] << 32;
+        r.l[i] = (uint32_t)(v >> sh) & 0xFFFFFFFu;
+    }
+    return r;
+}
+template <class A, class B>
+ZL_HD void unpack28(uint32_t* w, const Fp28<A, B>& a) {  // limbs < 2^28, value < 2^(32*N)
+#pragma unroll
+    for (int j = 0; j < B::N; j++) w[j] = 0;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) {
+        const int bit = 28 * i, word = bit >> 5, sh = bit & 31;
+        const uint64_t v = (uint64_t)a.l[i] << sh;
+        if (word < B::N) w[word] |= (uint32_t)v;
+        if (word + 1 < B::N) w[word + 1] |= (uint32_t)(v >> 32);
+    }
+}
+#define ZL_CONST28(NAME, FN)                                  \
+    template <class A, class B>                               \
+    ZL_HD Fp28<A, B> NAME() {                                 \
+        Fp28<A, B> r = Fp28<A, B>::zero();                    \
+        _Pragma("unroll") for (int i = 0; i < A::L; i++) r.l[i] = A::FN(i); \
+        return r;                                             \
+    }
+ZL_CONST28(const28_r2, r2)
+ZL_CONST28(const28_from_m32, from_m32)
+#undef ZL_CONST28
+}  // namespace zl
+
+// ---- uniform conversion API for both field representations (used at every memory / ABI boundary) -----------------------------
+template <class F>
+struct FieldIO;
+template <class P>
+struct FieldIO<Fp<P>> {
+    static constexpr int WORDS = P::N;
+    ZL_HD static Fp<P> load_canon(const uint32_t* w) { Fp<P> c; for (int i = 0; i < P::N; i++) c.l[i] = w[i]; return zl::to_mont(c); }
+    ZL_HD static Fp<P> load_mont32(const uint32_t* w) { Fp<P> c; for (int i = 0; i < P::N; i++) c.l[i] = w[i]; return c; }
+    ZL_HD static void store_canon(uint32_t* w, const Fp<P>& a) { const Fp<P> c = zl::from_mont(a); for (int i = 0; i < P::N; i++) w[i] = c.l[i]; }
+};
+template <class A, class B>
+struct FieldIO<Fp28<A, B>> {
+    using F = Fp28<A, B>;
+    static constexpr int WORDS = B::N;
+    ZL_HD static F load_canon(const uint32_t* w) { return zl::canon(zl::mul(zl::pack28<A, B>(w), zl::const28_r2<A, B>())); }
+    ZL_HD static F load_mont32(const uint32_t* w) { return zl::canon(zl::mul(zl::pack28<A, B>(w), zl::const28_from_m32<A, B>())); }
+    ZL_HD static void store_canon(uint32_t* w, const F& a) {
+        F one = F::zero();
+        one.l[0] = 1;
+        zl::unpack28(w, zl::canon(zl::mul(zl::wred(a), one)));
+    }
+};

@@ -51,22 +51,23 @@ __global__ void __launch_bounds__(256) k_qap_pointwise(Fp<FrP>* __restrict__ a, 
 template <class G>
 static XYZZ<typename G::F> affine_from_canon(const uint64_t* xy) {
     using F = typename G::F;
-    Affine<F> a;
-    memcpy(&a.x, xy, sizeof(F));
-    memcpy(&a.y, reinterpret_cast<const unsigned char*>(xy) + sizeof(F), sizeof(F));
-    if (a.is_inf()) return XYZZ<F>::inf();
-    a.x = zl::to_mont(a.x);
-    a.y = zl::to_mont(a.y);
-    return XYZZ<F>::from_affine(a);
+    constexpr int WORDS = FieldIO<F>::WORDS;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(xy);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2 * WORDS; k++) acc |= w[k];
+    if (!acc) return XYZZ<F>::inf();
+    return XYZZ<F>::from_affine(Affine<F>{FieldIO<F>::load_canon(w), FieldIO<F>::load_canon(w + WORDS)});
 }
 template <class G>
 static void store_canon(uint64_t* out_xy, uint8_t* out_inf, const XYZZ<typename G::F>& p) {
     using F = typename G::F;
-    Affine<F> a = zl::to_affine(p);
+    constexpr int WORDS = FieldIO<F>::WORDS;
+    uint32_t* w = reinterpret_cast<uint32_t*>(out_xy);
     *out_inf = p.is_inf() ? 1 : 0;
-    if (!p.is_inf()) { a.x = zl::from_mont(a.x); a.y = zl::from_mont(a.y); }
-    memcpy(out_xy, &a.x, sizeof(F));
-    memcpy(reinterpret_cast<unsigned char*>(out_xy) + sizeof(F), &a.y, sizeof(F));
+    if (p.is_inf()) { for (int k = 0; k < 2 * WORDS; k++) w[k] = 0; return; }
+    const Affine<F> a = zl::to_affine(p);
+    FieldIO<F>::store_canon(w, a.x);
+    FieldIO<F>::store_canon(w + WORDS, a.y);
 }
 template <class F>
 static XYZZ<F> from_partial(const uint64_t* partial) {
@@ -260,7 +261,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     XYZZ<F1> g_c = zl::mul_scalar(g_a, sw);
     zl::add_full(g_c, zl::mul_scalar(g1_b, rw));
     XYZZ<F1> rs_delta = zl::mul_scalar(zl::mul_scalar(delta1, rw), sw);
-    rs_delta.y = zl::neg(rs_delta.y);
+    zl::neg_inplace(rs_delta);
     zl::add_full(g_c, rs_delta);
     zl::add_full(g_c, from_partial<F1>(part[3]));
     zl::add_full(g_c, from_partial<F1>(part[2]));

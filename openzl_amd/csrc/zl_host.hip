@@ -207,14 +207,13 @@ Result<bool> Groth16<E>::verify(const VerifyingContext& vk, const Input& input, 
     const size_t q1 = 2 * G1::FQ64;
     const size_t ni = vk.gamma_abc_g1.size() / q1;
     if (ni == 0 || input.size() + 1 != ni) return res;  // ark: wrong number of public inputs -> Err(MalformedVerifyingKey)
+    constexpr int W1 = FieldIO<F1>::WORDS;
     auto load = [&](const uint64_t* xy) {
-        Affine<F1> a;
-        memcpy(&a.x, xy, sizeof(F1));
-        memcpy(&a.y, reinterpret_cast<const unsigned char*>(xy) + sizeof(F1), sizeof(F1));
-        if (a.is_inf()) return XYZZ<F1>::inf();
-        a.x = zl::to_mont(a.x);
-        a.y = zl::to_mont(a.y);
-        return XYZZ<F1>::from_affine(a);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(xy);
+        uint32_t acc = 0;
+        for (int k = 0; k < 2 * W1; k++) acc |= w[k];
+        if (!acc) return XYZZ<F1>::inf();
+        return XYZZ<F1>::from_affine(Affine<F1>{FieldIO<F1>::load_canon(w), FieldIO<F1>::load_canon(w + W1)});
     };
     // prepare_inputs: g_ic = gamma_abc[0] + sum_i x_i gamma_abc[i + 1]
     XYZZ<F1> acc = load(vk.gamma_abc_g1.data());
@@ -226,12 +225,12 @@ Result<bool> Groth16<E>::verify(const VerifyingContext& vk, const Input& input, 
     auto neg_canon = [&](const XYZZ<F1>& p, std::vector<uint64_t>& out) {  // canonical affine of -p
         out.assign(q1, 0);
         if (p.is_inf()) return;
-        Affine<F1> a = zl::to_affine(p);
-        a.y = zl::neg(a.y);
-        a.x = zl::from_mont(a.x);
-        a.y = zl::from_mont(a.y);
-        memcpy(out.data(), &a.x, sizeof(F1));
-        memcpy(reinterpret_cast<unsigned char*>(out.data()) + sizeof(F1), &a.y, sizeof(F1));
+        XYZZ<F1> n = p;
+        zl::neg_inplace(n);
+        const Affine<F1> a = zl::to_affine(n);
+        uint32_t* w = reinterpret_cast<uint32_t*>(out.data());
+        FieldIO<F1>::store_canon(w, a.x);
+        FieldIO<F1>::store_canon(w + W1, a.y);
     };
     std::vector<uint64_t> n_alpha, n_acc, n_c;
     neg_canon(load(vk.alpha_g1.data()), n_alpha);

@@ -623,15 +623,15 @@ __global__ void __launch_bounds__(128) k_bases_import(const uint32_t* __restrict
     using F = typename G::F;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    constexpr int WORDS = sizeof(F) / 4;
-    Affine<F> p;
+    constexpr int WORDS = FieldIO<F>::WORDS;  // 32-bit words per coordinate in the ABI layout
     const uint32_t* src = in + (size_t)i * 2 * WORDS;
-    uint32_t* px = reinterpret_cast<uint32_t*>(&p.x);
-    uint32_t* py = reinterpret_cast<uint32_t*>(&p.y);
-    for (int k = 0; k < WORDS; k++) { px[k] = src[k]; py[k] = src[WORDS + k]; }
-    bool inf = p.is_inf() || (inf_flags && inf_flags[i]);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2 * WORDS; k++) acc |= src[k];
+    const bool inf = acc == 0 || (inf_flags && inf_flags[i]);
     if (inf) { out[i] = Affine<F>::inf(); return; }
-    if (to_mont) { p.x = zl::to_mont(p.x); p.y = zl::to_mont(p.y); }
+    Affine<F> p;
+    if (to_mont) { p.x = FieldIO<F>::load_canon(src); p.y = FieldIO<F>::load_canon(src + WORDS); }
+    else { p.x = FieldIO<F>::load_mont32(src); p.y = FieldIO<F>::load_mont32(src + WORDS); }
     if (check) {
         F lhs = zl::sqr(p.y);
         F rhs = zl::add(zl::mul(zl::sqr(p.x), p.x), G::coeff_b());
@@ -645,13 +645,12 @@ __global__ void __launch_bounds__(128) k_bases_export(const Affine<typename G::F
     using F = typename G::F;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    constexpr int WORDS = sizeof(F) / 4;
-    Affine<F> p = in[i];
-    if (!p.is_inf()) { p.x = zl::from_mont(p.x); p.y = zl::from_mont(p.y); }
-    const uint32_t* px = reinterpret_cast<const uint32_t*>(&p.x);
-    const uint32_t* py = reinterpret_cast<const uint32_t*>(&p.y);
+    constexpr int WORDS = FieldIO<F>::WORDS;
+    const Affine<F> p = in[i];
     uint32_t* dst = out + (size_t)i * 2 * WORDS;
-    for (int k = 0; k < WORDS; k++) { dst[k] = px[k]; dst[WORDS + k] = py[k]; }
+    if (p.is_inf()) { for (int k = 0; k < 2 * WORDS; k++) dst[k] = 0; return; }
+    FieldIO<F>::store_canon(dst, p.x);
+    FieldIO<F>::store_canon(dst + WORDS, p.y);
 }
 // bases[i] = k[i] * G by double-and-add, then one inversion per point (input generator, untimed)
 template <class G>
@@ -959,14 +958,31 @@ static int partial_to_affine_t(const uint64_t* partial, uint64_t* out_xy, uint8_
     using F = typename G::F;
     XYZZ<F> p;
     memcpy(&p, partial, sizeof p);
-    Affine<F> a = zl::to_affine(p);
+    const Affine<F> a = zl::to_affine(p);
     const bool inf = p.is_inf();
     if (out_inf) *out_inf = inf ? 1 : 0;
-    if (!inf) { a.x = zl::from_mont(a.x); a.y = zl::from_mont(a.y); }
-    memcpy(out_xy, &a.x, sizeof(F));
-    memcpy(reinterpret_cast<unsigned char*>(out_xy) + sizeof(F), &a.y, sizeof(F));
+    constexpr int WORDS = FieldIO<F>::WORDS;
+    uint32_t* w = reinterpret_cast<uint32_t*>(out_xy);
+    if (inf) { for (int k = 0; k < 2 * WORDS; k++) w[k] = 0; return ZL_OK; }
+    FieldIO<F>::store_canon(w, a.x);
+    FieldIO<F>::store_canon(w + WORDS, a.y);
     return ZL_OK;
 }
+// canonical affine point -> opaque partial (tests; lets a caller inject a point into zl_partials_sum)
+template <class G>
+static int partial_from_affine_t(const uint64_t* xy, uint64_t* out_partial) {
+    using F = typename G::F;
+    constexpr int WORDS = FieldIO<F>::WORDS;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(xy);
+    uint32_t acc = 0;
+    for (int k = 0; k < 2 * WORDS; k++) acc |= w[k];
+    XYZZ<F> p = XYZZ<F>::inf();
+    if (acc) p = XYZZ<F>::from_affine(Affine<F>{FieldIO<F>::load_canon(w), FieldIO<F>::load_canon(w + WORDS)});
+    memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);
+    memcpy(out_partial, &p, sizeof p);
+    return ZL_OK;
+}
+int ZL_GNAME(zl_partial_from_affine)(const uint64_t* xy, uint64_t* out_partial) { return partial_from_affine_t<ZL_G>(xy, out_partial); }
 int ZL_GNAME(zl_partial_to_affine)(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf) {
     return partial_to_affine_t<ZL_G>(partial, out_xy, out_inf);
 }
@@ -991,7 +1007,7 @@ int ZL_GNAME(zl_partials_fold)(const uint64_t* partials, size_t count, uint64_t*
 template <class G>
 static int bases_upload_t(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out) {
     using F = typename G::F;
-    const size_t rec = 2 * sizeof(F);
+    const size_t rec = (size_t)2 * FieldIO<F>::WORDS * 4;  // ABI record: x||y in 32-bit words (independent of the device representation)
     if (stride == 0) stride = rec;
     if (stride < rec || n >= (1ull << 31)) return ZL_EINVAL;
     if (inf_off >= 0 && (size_t)inf_off >= stride) return ZL_EINVAL;
@@ -1072,12 +1088,13 @@ static int bases_download_t(zl_ctx* ctx, const zl_bases& b, size_t first, size_t
     if (!count) return ZL_OK;
     void* d_out;
     int rc;
-    if ((rc = zl_scratch_get(ctx, 5, count * 2 * sizeof(F), &d_out))) return rc;
+    const size_t rec = (size_t)2 * FieldIO<F>::WORDS * 4;
+    if ((rc = zl_scratch_get(ctx, 5, count * rec, &d_out))) return rc;
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL((k_bases_export<G>), dim3((uint32_t)((count + 127) / 128)), dim3(128), 0, st,
                        reinterpret_cast<const Affine<F>*>(b.d_pts) + first, (uint32_t)count, (uint32_t*)d_out);
     ZL_HIP(ctx, hipGetLastError());
-    ZL_HIP(ctx, hipMemcpyAsync(out_xy, d_out, count * 2 * sizeof(F), hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipMemcpyAsync(out_xy, d_out, count * rec, hipMemcpyDeviceToHost, st));
     ZL_HIP(ctx, hipStreamSynchronize(st));
     return ZL_OK;
 }

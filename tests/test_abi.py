@@ -36,16 +36,10 @@ def test_strerror_and_argument_checks():
 
 
 def _partial_from_affine(curve, pt):
-    """encode an affine point as the backend's XYZZ partial (Montgomery limbs, zz = zzz = R mod p)"""
-    n = curve.fq.limbs64
+    """wrap an affine point as the backend's opaque partial (zl_partial_from_affine)"""
+    xy = ol.points_to_limbs(curve, [pt])[0]
     out = np.zeros(ZL_PARTIAL_WORDS, dtype=np.uint64)
-    if pt is None:
-        one = ol.ints_to_limbs([curve.fq.to_mont(1)], n)[0]
-        out[0:n], out[n:2 * n] = one, one  # x = y = 1, zz = zzz = 0
-        return out
-    vals = [curve.fq.to_mont(pt[0]), curve.fq.to_mont(pt[1]), curve.fq.to_mont(1), curve.fq.to_mont(1)]
-    for i, v in enumerate(vals):
-        out[i * n:(i + 1) * n] = ol.ints_to_limbs([v], n)[0]
+    assert load_library().zl_partial_from_affine(curve.cid, 1, ol.p64(xy), ol.p64(out)) == 0
     return out
 
 
