@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+FQ_MUL_PEAK_G = 66.8  # measured: tools/fbench28.hip, 2 waves/SIMD, MI355X (profiles/r01_fbench_field_mul.log)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
@@ -92,6 +93,52 @@ def cpu_baseline(log_n_sample: int, threads_req: int):
     }, (curve, bases, s, r1)
 
 
+def skewed(s):
+    """Groth16-witness-like scalars: 50 % zeros, 25 % ones, the rest unchanged, shuffled."""
+    n = s.shape[0]
+    s2 = s.copy()
+    s2[: n // 2] = 0
+    s2[n // 2: 3 * n // 4] = np.array([1, 0, 0, 0], dtype=np.uint64)
+    perm = np.random.Generator(np.random.PCG64(11)).permutation(n)
+    return np.ascontiguousarray(s2[perm])
+
+
+def distributed_ntt_leg(be, dist, torch, dev, rank, world, log_m):
+    """One 2^(log_m + log2 world)-point transform over all ranks (weak scaling: 2^log_m elements per GPU): cross step ->
+    RCCL all_to_all_single -> local transform, and back.  Timed per transform with barriers, max over ranks."""
+    from openzl_amd import ZL_BLS12_381
+    from openzl_amd.sharded import DeviceNttEngine, sharded_ntt
+
+    log_g = world.bit_length() - 1
+    log_n = log_m + log_g
+    eng = DeviceNttEngine(be, ZL_BLS12_381)
+    x = random_scalars_lt_r(1 << log_m, 5000 + rank)  # this rank's block-column slice (any residues < r are valid Montgomery limbs)
+    f_ms, i_ms = [], []
+    cur = torch.from_numpy(x.view(np.int64)).to(dev)
+    for it in range(1 + 3):
+        for inverse, acc in ((False, f_ms), (True, i_ms)):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            cur = sharded_ntt(eng, cur, log_n, inverse=inverse, mont=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            if it:
+                acc.append((time.perf_counter() - t0) * 1e3)
+    ok = bool((cur.cpu().numpy().view(np.uint64) == x).all())
+    tt = torch.tensor([float(np.mean(f_ms)), float(np.mean(i_ms)), 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if tt[2].item() != 0.0:
+        raise RuntimeError("distributed NTT self-check failed: iNTT(NTT(x)) != x")
+    f, i = float(tt[0].item()), float(tt[1].item())
+    tot = float(1 << log_n)
+    sent = (1 << log_m) * 32.0 * (world - 1) / world
+    return {"log_n": log_n, "elements_per_gpu": 1 << log_m, "layout": "coefficients block-column, evaluations cyclic (include/zl_backend.h)",
+            "forward_ms": f, "inverse_ms": i, "forward_elems_per_s": tot / (f * 1e-3), "inverse_elems_per_s": tot / (i * 1e-3),
+            "exchange": "one RCCL all_to_all_single per transform", "bytes_sent_per_gpu": sent,
+            "self_check": "iNTT(NTT(x)) == x on every rank; bit-exact parity of the legs in tests/test_gpu_sharded_ntt.py"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +153,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-skew", action="store_true")
+    ap.add_argument("--scalars", choices=["uniform", "skewed"], default="uniform", help="skewed: 50%% zeros, 25%% ones, rest uniform (profiling aid)")
     ap.add_argument("--ntt-log-n", type=int, default=24)
     ap.add_argument("--groth16-k", type=int, default=4096, help="config 5: chained Poseidon hashes (4096 -> domain 2^20); 0 = skip")
     args = ap.parse_args()
@@ -150,6 +199,8 @@ def main():
     if pre_c >= 0:
         be.bases_precompute(h, pre_c)
     s_host = random_scalars_lt_r(n, 2000 + rank)
+    if args.scalars == "skewed":
+        s_host = skewed(s_host)
     d_scalars = torch.from_numpy(s_host.view(np.int64)).to(dev)
     torch.cuda.synchronize()
 
@@ -194,10 +245,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    skew_info = None
+    if rank == 0 and world == 1 and not args.no_skew:
+        # SURVEY.md §8d's non-uniform variant: Groth16-witness-like scalars (50 % zeros, 25 % ones, rest uniform), same bases
+        s2 = skewed(s_host)
+        d2 = torch.from_numpy(s2.view(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        ts = []
+        for it in range(1 + 3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            be.msm_partial_dev(h, d2.data_ptr(), n)
+            if it:
+                ts.append(time.perf_counter() - t1)
+        skew_info = {"scalars": "50% zeros, 25% ones, 25% uniform < r, shuffled", "ms_per_step": float(np.mean(ts)) * 1e3,
+                     "points_per_s": n / float(np.mean(ts)),
+                     "note": "zero digits are dropped by the recoder; scalars equal to 1 bypass the sort (compact list + direct sum, as "
+                             "arkworks special-cases them); other repeated values form giant buckets cut into fixed 64-entry chunks and merged "
+                             "in two stages; exactness of these paths: tests/test_gpu_msm.py (skewed cases), tests/test_gpu_msm_fuzz.py"}
+        del d2
+
     ntt_info = None
     if not args.no_ntt:
-        # second half of the metric.  N > 1: independent replicas, one 2^log_n transform per GPU (Groth16's a/b/c pipelines are
-        # independent transforms; a single distributed NTT is not built) -- every rank measures, rank 0 reports max-over-ranks.
+        # second half of the metric.  N > 1: (i) independent replicas, one 2^log_n transform per GPU (Groth16's a/b/c pipelines
+        # are independent transforms) -- every rank measures, rank 0 reports max-over-ranks; (ii) further down, ONE
+        # 2^(log_n + log2 N) transform spread over all ranks with a single RCCL all-to-all (openzl_amd/sharded.py).
         ln = args.ntt_log_n
         x = random_scalars_lt_r(1 << ln, 3000 + rank)
         dx = torch.from_numpy(x.view(np.int64)).to(dev)
@@ -311,7 +383,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"bls12_381_g1_msm_2^{args.log_n}_per_gpu", "points_per_gpu": n, "curve": "BLS12-381 G1",
-                       "scalars": "uniform < r (255 bit)", "bases": "k_i*G from a device generator, resident in HBM",
+                       "scalars": "uniform < r (255 bit)" if args.scalars == "uniform" else "50% zeros, 25% ones, 25% uniform", "bases": "k_i*G from a device generator, resident in HBM",
                        "window_bits": int(tm.window_bits),
                        "precomputed_table": (f"2^(c w) P_i for all windows, c={int(tm.window_bits)} (one merged bucket set; built at upload)"
                                              if pre_c >= 0 else "none"),
@@ -320,13 +392,42 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_final.json)",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
+                         "int_alu": {"unit": "G Fq-mul/s", "achieved": float(tm.entries) * 10.0 / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
+                                     "frac": float(tm.entries) * 10.0 / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
+                                     "note": "the roofline that actually binds: (point, window) pairs x 10 field multiplications per mixed add "
+                                             "(8M + 2S) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
+                                             "at the kernel's occupancy (tools/fbench28.hip; profiles/r01_fbench_field_mul.log)"},
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
             "cpu_baseline": cpu,
+            "msm_skewed_scalars": skew_info,
             "ntt": ntt_info,
             "groth16": g16_info,
         }
+    else:
+        line = None
+    if world > 1 and not args.no_ntt and (world & (world - 1)) == 0 and world <= 16 and os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl":
+        # Distributed NTT leg, last and under a watchdog: if the exchange stalls, the MSM line above is still printed.
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                line["ntt"]["distributed"] = {"error": "timed out after 120 s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, _give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            dinfo = distributed_ntt_leg(be, dist, torch, dev, rank, world, args.ntt_log_n)
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line, the headline number stands
+            dinfo = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            line["ntt"]["distributed"] = dinfo
+    if rank == 0:
         print(json.dumps(line), flush=True)
     be.bases_free(h)
     be.close()

@@ -52,6 +52,8 @@ enum {
 #define ZL_COSET 2u   /* NTT: coset variant (g = Fr multiplicative generator: 7 BLS12-381, 5 BN254) */
 #define ZL_INVERSE 4u /* NTT: inverse transform (scaled by n^-1) */
 #define ZL_CHECK 8u   /* bases upload: verify y^2 = x^3 + b on the device */
+#define ZL_MONT_IN 16u  /* NTT: only the input is Montgomery (ZL_MONT = both sides); the legs of the distributed transform */
+#define ZL_MONT_OUT 32u /* NTT: only the output is Montgomery */
 
 /* ---- context ------------------------------------------------------------------------------------------- */
 int zl_ctx_create(zl_ctx** out, int device_id);
@@ -100,6 +102,19 @@ int zl_partial_from_affine(zl_curve_t curve, zl_group_t group, const uint64_t* x
 /* data: 2^log_n Fr elements x 4 u64, in place, natural order in and out; flags: ZL_MONT, ZL_COSET, ZL_INVERSE */
 int zl_ntt(zl_ctx* ctx, zl_curve_t curve, uint64_t* data, unsigned log_n, unsigned flags);
 int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags);
+/* Multi-GPU transform (ark-poly has no distributed form -- same function as zl_ntt on the 2^log_n
+ * domain, split over G = 2^log_g ranks, M = N/G elements each, B = M/G, with ONE all-to-all between the two local steps):
+ *   block-column layout: rank g holds x[j1*M + g*B + c] at local [j1*B + c]  (j1 < G, c < B)
+ *   cyclic layout:       rank k holds X[k + G*k2]       at local [k2]        (k2 < M)
+ *   forward: zl_ntt_cross_dev (block-column data) -> all-to-all of G chunks of B elements -> zl_ntt_dev(log_n - log_g)
+ *            leaves the evaluations in cyclic layout;
+ *   inverse: zl_ntt_dev(log_n - log_g, ZL_INVERSE) on cyclic data -> all-to-all -> zl_ntt_cross_dev(ZL_INVERSE)
+ *            leaves the coefficients in block-column layout.
+ * zl_ntt_cross_dev does the G-point transform across the G local rows of each column, the w_N^(j2 k1) twiddle, and the
+ * ZL_COSET scaling of the whole 2^log_n domain; the local M-point leg is always called WITHOUT ZL_COSET.  Elements are
+ * Montgomery between the legs (ZL_MONT_IN / ZL_MONT_OUT pick the outer representation).  1 <= log_g <= 4, 2*log_g <= log_n.
+ * openzl_amd/sharded.py drives the three steps over torch.distributed (RCCL all_to_all_single). */
+int zl_ntt_cross_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags);
 
 /* ---- Groth16 prover (replaces ark_groth16::create_random_proof behind Groth16::<E>::prove, groth16.rs:445-457) - */
 /* R1CS in CSR form, as ark-relations' ConstraintMatrices hold it: variable order = instance block (index 0 is the

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libzl_backend.so")
 
 ZL_BLS12_381, ZL_BN254 = 1, 2
 ZL_G1, ZL_G2 = 1, 2
-ZL_MONT, ZL_COSET, ZL_INVERSE, ZL_CHECK = 1, 2, 4, 8
+ZL_MONT, ZL_COSET, ZL_INVERSE, ZL_CHECK, ZL_MONT_IN, ZL_MONT_OUT = 1, 2, 4, 8, 16, 32
 ZL_PARTIAL_WORDS = 48
 CURVES = {"bls12_381": ZL_BLS12_381, "bn254": ZL_BN254}
 FQ_LIMBS = {ZL_BLS12_381: 6, ZL_BN254: 4}
@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
 ]
@@ -91,6 +91,7 @@ def load_library(path: Optional[str] = None):
     L.zl_partial_from_affine.argtypes = [C.c_int, C.c_int, u64p, u64p]
     L.zl_ntt.argtypes = [vp, C.c_int, u64p, C.c_uint, C.c_uint]
     L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
+    L.zl_ntt_cross_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.zl_groth16_prove.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(R1csC), u64p, u64p, u64p, C.POINTER(G16ProofC)]
@@ -243,6 +244,14 @@ class Backend:
     def ntt_dev(self, curve: int, d_data: int, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = True):
         flags = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0) | (ZL_MONT if mont else 0)
         self._check(self.L.zl_ntt_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags), "zl_ntt_dev")
+
+    def ntt_dev_flags(self, curve: int, d_data: int, log_n: int, flags: int):
+        """zl_ntt_dev with raw flags (ZL_MONT_IN / ZL_MONT_OUT legs of the distributed transform)."""
+        self._check(self.L.zl_ntt_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags), "zl_ntt_dev")
+
+    def ntt_cross_dev(self, curve: int, d_data: int, log_n: int, log_g: int, rank: int, flags: int):
+        """Cross-rank step of the distributed transform (include/zl_backend.h: zl_ntt_cross_dev)."""
+        self._check(self.L.zl_ntt_cross_dev(self._ctx, curve, C.c_void_p(d_data), log_n, log_g, rank, flags), "zl_ntt_cross_dev")
 
     # ---- Groth16 ----------------------------------------------------------------------------------------------
     def groth16_prove(self, curve: int, pk: dict, r1cs: dict, assignment: np.ndarray, r: np.ndarray, s: np.ndarray):

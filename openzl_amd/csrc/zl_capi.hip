@@ -202,9 +202,16 @@ int zl_partial_from_affine(zl_curve_t curve, zl_group_t group, const uint64_t* x
 int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags) {
     if (!ctx || !d_data) return ZL_EINVAL;
     if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;
-    if (flags & ~(ZL_MONT | ZL_COSET | ZL_INVERSE)) return ZL_EINVAL;
+    if (flags & ~(ZL_MONT | ZL_COSET | ZL_INVERSE | ZL_MONT_IN | ZL_MONT_OUT)) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     return zl_ntt_run(ctx, curve, d_data, log_n, flags);
+}
+int zl_ntt_cross_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags) {
+    if (!ctx || !d_data) return ZL_EINVAL;
+    if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;
+    if (flags & ~(ZL_MONT | ZL_COSET | ZL_INVERSE | ZL_MONT_IN | ZL_MONT_OUT)) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return zl_ntt_cross_run(ctx, curve, d_data, log_n, log_g, rank, flags);
 }
 int zl_ntt(zl_ctx* ctx, zl_curve_t curve, uint64_t* data, unsigned log_n, unsigned flags) {
     if (!ctx || !data || log_n > 32) return ZL_EINVAL;

@@ -34,6 +34,8 @@
 
 #define ZL_CHUNK_MAX 64    // entries per lane in msm_accumulate (smaller for small inputs: more lanes, shorter chains)
 #define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
+#define ZL_GIANT_SPAN 4096 // ... and into more than this by ZL_GIANT_PARTS blocks (two stages)
+#define ZL_GIANT_PARTS 32
 #define ZL_SEG_DEFAULT 16  // buckets per lane in msm_reduce (32 for the big merged bucket set: fewer k0 multiples per bucket)
 
 // ------------------------------------------------------------------------------------------------ digits
@@ -46,13 +48,39 @@ __device__ __forceinline__ uint32_t zl_get_bits(const uint32_t* __restrict__ s, 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
+
+// Scalars equal to 1 (boolean witnesses: a large share of a Groth16 assignment; arkworks' MSM special-cases them too) bypass
+// the sort: the recoder emits no digits for them and appends the index to a compact list (one atomic per wave); k_msm_ones
+// then sums the listed bases directly.  Without this they would all land in bucket 1 of window 0 -- one giant bucket that
+// serialises the fine sort of its sub-group and the partial merge.
+__device__ __forceinline__ bool zl_take_one(const uint32_t* s, uint32_t i, uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+    const bool one = s[0] == 1u && (s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0u;
+    const uint64_t m = __ballot(one);
+    if (m == 0) return false;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(ones_count, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (one) ones_list[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    return one;
+}
+
 // MODE 0: histogram; MODE 1: scatter (cursor initialised with the bucket offsets)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
-                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ entries) {
+                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ entries,
+                                                    uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t* s = scalars + (size_t)i * 8;
+    const bool live = i < n;
+    const uint32_t* s = scalars + (size_t)(live ? i : 0) * 8;
+    uint32_t sv[8];
+    for (int k = 0; k < 8; k++) sv[k] = live ? s[k] : 0u;
+    if (MODE == 0) {
+        if (zl_take_one(sv, i, ones_list, ones_count)) return;
+    } else if (sv[0] == 1u && (sv[1] | sv[2] | sv[3] | sv[4] | sv[5] | sv[6] | sv[7]) == 0u) {
+        return;
+    }
+    if (!live) return;
     const uint32_t H = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -74,12 +102,16 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 // ---- LDS counting sort (c <= 16): no global atomics -------------------------------------------------------------
 // k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
-static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits) {
+static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits,
+                                                             uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-    const uint4 lo = sp[0], hi = sp[1];
-    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const bool live = i < n;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
+    uint4 lo = sp[0], hi = sp[1];
+    if (!live) lo = hi = make_uint4(0, 0, 0, 0);
+    uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;  // listed: contributes no digits
+    if (!live) return;
     const uint32_t H = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -172,12 +204,16 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 // share the buckets: n*W mixed adds into 2^(c-1) buckets and a single bucket reduction.  The bucket index has up to 23
 // bits, so the counting sort is two-level: partition by the high bits (group = bucket >> 15), then the LDS sort per group.
 static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
-                                                                  uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8) {
+                                                                  uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
+                                                                  uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-    const uint4 lo = sp[0], hi = sp[1];
-    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const bool live = i < n;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
+    uint4 lo = sp[0], hi = sp[1];
+    if (!live) lo = hi = make_uint4(0, 0, 0, 0);
+    uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;
+    if (!live) return;
     const uint32_t H = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -505,7 +541,8 @@ __global__ void __launch_bounds__(64, ZL_ACC_WAVES) k_msm_accumulate(const uint3
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
-                                                   uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
+                                                   uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
+                                                   uint32_t ZL_CHUNK) {
     using F = typename G::F;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
@@ -513,6 +550,7 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
     if (s == e) { bucket_sums[b] = XYZZ<F>::inf(); return; }
     const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
     if (t0 == t1) return;  // written directly by msm_accumulate
+    if (t1 - t0 + 1 > ZL_GIANT_SPAN) { giant_list[atomicAdd(giant_count, 1u)] = b; return; }
     if (t1 - t0 + 1 > ZL_BIG_SPAN) { big_list[atomicAdd(big_count, 1u)] = b; return; }
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t t = t0; t <= t1; t++) {
@@ -524,7 +562,24 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
 // lanes of the block-tree kernels: 256 for G1, 128 for G2 (384-B points: a 256-lane block is capped at 256 VGPRs and spills)
 template <class G>
 struct TreeLanes { static constexpr int N = sizeof(XYZZ<typename G::F>) > 256 ? 128 : 256; };
-// one block per giant bucket
+template <class G>
+__device__ __forceinline__ void zl_block_tree(XYZZ<typename G::F>* sh, XYZZ<typename G::F>& acc) {
+    using F = typename G::F;
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x];
+            const XYZZ<F> o = sh[threadIdx.x + off];
+            zl::add_full(a, o);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    acc = sh[0];
+    __syncthreads();
+}
+// one block per big bucket (ZL_BIG_SPAN < chunks <= ZL_GIANT_SPAN)
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
@@ -541,20 +596,65 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_
             const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
             zl::add_full(acc, p);
         }
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) {
-                XYZZ<F> a = sh[threadIdx.x];
-                const XYZZ<F> o = sh[threadIdx.x + off];
-                zl::add_full(a, o);
-                sh[threadIdx.x] = a;
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) bucket_sums[b] = sh[0];
-        __syncthreads();
+        zl_block_tree<G>(sh, acc);
+        if (threadIdx.x == 0) bucket_sums[b] = acc;
     }
+}
+// giant buckets (> ZL_GIANT_SPAN chunks: many equal scalars), stage 1: block (item, part) tree-sums its share of the bucket's
+// chunk partials -> giant_tmp[item * ZL_GIANT_PARTS + part]; stage 2: one lane per giant bucket folds the ZL_GIANT_PARTS sums
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ giant_list,
+                                                          const uint32_t* __restrict__ giant_count, uint32_t ZL_CHUNK) {
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t part = blockIdx.x % ZL_GIANT_PARTS;
+    for (uint32_t item = blockIdx.x / ZL_GIANT_PARTS; item < *giant_count; item += gridDim.x / ZL_GIANT_PARTS) {
+        const uint32_t b = giant_list[item];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+        const uint32_t per = (t1 - t0 + ZL_GIANT_PARTS) / ZL_GIANT_PARTS;  // ceil((t1 - t0 + 1) / parts)
+        const uint32_t lo = t0 + part * per, hi = min(t1 + 1, lo + per);
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+            const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+            zl::add_full(acc, p);
+        }
+        zl_block_tree<G>(sh, acc);
+        if (threadIdx.x == 0) giant_tmp[(size_t)item * ZL_GIANT_PARTS + part] = acc;
+    }
+}
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __restrict__ bucket_sums, const XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
+    using F = typename G::F;
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *giant_count) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t k = 0; k < ZL_GIANT_PARTS; k++) {
+        const XYZZ<F> p = giant_tmp[(size_t)item * ZL_GIANT_PARTS + k];
+        zl::add_full(acc, p);
+    }
+    bucket_sums[giant_list[item]] = acc;
+}
+// sum of the bases whose scalar is 1 (list built by the recoder): strided mixed adds per lane, block tree -> out[block]
+#define ZL_ONES_BLOCKS 128
+
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __restrict__ ones_list, const uint32_t* __restrict__ ones_count,
+                                                   const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out) {
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t cnt = *ones_count;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+        const Affine<F> P = bases[ones_list[j]];
+        if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, false);
+    }
+    zl_block_tree<G>(sh, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ bucket reduction
@@ -742,6 +842,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         const uint32_t total_segs = segs_per_set * SETS;
         const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
         const uint32_t max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
+        const uint32_t max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         // tree over the segment results: sets with many segments are summed in two stages
         const uint32_t SUMW = 2048;
         const uint32_t stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
@@ -751,7 +852,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         void* p;
         int rc;
         // slot 0: counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | big count
-        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + 1 + 16;
+        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n;
         if ((rc = zl_scratch_get(ctx, 0, small_words * 4, &p))) return rc;
         d_counts = (uint32_t*)p;
         d_offsets = d_counts + (NB + 1);
@@ -760,23 +861,29 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         uint32_t* d_block_sums = d_small;
         uint32_t* d_big_list = d_block_sums + scan_blocks + 1;
         uint32_t* d_big_count = d_big_list + max_big;
+        uint32_t* d_ones_count = d_big_count + 1;
+        uint32_t* d_giant_count = d_big_count + 2;
+        uint32_t* d_giant_list = d_big_count + 16;
+        uint32_t* d_ones_list = d_giant_list + max_giant;
         if ((rc = zl_scratch_get(ctx, 1, maxE * 4, &p))) return rc;
         d_entries = (uint32_t*)p;
         if ((rc = zl_scratch_get(ctx, 2, (size_t)NB * sizeof(X), &p))) return rc;
         d_buckets = (X*)p;
         if ((rc = zl_scratch_get(ctx, 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
         d_partials = (X*)p;
-        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + (size_t)SETS * (stage1 + 1) + 1) * sizeof(X), &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + (size_t)SETS * (stage1 + 1) + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
         d_segs = (X*)p;
         X* d_stage1 = d_segs + total_segs;
-        X* d_sets = d_stage1 + (size_t)SETS * stage1;
+        X* d_sets = d_stage1 + (size_t)SETS * stage1;  // SETS window sums, then the sum of the scalar-1 bases
+        X* d_ones_parts = d_sets + SETS + 1;
+        X* d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
 
         hipStream_t st = ctx->stream;
         const Affine<F>* d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
-        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 4, st));
+        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 12, st));  // big, ones, giant counts
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
         static bool attr_done = false;
         if (!attr_done) {
@@ -808,7 +915,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_lo16, d_hi8);
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_lo16, d_hi8, d_ones_list, d_ones_count);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
@@ -860,7 +967,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits);
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
@@ -874,18 +981,26 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {
             // wide windows without a table: histogram / scatter with global atomics
-            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr);
+            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries);
+            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count);
         }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
+                           d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count);
+        // scalar-1 bases: window-0 table entries are the bases themselves
+        hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
+                           pre ? d_bases + first : d_bases, d_ones_parts);
+        hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
+                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + SETS);
         hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs, ZL_SEG);
         if (stage1) {
             // (set, part) partial sums of SUMW segment results each, then one block per set over the partials
@@ -896,9 +1011,9 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         }
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
         ZL_HIP(ctx, hipGetLastError());
-        std::vector<X> hw(SETS);
+        std::vector<X> hw(SETS + 1);
         uint32_t hE = 0;
-        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_sets, sizeof(X) * SETS, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_sets, sizeof(X) * (SETS + 1), hipMemcpyDeviceToHost, st));
         ZL_HIP(ctx, hipMemcpyAsync(&hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
         ZL_HIP(ctx, hipStreamSynchronize(st));
         if (ctx->timing_on) {
@@ -917,6 +1032,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
                 zl::add_full(total, hw[w]);
             }
         }
+        zl::add_full(total, hw[SETS]);
     }
     static_assert(sizeof(X) <= ZL_PARTIAL_WORDS * 8, "partial too small");
     memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);

@@ -273,10 +273,12 @@ template <class FrP>
 static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned flags) {
     using F = Fp<FrP>;
     if (n > (unsigned)FrP::TWO_ADICITY || n > 30) return ZL_EINVAL;
-    const bool inverse = flags & ZL_INVERSE, coset = flags & ZL_COSET, mont = flags & ZL_MONT;
+    const bool inverse = flags & ZL_INVERSE, coset = flags & ZL_COSET;
+    const bool mont_in = flags & (ZL_MONT | ZL_MONT_IN), mont_out = flags & (ZL_MONT | ZL_MONT_OUT);
     ctx->timing = zl_timing{};
     if (n == 0) {
         // one element: forward/inverse are the identity (n^-1 = 1, g^0 = 1)
+        if (mont_in != mont_out) return ZL_EINVAL;
         return ZL_OK;
     }
     zl_twiddles* tw;
@@ -322,9 +324,9 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         a.g_lo = g_lo;
         a.g_hi = g_hi;
         a.w_small = small + ((size_t)1 << (a.s ? a.s - 1 : 0));
-        a.to_mont = (p == 1 && !mont) ? 1 : 0;
+        a.to_mont = (p == 1 && !mont_in) ? 1 : 0;
         a.pre_coset = (p == 1 && coset && !inverse) ? 1 : 0;
-        a.from_mont = (last && !mont) ? 1 : 0;
+        a.from_mont = (last && !mont_out) ? 1 : 0;
         a.post_coset = (last && coset && inverse) ? 1 : 0;
         a.post_scale = (last && inverse && !coset) ? 1 : 0;
         for (int k = 0; k < 8; k++) a.ninv[k] = ninv.l[k];
@@ -354,6 +356,154 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     }
     ctx->timing.launches = pl.P;
     return ZL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ distributed transform
+// One rank's "cross" step of a 2^n-point transform spread over G = 2^lg ranks (four-step with ONE
+// all-to-all).  M = N/G, B = M/G.  Index split  j = j1*M + j2 (j1 < G),  k = k1 + G*k2 (k1 < G):
+//     X[k1 + G k2] = sum_j2 w_M^(j2 k2) * [ w_N^(j2 k1) * sum_j1 x[j1 M + j2] w_G^(j1 k1) ]
+// "block-column" layout: rank g holds x[j1*M + g*B + c] at local [j1*B + c];  "cyclic" layout: rank k1 holds X[k1 + G*k2] at
+// local [k2].  Forward: this kernel on block-column data (G-point DFT down each local column, then the twiddle), all-to-all
+// (row k1 -> rank k1), local M-point transform.  Inverse: local inverse M-point transform on cyclic data, all-to-all, this
+// kernel (twiddle, inverse G-point DFT, 1/G).  Coset factors h^(j1 M + j2) split into a per-row constant h^(M j1) and a
+// per-column factor h^j2 that rides on the twiddle.  One thread owns one column: G loads, G stores, all arithmetic in registers.
+struct CrossArgs {
+    uint32_t n_log, lg, logB, L, rank;
+    uint32_t inverse, coset, to_mont, from_mont;
+    const void *t_lo, *t_hi, *g_lo, *g_hi, *w_small;  // tables of the full 2^n domain (inverse tables when inverse)
+    uint32_t cst[8];           // constant folded into the twiddle: 1 (forward), 1/G (inverse), M (inverse coset: g_hi carries 1/N)
+    uint32_t row[16][8];       // coset: h^(+-M j1)
+};
+template <class FrP, int LG>
+__global__ void __launch_bounds__(256) k_ntt_cross(Fp<FrP>* __restrict__ data, CrossArgs a) {
+    using F = Fp<FrP>;
+    constexpr int G = 1 << LG;
+    const uint32_t B = 1u << a.logB;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const uint64_t j2 = ((uint64_t)a.rank << a.logB) + c;
+    const F* t_lo = reinterpret_cast<const F*>(a.t_lo);
+    const F* t_hi = reinterpret_cast<const F*>(a.t_hi);
+    const F* w_small = reinterpret_cast<const F*>(a.w_small);
+    F v[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        v[j] = data[(size_t)j * B + c];
+        if (a.to_mont) v[j] = zl::to_mont(v[j]);
+    }
+    // tw = cst * (coset ? h^(+-j2) : 1), step = w_N^(+-j2): row k1 is scaled by tw * step^k1
+    F tw, step = twiddle2(t_lo, t_hi, a.L, j2);
+#pragma unroll
+    for (int w = 0; w < F::N; w++) tw.l[w] = a.cst[w];
+    if (a.coset) tw = zl::mul(tw, twiddle2(reinterpret_cast<const F*>(a.g_lo), reinterpret_cast<const F*>(a.g_hi), a.L, j2));
+    if (a.inverse) {
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            v[k] = zl::mul(v[k], tw);
+            tw = zl::mul(tw, step);
+        }
+    } else if (a.coset) {
+#pragma unroll
+        for (int j = 1; j < G; j++) {
+            F r;
+#pragma unroll
+            for (int w = 0; w < F::N; w++) r.l[w] = a.row[j][w];
+            v[j] = zl::mul(v[j], r);
+        }
+    }
+    // G-point DIF butterflies; output k sits at position bitrev(k)
+#pragma unroll
+    for (int hl = LG - 1; hl >= 0; hl--) {
+        const int h = 1 << hl;
+#pragma unroll
+        for (int q = 0; q < G / 2; q++) {
+            const int k = q & (h - 1), i = ((q >> hl) << (hl + 1)) | k;
+            const F u = v[i], x = v[i + h];
+            v[i] = zl::add(u, x);
+            F d = zl::sub(u, x);
+            if (k != 0) d = zl::mul(d, w_small[k << (LG - 1 - hl)]);
+            v[i + h] = d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        int pos = 0;
+#pragma unroll
+        for (int b = 0; b < LG; b++) pos |= ((k >> b) & 1) << (LG - 1 - b);
+        F x = v[pos];
+        if (!a.inverse) {
+            x = zl::mul(x, tw);
+            tw = zl::mul(tw, step);
+        } else if (a.coset && k != 0) {
+            F r;
+#pragma unroll
+            for (int w = 0; w < F::N; w++) r.l[w] = a.row[k][w];
+            x = zl::mul(x, r);
+        }
+        if (a.from_mont) x = zl::from_mont(x);
+        data[(size_t)k * B + c] = x;
+    }
+}
+
+template <class FrP>
+static int ntt_cross_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned lg, unsigned rank, unsigned flags) {
+    using F = Fp<FrP>;
+    if (n > (unsigned)FrP::TWO_ADICITY || n > 32 || lg < 1 || lg > 4 || 2 * lg > n || rank >= (1u << lg)) return ZL_EINVAL;
+    const bool inverse = flags & ZL_INVERSE, coset = flags & ZL_COSET;
+    const bool mont_in = flags & (ZL_MONT | ZL_MONT_IN), mont_out = flags & (ZL_MONT | ZL_MONT_OUT);
+    zl_twiddles* tw;
+    int rc;
+    if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw))) return rc;
+    const unsigned L = tw->lo_bits;
+    CrossArgs a{};
+    a.n_log = n;
+    a.lg = lg;
+    a.logB = n - 2 * lg;
+    a.L = L;
+    a.rank = rank;
+    a.inverse = inverse;
+    a.coset = coset;
+    a.to_mont = !mont_in;
+    a.from_mont = !mont_out;
+    const F* t_lo = reinterpret_cast<const F*>(tw->d_lo);
+    const F* t_hi = reinterpret_cast<const F*>(tw->d_hi);
+    a.t_lo = t_lo;
+    a.t_hi = t_hi;
+    a.g_lo = t_hi + ((size_t)1 << (n - L));
+    a.g_hi = reinterpret_cast<const F*>(a.g_lo) + ((size_t)1 << L);
+    a.w_small = reinterpret_cast<const F*>(tw->d_small) + ((size_t)1 << (lg - 1));
+    F cst = F::one();
+    if (inverse) cst = coset ? zl::from_u64<FrP>(1ull << (n - lg)) : zl::inv(zl::from_u64<FrP>(1ull << lg));
+    for (int w = 0; w < F::N; w++) a.cst[w] = cst.l[w];
+    if (coset) {
+        F g;
+        for (int i = 0; i < F::N; i++) g.l[i] = FrP::generator(i);
+        if (inverse) g = zl::inv(g);
+        F gM = g;
+        for (unsigned i = 0; i < n - lg; i++) gM = zl::sqr(gM);  // h^(+-M)
+        F acc = F::one();
+        for (unsigned j = 0; j < (1u << lg); j++) {
+            for (int w = 0; w < F::N; w++) a.row[j][w] = acc.l[w];
+            acc = zl::mul(acc, gM);
+        }
+    }
+    F* data = reinterpret_cast<F*>(d_data);
+    const uint32_t B = 1u << a.logB;
+    const dim3 grid((B + 255) / 256), block(256);
+    hipStream_t st = ctx->stream;
+    switch (lg) {
+        case 1: hipLaunchKernelGGL((k_ntt_cross<FrP, 1>), grid, block, 0, st, data, a); break;
+        case 2: hipLaunchKernelGGL((k_ntt_cross<FrP, 2>), grid, block, 0, st, data, a); break;
+        case 3: hipLaunchKernelGGL((k_ntt_cross<FrP, 3>), grid, block, 0, st, data, a); break;
+        default: hipLaunchKernelGGL((k_ntt_cross<FrP, 4>), grid, block, 0, st, data, a); break;
+    }
+    ZL_HIP(ctx, hipGetLastError());
+    return ZL_OK;
+}
+int zl_ntt_cross_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags) {
+    if (curve == ZL_BLS12_381) return ntt_cross_t<BLS12_381_Fr>(ctx, curve, d_data, log_n, log_g, rank, flags);
+    if (curve == ZL_BN254) return ntt_cross_t<BN254_Fr>(ctx, curve, d_data, log_n, log_g, rank, flags);
+    return ZL_EINVAL;
 }
 
 int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags) {

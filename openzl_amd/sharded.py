@@ -1,9 +1,17 @@
-"""Multi-GPU MSM: one process per GPU, each owning a contiguous shard of (bases, scalars).
+"""Multi-GPU MSM and NTT.
+
+MSM: one process per GPU, each owning a contiguous shard of (bases, scalars).
 
 Every rank runs the complete local Pippenger down to one un-normalised partial sum (ZL_PARTIAL_WORDS u64 = one XYZZ
 point), the partials are all-gathered (RCCL on GPUs: ncclAllGather of raw u64 words -- elliptic-curve addition cannot
 be an RCCL reduce op, so gather-then-add IS the reduce) and folded identically on every rank by zl_partials_sum.
 Communication is O(100 B) per rank, so scaling is set by the local MSM alone.
+
+NTT: one 2^log_n transform spread over G = 2^log_g ranks is the four-step factorisation with exactly one exchange
+(SURVEY.md §8e): cross-rank G-point transform + twiddle (zl_ntt_cross_dev), all_to_all_single of G chunks of M/G elements
+(RCCL; each rank sends (G-1)/G of its M*32 bytes over xGMI), local M-point transform (zl_ntt_dev).  Coefficients live in the
+"block-column" layout, evaluations in the "cyclic" layout (include/zl_backend.h); pointwise work between transforms (the
+QAP witness map) is layout-agnostic, so a chain of transforms never needs a second exchange.
 """
 from __future__ import annotations
 
@@ -48,3 +56,71 @@ def sharded_msm(local_partial: Callable[[], np.ndarray], curve: int, group: int 
     else:
         parts = part.reshape(1, -1)
     return fold_partials(curve, parts, group)
+
+
+# ---- distributed NTT -------------------------------------------------------------------------------------------
+def block_column_slice(x: np.ndarray, log_g: int, rank: int) -> np.ndarray:
+    """This rank's part of a natural-order vector x (N, 4) in the block-column layout: local[j1*B + c] = x[j1*M + rank*B + c]."""
+    G = 1 << log_g
+    M = x.shape[0] // G
+    B = M // G
+    return np.ascontiguousarray(x.reshape(G, G, B, -1)[:, rank].reshape(M, -1))
+
+
+def cyclic_slice(X: np.ndarray, log_g: int, rank: int) -> np.ndarray:
+    """This rank's part of a natural-order vector X in the cyclic layout: local[k2] = X[rank + G*k2]."""
+    return np.ascontiguousarray(X[rank :: 1 << log_g])
+
+
+class DeviceNttEngine:
+    """The two local legs on a GPU rank: tensors are int64 device tensors of shape (M, 4) holding Fr limbs."""
+
+    def __init__(self, backend, curve: int):
+        self.backend, self.curve = backend, curve
+
+    def cross(self, t, log_n, log_g, rank, flags):
+        self.backend.ntt_cross_dev(self.curve, t.data_ptr(), log_n, log_g, rank, flags)
+
+    def local(self, t, log_m, flags):
+        self.backend.ntt_dev_flags(self.curve, t.data_ptr(), log_m, flags)
+
+    def sync(self):
+        self.backend.sync()
+
+
+def sharded_ntt(engine, local, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = False, group=None):
+    """One rank's part of a 2^log_n-point transform over the ranks of `group` (world size G = 2^log_g, 1 <= log_g <= 4).
+
+    forward: `local` holds this rank's block-column slice of the coefficients; returns its cyclic slice of the evaluations.
+    inverse: `local` holds its cyclic slice of the evaluations; returns its block-column slice of the coefficients.
+    `local` is an int64 tensor (M, 4) (device tensor on GPU ranks; it is overwritten); `engine` supplies the local legs
+    (DeviceNttEngine on GPUs).  `mont`: elements are Montgomery limbs on both sides."""
+    import torch
+    import torch.distributed as dist
+    from .backend import ZL_COSET, ZL_INVERSE, ZL_MONT, ZL_MONT_IN, ZL_MONT_OUT
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    log_g = world.bit_length() - 1
+    if (1 << log_g) != world or not 1 <= log_g <= 4 or 2 * log_g > log_n:
+        raise ValueError("sharded_ntt needs a power-of-two world size in [2, 16] with G*G <= N")
+    M = 1 << (log_n - log_g)
+    if tuple(local.shape) != (M, 4):
+        raise ValueError(f"local slice must have shape ({M}, 4)")
+    base = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0)
+    plain = ZL_INVERSE if inverse else 0
+    out = torch.empty_like(local)
+    if not inverse:
+        engine.cross(local, log_n, log_g, rank, base | (ZL_MONT if mont else ZL_MONT_OUT))
+        engine.sync()
+        dist.all_to_all_single(out.view(-1), local.view(-1), group=group)
+        engine.local(out, log_n - log_g, plain | (ZL_MONT if mont else ZL_MONT_IN))
+    else:
+        engine.local(local, log_n - log_g, plain | (ZL_MONT if mont else ZL_MONT_OUT))
+        engine.sync()
+        dist.all_to_all_single(out.view(-1), local.view(-1), group=group)
+        engine.cross(out, log_n, log_g, rank, base | (ZL_MONT if mont else ZL_MONT_IN))
+    if out.is_cuda:
+        torch.cuda.current_stream(out.device).synchronize()  # the collective ran on torch's stream, the legs on the ctx stream
+    engine.sync()
+    return out

@@ -41,6 +41,12 @@ def backend():
     """The HIP backend through the C ABI.  No fallback: a missing library or GPU is a hard failure under -m gpu."""
     from openzl_amd import Backend
 
+    # torch ships its own HIP runtime: when both live in one process torch must initialise first (bench.py does the same),
+    # otherwise torch.cuda sees no device.  Only the tests that shuffle device tensors (virtual-rank NTT) need torch at all.
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
     b = Backend(0)
     yield b
     b.close()

@@ -149,6 +149,7 @@ def test_msm_skewed_scalars_bls(backend):
     S = ol.random_scalars(curve, n, 52)
     S[: n // 2] = 0
     S[n // 2: 3 * n // 4] = ol.ints_to_limbs([1], 4)[0]
+    S[3 * n // 4: 7 * n // 8] = ol.ints_to_limbs([3], 4)[0]
     h = backend.bases_generate(curve.cid, k)
     got, inf = backend.msm(h, S)
     backend.bases_free(h)
@@ -187,10 +188,59 @@ def test_msm_precomputed_known_discrete_log_2_20(backend):
     k = ol.random_scalars(curve, n, 81)
     S = ol.random_scalars(curve, n, 82)
     S[: n // 4] = 0
-    S[n // 4: n // 2] = ol.ints_to_limbs([1], 4)[0]  # skewed: one giant bucket
+    S[n // 4: n // 2] = ol.ints_to_limbs([1], 4)[0]  # scalar-1 bypass list
+    S[n // 2: 3 * n // 4] = ol.ints_to_limbs([2], 4)[0]  # one giant bucket (two-stage partial merge)
+    S[3 * n // 4: 3 * n // 4 + 5000] = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]  # a big (single-block) bucket, negative digit
     h = backend.bases_generate(curve.cid, k)
     backend.bases_precompute(h, 0)
     got, inf = backend.msm(h, S)
     backend.bases_free(h)
     dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % curve.fr.p
+    assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
+
+
+def _dot_mod_r_u64k(S: np.ndarray, k64: np.ndarray, r: int) -> int:
+    """sum_i S_i * k_i mod r for (n,4) u64 scalars and u64 multipliers, exact, vectorised (32-bit limb products split into halves
+    so that 2^26 of them sum inside a u64)."""
+    s32 = np.ascontiguousarray(S).view(np.uint32).reshape(-1, 8)
+    k32 = np.ascontiguousarray(k64).view(np.uint32).reshape(-1, 2)
+    total = 0
+    for a in range(8):
+        sa = s32[:, a].astype(np.uint64)
+        for b in range(2):
+            prod = sa * k32[:, b].astype(np.uint64)
+            lo = int((prod & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+            hi = int((prod >> np.uint64(32)).sum(dtype=np.uint64))
+            total += (lo + (hi << 32)) << (32 * (a + b))
+    return total % r
+
+
+def test_config4_eight_shards_of_2_23(backend):
+    """BASELINE config 4 on one device: n = 2^26 as 8 contiguous shards of 2^23, each shard's points generated
+    on the device from its own multipliers, one un-normalised partial per shard (what a rank all-gathers), folded by
+    zl_partials_sum -- checked exactly against (sum s_i k_i) G."""
+    import torch
+
+    curve = po.BLS12_381
+    shards, n_s = 8, 1 << 23
+    r = curve.fr.p
+    parts = []
+    dot = 0
+    for g in range(shards):
+        rng = np.random.Generator(np.random.PCG64(9000 + g))
+        k64 = rng.integers(1, 1 << 63, size=n_s, dtype=np.uint64)
+        k = np.zeros((n_s, 4), dtype=np.uint64)
+        k[:, 0] = k64
+        S = ol.random_scalars(curve, n_s, 9100 + g)
+        if g == 3:  # Groth16-witness-like shard: half zeros, a quarter ones
+            S[: n_s // 2] = 0
+            S[n_s // 2: 3 * n_s // 4] = ol.ints_to_limbs([1], 4)[0]
+        h = backend.bases_generate(curve.cid, k)
+        d_s = torch.from_numpy(S.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        parts.append(backend.msm_partial_dev(h, d_s.data_ptr(), n_s))
+        backend.bases_free(h)
+        del d_s
+        dot = (dot + _dot_mod_r_u64k(S, k64, r)) % r
+    got, inf = backend.partials_sum(curve.cid, np.stack(parts))
     assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
