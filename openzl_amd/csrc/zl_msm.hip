@@ -372,6 +372,177 @@ static __global__ void __launch_bounds__(256) k_msm_sub_scatter(const uint16_t* 
     }
     for (uint32_t j = body1 + threadIdx.x; j < hi; j += blockDim.x) emit(part_lo[j], part_idx[j]);
 }
+// ---- LDS-staged partition (levels 1 and 2) ----------------------------------------------------------------------------------------
+// A direct multi-stream scatter issues, per store instruction, up to 64 four-byte writes into different cache lines.  Staging a tile
+// of ZL_PT entries in LDS first (histogram -> bin starts -> scatter inside LDS) turns the global writes into runs of
+// ~ZL_PT/bins consecutive entries per bin, written by consecutive lanes.  BINS <= 256.  Entries of a tile are held in registers
+// between the histogram and the LDS scatter (ZL_PT / 256 per lane).
+#define ZL_PT 4096
+struct PartStage {
+    uint32_t gcur[256];   // global cursor of every bin (this block's private stream)
+    uint32_t hist[256];
+    uint32_t start[257];
+    uint32_t idx[ZL_PT];
+    uint16_t code[ZL_PT];
+};
+// after hist[] is final for the tile: exclusive scan (block of 256 lanes) -> start[]
+__device__ __forceinline__ void zl_part_scan(PartStage& st) {
+    // 256 values, 4 waves: wave-level inclusive scan with shuffles, then wave offsets through LDS
+    __shared__ uint32_t wsum[4];
+    const uint32_t v = st.hist[threadIdx.x];
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if ((threadIdx.x & 63) >= (uint32_t)off) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
+    st.start[threadIdx.x] = base + x - v;
+    if (threadIdx.x == 255) st.start[256] = base + x;
+    __syncthreads();
+}
+// copy the staged tile out: staged position j belongs to bin b(j); destination = gcur[b] + (j - start[b]).  BINFN maps the staged
+// 16-bit code to its bin, OUTFN to the code stored at the next level.
+template <class BinFn, class OutFn>
+__device__ __forceinline__ void zl_part_flush(PartStage& st, uint32_t cnt, uint16_t* __restrict__ out_lo, uint32_t* __restrict__ out_idx, BinFn binfn, OutFn outfn) {
+    for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+        const uint32_t code = st.code[j];
+        const uint32_t b = binfn(code);
+        const uint32_t dest = st.gcur[b] + (j - st.start[b]);
+        out_lo[dest] = (uint16_t)outfn(code);
+        out_idx[dest] = st.idx[j];
+    }
+    __syncthreads();
+    st.gcur[threadIdx.x] += st.hist[threadIdx.x];
+    st.hist[threadIdx.x] = 0;
+    __syncthreads();
+}
+// level 1, block (slice, w): (group id from hi8, code from lo16) -> group-partitioned lists.  The staged 16-bit code cannot carry the
+// 8-bit group id too, so the group rides in a parallel LDS byte array.
+static __global__ void __launch_bounds__(256) k_msm_part_scatter_st(const uint16_t* __restrict__ lo16, const uint8_t* __restrict__ hi8, uint32_t n, uint32_t W,
+                                                                      uint32_t G, uint32_t per_slice, uint32_t nslices, const uint32_t* __restrict__ part_off,
+                                                                      uint32_t table_stride, uint32_t first, uint16_t* __restrict__ out_lo,
+                                                                      uint32_t* __restrict__ out_idx) {
+    __shared__ PartStage st;
+    __shared__ uint8_t grp[ZL_PT];
+    const uint32_t slice = blockIdx.x, w = blockIdx.y;
+    st.gcur[threadIdx.x] = threadIdx.x < G ? part_off[((size_t)threadIdx.x * W + w) * nslices + slice] : 0u;
+    st.hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
+    const uint8_t* hw = hi8 + (size_t)w * n;
+    const uint16_t* lw = lo16 + (size_t)w * n;
+    const uint32_t add = w * table_stride + first;
+    const bool al = ((((size_t)w * n) | lo) & 15) == 0;  // row base and slice start 16-aligned: 16 entries per 16-B load of hi8
+    constexpr int EPT = ZL_PT / 256;                     // 16 entries per lane per tile
+    for (uint32_t t0 = lo; t0 < hi; t0 += ZL_PT) {
+        const uint32_t j0 = t0 + threadIdx.x * EPT;      // this lane's 16 consecutive entries
+        uint32_t g[EPT], code[EPT], rank[EPT];
+        if (al && j0 + EPT <= hi) {
+            const uint4 v = *reinterpret_cast<const uint4*>(hw + j0);
+            const uint4 l0 = *reinterpret_cast<const uint4*>(lw + j0), l1 = *reinterpret_cast<const uint4*>(lw + j0 + 8);
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t lws[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                g[k] = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                code[k] = (lws[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                const bool ok = j0 + k < hi;
+                g[k] = ok ? hw[j0 + k] : 0xFFu;
+                code[k] = ok ? lw[j0 + k] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; k++) rank[k] = g[k] != 0xFFu ? atomicAdd(&st.hist[g[k]], 1u) : 0u;
+        __syncthreads();
+        zl_part_scan(st);
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            if (g[k] != 0xFFu) {
+                const uint32_t pos = st.start[g[k]] + rank[k];
+                st.code[pos] = (uint16_t)code[k];
+                st.idx[pos] = add + j0 + k;
+                grp[pos] = (uint8_t)g[k];
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = st.start[256];
+        for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+            const uint32_t b = grp[j];
+            const uint32_t dest = st.gcur[b] + (j - st.start[b]);
+            out_lo[dest] = st.code[j];
+            out_idx[dest] = st.idx[j];
+        }
+        __syncthreads();
+        st.gcur[threadIdx.x] += st.hist[threadIdx.x];
+        st.hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+// level 2, block (slice, g): sub-group id = (code >> 8) & 127 -> sub-group-partitioned lists (fine bucket + sign kept in the code)
+static __global__ void __launch_bounds__(256) k_msm_sub_scatter_st(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_idx,
+                                                                     const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
+                                                                     const uint32_t* __restrict__ total, uint32_t fslices, const uint32_t* __restrict__ sub_off,
+                                                                     uint16_t* __restrict__ out_lo, uint32_t* __restrict__ out_idx) {
+    __shared__ PartStage st;
+    const uint32_t slice = blockIdx.x, g = blockIdx.y;
+    st.gcur[threadIdx.x] = threadIdx.x < 128 ? sub_off[((size_t)g * 128 + threadIdx.x) * fslices + slice] : 0u;
+    st.hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t s, e;
+    zl_group_range(part_off, g, G, stride, *total, s, e);
+    const uint32_t per = (e - s + fslices - 1) / fslices;
+    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
+    constexpr int EPT = ZL_PT / 256;  // 16 entries per lane per tile, as two 8-entry groups aligned to 8 (16-B loads of the u16 codes)
+    const uint32_t a0 = lo & ~7u;     // tiles start on an 8-aligned index; entries outside [lo, hi) are masked
+    for (uint32_t t0 = a0; t0 < hi; t0 += ZL_PT) {
+        const uint32_t j0 = t0 + threadIdx.x * EPT;
+        uint32_t code[EPT], idx[EPT], rank[EPT];
+        bool ok[EPT];
+        if (j0 >= lo && j0 + EPT <= hi) {
+            const uint4 c0 = *reinterpret_cast<const uint4*>(part_lo + j0), c1 = *reinterpret_cast<const uint4*>(part_lo + j0 + 8);
+            const uint4* iv = reinterpret_cast<const uint4*>(part_idx + j0);
+            const uint4 i0 = iv[0], i1 = iv[1], i2 = iv[2], i3 = iv[3];
+            const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const uint32_t iw[16] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w};
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                code[k] = (cw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                idx[k] = iw[k];
+                ok[k] = true;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                ok[k] = j0 + k >= lo && j0 + k < hi;
+                code[k] = ok[k] ? part_lo[j0 + k] : 0u;
+                idx[k] = ok[k] ? part_idx[j0 + k] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; k++) rank[k] = ok[k] ? atomicAdd(&st.hist[(code[k] >> 8) & 127u], 1u) : 0u;
+        __syncthreads();
+        zl_part_scan(st);
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            if (ok[k]) {
+                const uint32_t pos = st.start[(code[k] >> 8) & 127u] + rank[k];
+                st.code[pos] = (uint16_t)code[k];
+                st.idx[pos] = idx[k];
+            }
+        }
+        __syncthreads();
+        zl_part_flush(st, st.start[256], out_lo, out_idx, [](uint32_t c) { return (c >> 8) & 127u; },
+                      [](uint32_t c) { return (c & 0xFFu) | (c & 0x8000u); });
+    }
+}
 // block per sub-group: histogram of its 256 buckets -> counts[sg*256 + bin]  (sg*256 + bin IS the bucket index)
 static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ sub_off, uint32_t SG,
                                                                 uint32_t fslices, const uint32_t* __restrict__ total, uint32_t* __restrict__ counts) {
@@ -803,9 +974,11 @@ static int zl_pick_window(size_t n, int sc_bits) {
 
 static int zl_pick_window_precomp(size_t n, int sc_bits) {
     // merged windows: n*W mixed adds + ONE bucket set of 2^(c-1) buckets (merge + reduce ~6 add-equivalents per bucket)
+    // measured at 2^20: c = 16 and c = 20 tie (4.9 ms), 17..19 are slower (half-filled staging blocks); below 2^21 keep one group
+    if (n < ((size_t)1 << 21)) return 16;
     double best = 1e300;
     int best_c = 16;
-    for (int c = 16; c <= 23; c++) {
+    for (int c = 20; c <= 23; c++) {
         int W = (sc_bits + 1 + c - 1) / c;
         double cost = (double)n * W + 6.0 * (double)(1u << (c - 1));
         if (cost < best) { best = cost; best_c = c; }
@@ -834,7 +1007,8 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         const uint32_t NB = (uint32_t)NB64;
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
-        while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
+        if (getenv("ZL_TUNE_CHUNK")) ZL_CHUNK = (uint32_t)std::max(8, atoi(getenv("ZL_TUNE_CHUNK")));
+        while (!getenv("ZL_TUNE_CHUNK") && ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         uint32_t ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (uint32_t)ZL_SEG_DEFAULT;
         if (getenv("ZL_TUNE_SEG")) ZL_SEG = (uint32_t)std::max(1, atoi(getenv("ZL_TUNE_SEG")));
@@ -920,7 +1094,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
             hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
-            hipLaunchKernelGGL(k_msm_part_scatter, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
+            hipLaunchKernelGGL(k_msm_part_scatter_st, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
                                (uint32_t)bs.n, (uint32_t)first, d_part_lo, d_part_idx);
             const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
             // level 2: 128 sub-groups (256 buckets each) per group; level 3: LDS-staged sort per sub-group
@@ -942,7 +1116,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_scan_block_sums, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2);
             hipLaunchKernelGGL(k_scan_apply, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2, d_off2, d_c2);
-            hipLaunchKernelGGL(k_msm_sub_scatter, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
+            hipLaunchKernelGGL(k_msm_sub_scatter_st, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
                                d_idx2);
             hipLaunchKernelGGL(k_msm_fine_hist, dim3(SG), dim3(256), 0, st, d_lo2, d_off2, SG, fsl, d_off2 + P2, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
