@@ -567,7 +567,7 @@ static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __
 // block per sub-group: sort the sub-group's entries by bucket inside LDS (cursors = bucket offsets relative to the sub-group),
 // then copy the staged run to the entry list with consecutive lanes writing consecutive words.  Oversized sub-groups (skewed
 // scalars) fall back to direct scattered stores.
-static __global__ void __launch_bounds__(512) k_msm_fine_sort(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ idx2,
+static __global__ void __launch_bounds__(1024) k_msm_fine_sort(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ idx2,
                                                                 const uint32_t* __restrict__ sub_off, uint32_t SG, uint32_t fslices,
                                                                 const uint32_t* __restrict__ total, const uint32_t* __restrict__ offsets, uint32_t cap,
                                                                 uint32_t* __restrict__ entries) {
@@ -1128,7 +1128,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr2 = true;
             }
-            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(512), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
+            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(getenv("ZL_TUNE_FS") ? atoi(getenv("ZL_TUNE_FS")) : 1024), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
                                d_entries);
         } else if (c <= 16) {
             // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
