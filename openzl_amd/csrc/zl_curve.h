@@ -30,6 +30,7 @@ template <class P> ZL_HD Fp2<P> neg(const Fp2<P>& a) { return Fp2<P>{neg(a.c0), 
 template <int J, class P> ZL_HD Fp2<P> subk(const Fp2<P>& a, const Fp2<P>& b) { return sub(a, b); }
 template <int J, class P> ZL_HD Fp2<P> negk(const Fp2<P>& a) { return neg(a); }
 template <class P> ZL_HD Fp2<P> wred(const Fp2<P>& a) { return a; }
+template <class P> ZL_HD Fp<P> muladd(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) { return add(mul(a, b), mul(c, d)); }
 template <class P> ZL_HD Fp2<P> canon(const Fp2<P>& a) { return a; }
 template <class P> ZL_HD Fp2<P> mul(const Fp2<P>& a, const Fp2<P>& b) {
     // Karatsuba: 3 base multiplications
@@ -37,6 +38,7 @@ template <class P> ZL_HD Fp2<P> mul(const Fp2<P>& a, const Fp2<P>& b) {
     Fp<P> s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     return Fp2<P>{sub(v0, v1), sub(sub(s, v0), v1)};
 }
+template <class P> ZL_HD Fp2<P> muladd(const Fp2<P>& a, const Fp2<P>& b, const Fp2<P>& c, const Fp2<P>& d) { return add(mul(a, b), mul(c, d)); }
 template <class P> ZL_HD Fp2<P> sqr(const Fp2<P>& a) {
     // (c0+c1)(c0-c1) + 2 c0 c1 u
     Fp<P> t = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
@@ -93,7 +95,7 @@ ZL_HD XYZZ<F> dbl_affine(const F& x, const F& y) {          // x, y < 8
     const F m = add(dbl(xx), xx);                             // < 6
     XYZZ<F> r;
     r.x = subk<2>(sqr(m), dbl(s));                            // 36 -> 2; dbl(s) < 4 -> < 6
-    r.y = subk<1>(mul(m, subk<3>(s, r.x)), mul(w, y));        // s - x3 < 10; 60 -> 2; w*y: 16 -> 2 -> < 4
+    r.y = muladd(m, subk<3>(s, r.x), w, negk<3>(y));          // m (s - x3) - w y, one reduction: 6*10 + 2*8 -> < 2
     r.zz = v;
     r.zzz = w;
     return r;  // y == 0 -> zz == 0 -> infinity (does not occur on these curves)
@@ -107,7 +109,7 @@ ZL_HD void dbl_inplace(XYZZ<F>& p) {
     const F xx = sqr(p.x);
     const F m = add(dbl(xx), xx);                             // < 6
     const F x3 = subk<2>(sqr(m), dbl(s));                     // < 6
-    p.y = subk<1>(mul(m, subk<3>(s, x3)), mul(w, p.y));       // < 4
+    p.y = muladd(m, subk<3>(s, x3), w, negk<3>(p.y));         // 60 + 16 -> < 2
     p.x = x3;
     p.zz = mul(v, p.zz);                                      // 16 -> < 2
     p.zzz = mul(w, p.zzz);
@@ -129,7 +131,7 @@ ZL_HD void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
     }
     const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2
     const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q));       // (2 + 2) + 4 -> < 8
-    p.y = subk<1>(mul(r, subk<3>(q, x3)), mul(p.y, ppp));     // q - x3 < 10; 100 -> 2; 16 -> 2 -> < 4
+    p.y = muladd(r, subk<3>(q, x3), negk<3>(p.y), ppp);       // r (q - x3) - y1 ppp, one reduction: 10*10 + 8*2 -> < 2
     p.x = x3;
     p.zz = mul(p.zz, pp);                                     // < 2
     p.zzz = mul(p.zzz, ppp);
@@ -149,7 +151,7 @@ ZL_HD void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
     }
     const F pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(u1, pp);  // < 2
     const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q_));      // < 8
-    p.y = subk<1>(mul(r, subk<3>(q_, x3)), mul(s1, ppp));     // < 4
+    p.y = muladd(r, subk<3>(q_, x3), negk<1>(s1), ppp);       // 4*10 + 2*2 -> < 2
     p.x = x3;
     p.zz = mul(mul(p.zz, q.zz), pp);
     p.zzz = mul(mul(p.zzz, q.zzz), ppp);

@@ -8,6 +8,7 @@
 //     mul(a, b)      needs B(a) * B(b) <= 2500  (a*b < 2^392 q)          -> result < 2q
 //     add(a, b)      -> B(a) + B(b);    dbl(a) -> 2 B(a)
 //     subk<J>(a, b)  needs B(b) <= 2^J                                     -> B(a) + 2^J      (a - b + 2^J q, limb-wise non-negative)
+//     muladd(a,b,c,d) needs B(a) B(b) + B(c) B(d) <= 2500                 -> result < 2q  (a*b + c*d, one shared reduction)
 //     wred(a)        needs B(a) <= 2000                                    -> < 4q            (top-limb quotient estimate)
 //     is_zero(a)     needs B(a) <= 2000; exact test of a == 0 (mod q)
 // Every point routine of zl_curve.h takes coordinates < 8q and returns coordinates < 8q; its comments carry the bound of every
@@ -119,6 +120,54 @@ ZL_HD Fp28<A, B> mul_body28(const Fp28<A, B>& a, const Fp28<A, B>& b) {
         acc >>= 28;
     }
     return r;
+}
+// (a*b + c*d)/2^392 with ONE reduction: the two product scans share the column accumulators (<= 28 + 14 products of < 2^56 per
+// column), so a difference of products costs 588 mads instead of 784.  < 2q when a*b + c*d < 2^392 q.
+template <class A, class B>
+ZL_HD Fp28<A, B> muladd_body28(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, B>& c, const Fp28<A, B>& d) {
+    constexpr int L = A::L;
+    uint32_t m[L];
+    Fp28<A, B> r = a;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        m[k] = ((uint32_t)acc * A::INV) & 0xFFFFFFFu;
+        acc += (uint64_t)m[k] * A::mod(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        r.l[k - L] = (uint32_t)acc & 0xFFFFFFFu;
+        acc >>= 28;
+    }
+    return r;
+}
+template <class A, class B>
+ZL_NOINLINE_HD Fp28<A, B> muladd_call28(Fp28<A, B> a, Fp28<A, B> b, Fp28<A, B> c, Fp28<A, B> d) {
+    return muladd_body28(a, b, c, d);
+}
+// a*b + c*d (Montgomery), needs B(a) B(b) + B(c) B(d) <= 2500 -> < 2q
+template <class A, class B>
+ZL_HD Fp28<A, B> muladd(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, B>& c, const Fp28<A, B>& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_INLINE_MUL28)
+    return muladd_body28(a, b, c, d);
+#else
+    return muladd_call28<A, B>(a, b, c, d);
+#endif
 }
 template <class A, class B>
 ZL_NOINLINE_HD Fp28<A, B> mul_call28(Fp28<A, B> a, Fp28<A, B> b) {
