@@ -92,7 +92,7 @@ int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, s
 int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf);
 /* multi-GPU building block: the un-normalised partial sum of this shard (opaque, ZL_PARTIAL_WORDS u64s), to
  * be all-gathered (RCCL/ncclUint64) and folded with zl_partials_sum on any rank. */
-#define ZL_PARTIAL_WORDS 48
+#define ZL_PARTIAL_WORDS 64
 int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial);
 int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
 /* wrap a canonical affine point (all-zero = infinity) as a partial, e.g. to fold an extra term into zl_partials_sum */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libzl_backend.so")
 ZL_BLS12_381, ZL_BN254 = 1, 2
 ZL_G1, ZL_G2 = 1, 2
 ZL_MONT, ZL_COSET, ZL_INVERSE, ZL_CHECK, ZL_MONT_IN, ZL_MONT_OUT = 1, 2, 4, 8, 16, 32
-ZL_PARTIAL_WORDS = 48
+ZL_PARTIAL_WORDS = 64
 CURVES = {"bls12_381": ZL_BLS12_381, "bn254": ZL_BN254}
 FQ_LIMBS = {ZL_BLS12_381: 6, ZL_BN254: 4}
 

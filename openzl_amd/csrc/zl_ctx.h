@@ -41,25 +41,26 @@ struct BnG1 {
     ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
     ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
 };
-template <class C2, class FqP_, class FrP_, int SCB, int FQ64_>
+template <class C2, class FqP_, class FrP_, class F_, int SCB, int FQ64_>
 struct G2Cfg {
     using FqP = FqP_;
     using FrP = FrP_;
-    using F = Fp2<FqP>;
+    using F = F_;
     static constexpr int SC_BITS = SCB;
     static constexpr int FQ64 = FQ64_;
     static constexpr int COORDS = 2;
-    ZL_HD static F mk(uint32_t (*f0)(int), uint32_t (*f1)(int)) {
-        F r;
-        for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = f0(i); r.c1.l[i] = f1(i); }
-        return r;
+    ZL_HD static F mk(uint32_t (*f0)(int), uint32_t (*f1)(int)) {  // two components as arkworks' Montgomery words
+        uint32_t w[2 * FqP::N];
+        for (int i = 0; i < FqP::N; i++) { w[i] = f0(i); w[FqP::N + i] = f1(i); }
+        return FieldIO<F>::load_mont32(w);
     }
-    ZL_HD static F gen_x() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::gx0(i); r.c1.l[i] = C2::gx1(i); } return r; }
-    ZL_HD static F gen_y() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::gy0(i); r.c1.l[i] = C2::gy1(i); } return r; }
-    ZL_HD static F coeff_b() { F r; for (int i = 0; i < FqP::N; i++) { r.c0.l[i] = C2::b0(i); r.c1.l[i] = C2::b1(i); } return r; }
+    ZL_HD static F gen_x() { return mk(C2::gx0, C2::gx1); }
+    ZL_HD static F gen_y() { return mk(C2::gy0, C2::gy1); }
+    ZL_HD static F coeff_b() { return mk(C2::b0, C2::b1); }
 };
-using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, 255, 6>;
-using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, 254, 4>;
+// BLS12-381 G2 on the lazily reduced 28-bit field (Fq2 products as dual scans, zl_field28.h); BN254 G2 on 32-bit limbs
+using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2L<Fp28<BLS12_381_Fq28, BLS12_381_Fq>>, 255, 6>;
+using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2<BN254_Fq>, 254, 4>;
 
 // ---- context ----------------------------------------------------------------------------------------------
 struct zl_bases {

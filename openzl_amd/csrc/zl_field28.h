@@ -156,6 +156,46 @@ ZL_HD Fp28<A, B> muladd_body28(const Fp28<A, B>& a, const Fp28<A, B>& b, const F
     }
     return r;
 }
+// (a*b + c*d + e*f + g*h)/2^392 with one reduction (an Fq2 component of a sum of two Fq2 products): 784 + 196 mads.
+// Columns hold <= 56 + 14 products of < 2^56 (top limbs slightly wider): < 2^63.  < 2q when the four products sum below 2^392 q.
+template <class A, class B>
+ZL_HD Fp28<A, B> muladd4_body28(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, B>& c, const Fp28<A, B>& d, const Fp28<A, B>& e,
+                                const Fp28<A, B>& f, const Fp28<A, B>& g, const Fp28<A, B>& h) {
+    constexpr int L = A::L;
+    uint32_t m[L];
+    Fp28<A, B> r = a;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+            acc += (uint64_t)e.l[i] * f.l[k - i];
+            acc += (uint64_t)g.l[i] * h.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        m[k] = ((uint32_t)acc * A::INV) & 0xFFFFFFFu;
+        acc += (uint64_t)m[k] * A::mod(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+            acc += (uint64_t)e.l[i] * f.l[k - i];
+            acc += (uint64_t)g.l[i] * h.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * A::mod(k - i);
+        r.l[k - L] = (uint32_t)acc & 0xFFFFFFFu;
+        acc >>= 28;
+    }
+    return r;
+}
 template <class A, class B>
 ZL_NOINLINE_HD Fp28<A, B> muladd_call28(Fp28<A, B> a, Fp28<A, B> b, Fp28<A, B> c, Fp28<A, B> d) {
     return muladd_body28(a, b, c, d);
@@ -295,6 +335,47 @@ ZL_HD void unpack28(uint32_t* w, const Fp28<A, B>& a) {  // limbs < 2^28, value 
 ZL_CONST28(const28_r2, r2)
 ZL_CONST28(const28_from_m32, from_m32)
 #undef ZL_CONST28
+}  // namespace zl
+
+// ---- quadratic extension helpers: Fq2 = Fq[u]/(u^2 + 1) on two Fp28 components --------------------------------------------------
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u: each component is ONE dual product scan (muladd_body28) with the
+// subtraction done on a biased operand, so an Fq2 product is 1176 mads with two reductions and returns components < 2q, i.e. the same
+// contract as the base field: the point formulas of zl_curve.h apply unchanged.  Operand components must be < 16q.
+// On the device the three routines are real calls (the Fq2 point code would not fit the instruction cache inlined: a mixed
+// addition is ~10.6 k mads); arguments travel as scalar words so that they stay in VGPRs (first 32) / the stack, never in a struct.
+#define ZL_P14(x) uint32_t x##0, uint32_t x##1, uint32_t x##2, uint32_t x##3, uint32_t x##4, uint32_t x##5, uint32_t x##6, uint32_t x##7, uint32_t x##8, uint32_t x##9, uint32_t x##10, uint32_t x##11, uint32_t x##12, uint32_t x##13
+#define ZL_A14(v) v.l[0], v.l[1], v.l[2], v.l[3], v.l[4], v.l[5], v.l[6], v.l[7], v.l[8], v.l[9], v.l[10], v.l[11], v.l[12], v.l[13]
+#define ZL_S14(v, x) v.l[0] = x##0; v.l[1] = x##1; v.l[2] = x##2; v.l[3] = x##3; v.l[4] = x##4; v.l[5] = x##5; v.l[6] = x##6; v.l[7] = x##7; v.l[8] = x##8; v.l[9] = x##9; v.l[10] = x##10; v.l[11] = x##11; v.l[12] = x##12; v.l[13] = x##13
+struct Pair28 { uint32_t l[28]; };  // two 14-limb components, returned in registers
+namespace zl {
+template <class A, class B>
+ZL_HD Pair28 pair28(const Fp28<A, B>& c0, const Fp28<A, B>& c1) {
+    Pair28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) { r.l[i] = c0.l[i]; r.l[14 + i] = c1.l[i]; }
+    return r;
+}
+template <class A, class B>
+ZL_HD void unpair28(const Pair28& p, Fp28<A, B>& c0, Fp28<A, B>& c1) {
+    c0 = Fp28<A, B>::zero();
+    c1 = Fp28<A, B>::zero();
+#pragma unroll
+    for (int i = 0; i < 14; i++) { c0.l[i] = p.l[i]; c1.l[i] = p.l[14 + i]; }
+}
+template <class A, class B>
+ZL_NOINLINE_HD Pair28 fq2_mul_call28(ZL_P14(wa), ZL_P14(wb), ZL_P14(wc), ZL_P14(wd)) {  // (a + b u)(c + d u), components < 16q
+    static_assert(A::L == 14, "Fq2 helpers are written for 14 limbs");
+    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
+    ZL_S14(a0, wa); ZL_S14(a1, wb); ZL_S14(b0, wc); ZL_S14(b1, wd);
+    const Fp28<A, B> nb1 = negk<4>(b1);
+    return pair28(muladd_body28(a0, b0, a1, nb1), muladd_body28(a0, b1, a1, b0));
+}
+template <class A, class B>
+ZL_NOINLINE_HD Pair28 fq2_sqr_call28(ZL_P14(wa), ZL_P14(wb)) {  // (a + b u)^2 = (a + b)(a - b) + 2ab u, components < 16q
+    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0;
+    ZL_S14(a0, wa); ZL_S14(a1, wb);
+    return pair28(mul_body28(add(a0, a1), subk<4>(a0, a1)), mul_body28(dbl(a0), a1));
+}
 }  // namespace zl
 
 // ---- uniform conversion API for both field representations (used at every memory / ABI boundary) -----------------------------

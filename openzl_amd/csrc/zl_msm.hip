@@ -263,47 +263,6 @@ static __global__ void __launch_bounds__(256) k_msm_part_hist(const uint8_t* __r
     __syncthreads();
     if (threadIdx.x < G) counts[((size_t)threadIdx.x * W + w) * nslices + slice] = hist[threadIdx.x];
 }
-// block (slice, w): scatter (fine code, table index) into the group-partitioned lists
-static __global__ void __launch_bounds__(256) k_msm_part_scatter(const uint16_t* __restrict__ lo16, const uint8_t* __restrict__ hi8, uint32_t n, uint32_t W,
-                                                                   uint32_t G, uint32_t per_slice, uint32_t nslices, const uint32_t* __restrict__ part_off,
-                                                                   uint32_t table_stride, uint32_t first, uint16_t* __restrict__ out_lo,
-                                                                   uint32_t* __restrict__ out_idx) {
-    __shared__ uint32_t cur[256];
-    const uint32_t slice = blockIdx.x, w = blockIdx.y;
-    if (threadIdx.x < G) cur[threadIdx.x] = part_off[((size_t)threadIdx.x * W + w) * nslices + slice];
-    __syncthreads();
-    const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
-    const uint8_t* hw = hi8 + (size_t)w * n;
-    const uint16_t* lw = lo16 + (size_t)w * n;
-    const uint32_t add = w * table_stride + first;
-    const bool al = ((((size_t)w * n) | lo) & 15) == 0;
-    const uint32_t body1 = al ? lo + ((hi - lo) & ~15u) : lo;
-    const uint4* hv = reinterpret_cast<const uint4*>(hw);
-    const uint4* lv = reinterpret_cast<const uint4*>(lw);
-    for (uint32_t i16 = lo / 16 + threadIdx.x; i16 < body1 / 16; i16 += blockDim.x) {
-        const uint4 v = hv[i16];
-        const uint4 l0 = lv[2 * (size_t)i16], l1 = lv[2 * (size_t)i16 + 1];
-        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t lws[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t g = (words[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            if (g != 0xFFu) {
-                const uint32_t pos = atomicAdd(&cur[g], 1u);
-                out_lo[pos] = (uint16_t)(lws[k >> 1] >> ((k & 1) * 16));
-                out_idx[pos] = add + i16 * 16 + k;
-            }
-        }
-    }
-    for (uint32_t i = body1 + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t g = hw[i];
-        if (g != 0xFFu) {
-            const uint32_t pos = atomicAdd(&cur[g], 1u);
-            out_lo[pos] = lw[i];
-            out_idx[pos] = add + i;
-        }
-    }
-}
 // group range [s, e) from the scanned partition counters
 __device__ __forceinline__ void zl_group_range(const uint32_t* __restrict__ part_off, uint32_t g, uint32_t G, uint32_t stride, uint32_t E, uint32_t& s,
                                                uint32_t& e) {
@@ -340,37 +299,6 @@ static __global__ void __launch_bounds__(256) k_msm_sub_hist(const uint16_t* __r
     for (uint32_t j = body1 + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[(part_lo[j] >> 8) & 127u], 1u);
     __syncthreads();
     if (threadIdx.x < 128) counts[((size_t)g * 128 + threadIdx.x) * fslices + slice] = hist[threadIdx.x];
-}
-static __global__ void __launch_bounds__(256) k_msm_sub_scatter(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_idx,
-                                                                  const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
-                                                                  const uint32_t* __restrict__ total, uint32_t fslices, const uint32_t* __restrict__ sub_off,
-                                                                  uint16_t* __restrict__ out_lo, uint32_t* __restrict__ out_idx) {
-    __shared__ uint32_t cur[128];
-    const uint32_t slice = blockIdx.x, g = blockIdx.y;
-    if (threadIdx.x < 128) cur[threadIdx.x] = sub_off[((size_t)g * 128 + threadIdx.x) * fslices + slice];
-    __syncthreads();
-    uint32_t s, e;
-    zl_group_range(part_off, g, G, stride, *total, s, e);
-    const uint32_t per = (e - s + fslices - 1) / fslices;
-    const uint32_t lo = min(e, s + slice * per), hi = min(e, lo + per);
-    auto emit = [&](uint32_t code, uint32_t idx) {
-        const uint32_t pos = atomicAdd(&cur[(code >> 8) & 127u], 1u);
-        out_lo[pos] = (uint16_t)((code & 0xFFu) | (code & 0x8000u));  // fine bucket (8 bits) + sign
-        out_idx[pos] = idx;
-    };
-    const uint32_t body0 = min(hi, (lo + 7u) & ~7u), body1 = max(body0, hi & ~7u);
-    for (uint32_t j = lo + threadIdx.x; j < body0; j += blockDim.x) emit(part_lo[j], part_idx[j]);
-    const uint4* dv = reinterpret_cast<const uint4*>(part_lo);
-    const uint4* iv = reinterpret_cast<const uint4*>(part_idx);
-    for (uint32_t j8 = body0 / 8 + threadIdx.x; j8 < body1 / 8; j8 += blockDim.x) {
-        const uint4 v = dv[j8];
-        const uint4 i0 = iv[2 * (size_t)j8], i1 = iv[2 * (size_t)j8 + 1];
-        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t idxs[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-#pragma unroll
-        for (int k = 0; k < 8; k++) emit((words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, idxs[k]);
-    }
-    for (uint32_t j = body1 + threadIdx.x; j < hi; j += blockDim.x) emit(part_lo[j], part_idx[j]);
 }
 // ---- LDS-staged partition (levels 1 and 2) ----------------------------------------------------------------------------------------
 // A direct multi-stream scatter issues, per store instruction, up to 64 four-byte writes into different cache lines.  Staging a tile
@@ -959,6 +887,11 @@ __global__ void __launch_bounds__(64) k_bases_precompute(const Affine<typename G
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
+// developer tuning knobs (profiling sweeps only; unset in production): ZL_TUNE_CHUNK, ZL_TUNE_SEG, ZL_TUNE_FS, ZL_TUNE_RANGES
+static int zl_tune(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 static int zl_pick_window(size_t n, int sc_bits) {
     // accumulate: n mixed adds per window; per-bucket overhead (merge + segmented reduce) measured at ~2 add-equivalents
     // (tools/msm_sweep.py: c = 16 wins from 2^18 up, c = 13 at 2^16).  c <= 16 keeps the LDS counting sort.
@@ -1007,20 +940,20 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         const uint32_t NB = (uint32_t)NB64;
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
-        if (getenv("ZL_TUNE_CHUNK")) ZL_CHUNK = (uint32_t)std::max(8, atoi(getenv("ZL_TUNE_CHUNK")));
-        while (!getenv("ZL_TUNE_CHUNK") && ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
+        while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
+        ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         // segment length of the bucket reduction: long for the big merged set (amortises the k0 multiple), short otherwise so that
         // the kernel has at least one wave per SIMD (measured: 2^20 plain 4.18 -> 4.04 ms, 2^16 1.81 -> 1.49 ms)
         uint32_t ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (NB >= (1u << 17) ? 8u : 4u);
-        if (getenv("ZL_TUNE_SEG")) ZL_SEG = (uint32_t)std::max(1, atoi(getenv("ZL_TUNE_SEG")));
+        ZL_SEG = (uint32_t)std::max(1, zl_tune("ZL_TUNE_SEG", (int)ZL_SEG));
         const uint32_t segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
         const uint32_t total_segs = segs_per_set * SETS;
         const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
         const uint32_t max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
         const uint32_t max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         // tree over the segment results: sets with many segments are summed in two stages
-        const uint32_t SUMW = 2048;
+        const uint32_t SUMW = 256;
         const uint32_t stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
 
         uint32_t *d_counts, *d_offsets, *d_cursor, *d_entries, *d_small;
@@ -1061,12 +994,9 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 12, st));  // big, ones, giant counts
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_done = true;
-        }
+        // per call, not once per process: the attribute is per device and a process may own several contexts
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (pre) {
             // ---- two-level counting sort over the merged bucket set ------------------------------------------------------
             if (c < 16) return ZL_EINVAL;
@@ -1125,12 +1055,8 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
             const uint32_t cap = 36 * 1024;  // staged entries per block: 144 KiB + 1 KiB of cursors (1 block per CU); typical sub-group: n*W/SG
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr2 = true;
-            }
-            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(getenv("ZL_TUNE_FS") ? atoi(getenv("ZL_TUNE_FS")) : 1024), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(zl_tune("ZL_TUNE_FS", 1024)), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
                                d_entries);
         } else if (c <= 16) {
             // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
@@ -1152,7 +1078,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
             uint32_t ranges = 1;
             while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
-            if (getenv("ZL_TUNE_RANGES")) ranges = std::max(1, atoi(getenv("ZL_TUNE_RANGES")));
+            ranges = (uint32_t)std::max(1, zl_tune("ZL_TUNE_RANGES", (int)ranges));
             const uint32_t RB = (H + ranges - 1) / ranges;
             hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {

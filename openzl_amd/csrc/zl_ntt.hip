@@ -301,12 +301,9 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     const F* small = reinterpret_cast<const F*>(tw->d_small);
     F ninv = zl::inv(zl::from_u64<FrP>(1ull << n));
     hipStream_t st = ctx->stream;
-    static bool attr_done = false;
-    if (!attr_done) {  // tiles + tables can exceed the 64 KiB default dynamic-LDS limit (gfx950 has 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    // tiles + tables can exceed the 64 KiB default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so set per call
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     uint32_t S_prev = 0;
     for (uint32_t p = 1; p <= pl.P; p++) {
