@@ -37,11 +37,8 @@ def _digest(paths, extra="") -> str:
 def _units():
     units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
     for g in GROUPS:
-        # Fq2 accumulators: 1 wave/SIMD register budget avoids scratch spills.  BLS12-381 G2 (28-bit lazy field) inlines its Fq2 dual
-        # product scans (-13 % on the whole MSM vs out-of-line calls with 56 argument words); BN254 G2 keeps the called 32-bit multiplier.
+        # Fq2 accumulators: 1 wave/SIMD register budget avoids scratch spills
         extra = ["-DZL_ACC_WAVES=1"] if g.endswith("G2") else []
-        if g == "BlsG2":
-            extra = extra + ["-DZL_INLINE_FQ2"]
         # G1 device code inlines the multiplier: -4.5 % on the accumulate kernel vs the out-of-line call (host code keeps the call).
         if g.endswith("G1"):
             extra = extra + ["-DZL_INLINE_MUL_DEVICE"]

@@ -63,63 +63,72 @@ struct FieldIO<Fp2<P>> {
 
 // ---- Fq2 over the lazily reduced 28-bit base field (BLS12-381 G2) ------------------------------------------------------------------
 // Same contracts as Fp28 component-wise (zl_field28.h): mul / sqr return components < 2q, add / subk<J> track bounds, so the point
-// formulas below need no second set of annotations.
-template <class B>
-struct Fp2L {
+// formulas below need no second set of annotations.  Two flavours with one memory layout: INL = false calls the out-of-line Fq2
+// product routines (small code: every kernel but one), INL = true inlines the product scans -- used by the bucket accumulation
+// only, where it is worth 2 ms per 2^20 MSM; inlining it everywhere costs 6 minutes of compile time for no measurable gain.
+template <class B, bool INL>
+struct Fp2LT {
     B c0, c1;
-    ZL_HD static Fp2L zero() { return Fp2L{B::zero(), B::zero()}; }
-    ZL_HD static Fp2L one() { return Fp2L{B::one(), B::zero()}; }
+    ZL_HD static Fp2LT zero() { return Fp2LT{B::zero(), B::zero()}; }
+    ZL_HD static Fp2LT one() { return Fp2LT{B::one(), B::zero()}; }
     ZL_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
     ZL_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
-    ZL_HD bool operator==(const Fp2L& o) const { return c0 == o.c0 && c1 == o.c1; }
-    ZL_HD bool operator!=(const Fp2L& o) const { return !(*this == o); }
+    ZL_HD bool operator==(const Fp2LT& o) const { return c0 == o.c0 && c1 == o.c1; }
+    ZL_HD bool operator!=(const Fp2LT& o) const { return !(*this == o); }
 };
+template <class B> using Fp2L = Fp2LT<B, false>;
+// the flavour a hot kernel computes in (identity for every other field)
+template <class F> struct HotField { using type = F; };
+template <class B> struct HotField<Fp2LT<B, false>> { using type = Fp2LT<B, true>; };
 namespace zl {
-template <class B> ZL_HD Fp2L<B> add(const Fp2L<B>& a, const Fp2L<B>& b) { return Fp2L<B>{add(a.c0, b.c0), add(a.c1, b.c1)}; }
-template <class B> ZL_HD Fp2L<B> dbl(const Fp2L<B>& a) { return Fp2L<B>{dbl(a.c0), dbl(a.c1)}; }
-template <int J, class B> ZL_HD Fp2L<B> subk(const Fp2L<B>& a, const Fp2L<B>& b) { return Fp2L<B>{subk<J>(a.c0, b.c0), subk<J>(a.c1, b.c1)}; }
-template <int J, class B> ZL_HD Fp2L<B> negk(const Fp2L<B>& a) { return Fp2L<B>{negk<J>(a.c0), negk<J>(a.c1)}; }
-template <class B> ZL_HD Fp2L<B> sub(const Fp2L<B>& a, const Fp2L<B>& b) { return subk<4>(a, b); }
-template <class B> ZL_HD Fp2L<B> neg(const Fp2L<B>& a) { return negk<4>(a); }
-template <class B> ZL_HD Fp2L<B> wred(const Fp2L<B>& a) { return Fp2L<B>{wred(a.c0), wred(a.c1)}; }
-template <class B> ZL_HD Fp2L<B> canon(const Fp2L<B>& a) { return Fp2L<B>{canon(a.c0), canon(a.c1)}; }
-template <class A, class P> ZL_HD Fp2L<Fp28<A, P>> mul(const Fp2L<Fp28<A, P>>& a, const Fp2L<Fp28<A, P>>& b) {
-#ifdef ZL_INLINE_FQ2
-    return Fp2L<Fp28<A, P>>{muladd_body28(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd_body28(a.c0, b.c1, a.c1, b.c0)};
-#endif
-    Fp2L<Fp28<A, P>> r;
-    unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
-    return r;
+template <class B, bool I> ZL_HD Fp2LT<B, I> add(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+template <class B, bool I> ZL_HD Fp2LT<B, I> dbl(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{dbl(a.c0), dbl(a.c1)}; }
+template <int J, class B, bool I> ZL_HD Fp2LT<B, I> subk(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{subk<J>(a.c0, b.c0), subk<J>(a.c1, b.c1)}; }
+template <int J, class B, bool I> ZL_HD Fp2LT<B, I> negk(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{negk<J>(a.c0), negk<J>(a.c1)}; }
+template <class B, bool I> ZL_HD Fp2LT<B, I> sub(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return subk<4>(a, b); }
+template <class B, bool I> ZL_HD Fp2LT<B, I> neg(const Fp2LT<B, I>& a) { return negk<4>(a); }
+template <class B, bool I> ZL_HD Fp2LT<B, I> wred(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{wred(a.c0), wred(a.c1)}; }
+template <class B, bool I> ZL_HD Fp2LT<B, I> canon(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{canon(a.c0), canon(a.c1)}; }
+template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> mul(const Fp2LT<Fp28<A, P>, I>& a, const Fp2LT<Fp28<A, P>, I>& b) {
+    if constexpr (I) {
+        return Fp2LT<Fp28<A, P>, I>{muladd_body28(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd_body28(a.c0, b.c1, a.c1, b.c0)};
+    } else {
+        Fp2LT<Fp28<A, P>, I> r;
+        unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
+        return r;
+    }
 }
-template <class A, class P> ZL_HD Fp2L<Fp28<A, P>> sqr(const Fp2L<Fp28<A, P>>& a) {
-#ifdef ZL_INLINE_FQ2
-    return Fp2L<Fp28<A, P>>{mul_body28(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul_body28(dbl(a.c0), a.c1)};
-#endif
-    Fp2L<Fp28<A, P>> r;
-    unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
-    return r;
+template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> sqr(const Fp2LT<Fp28<A, P>, I>& a) {
+    if constexpr (I) {
+        return Fp2LT<Fp28<A, P>, I>{mul_body28(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul_body28(dbl(a.c0), a.c1)};
+    } else {
+        Fp2LT<Fp28<A, P>, I> r;
+        unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
+        return r;
+    }
 }
-// a b + c d.  Inlined build: each component is ONE four-product scan (980 mads) -> components < 2q; operands' components < 16q.
-// Called build: two calls and a lazy add (components < 4q; a four-product call would need 112 argument words).
-template <class A, class P>
-ZL_HD Fp2L<Fp28<A, P>> muladd(const Fp2L<Fp28<A, P>>& a, const Fp2L<Fp28<A, P>>& b, const Fp2L<Fp28<A, P>>& c, const Fp2L<Fp28<A, P>>& d) {
-#ifdef ZL_INLINE_FQ2
-    return Fp2L<Fp28<A, P>>{muladd4_body28(a.c0, b.c0, a.c1, negk<4>(b.c1), c.c0, d.c0, c.c1, negk<4>(d.c1)),
-                            muladd4_body28(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
-#endif
-    return add(mul(a, b), mul(c, d));
+// a b + c d.  Inlined flavour: each component is ONE four-product scan (980 mads) -> components < 2q; operands' components < 16q.
+// Called flavour: two calls and a lazy add (components < 4q; a four-product call would need 112 argument words).
+template <class A, class P, bool I>
+ZL_HD Fp2LT<Fp28<A, P>, I> muladd(const Fp2LT<Fp28<A, P>, I>& a, const Fp2LT<Fp28<A, P>, I>& b, const Fp2LT<Fp28<A, P>, I>& c, const Fp2LT<Fp28<A, P>, I>& d) {
+    if constexpr (I) {
+        return Fp2LT<Fp28<A, P>, I>{muladd4_body28(a.c0, b.c0, a.c1, negk<4>(b.c1), c.c0, d.c0, c.c1, negk<4>(d.c1)),
+                                   muladd4_body28(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+    } else {
+        return add(mul(a, b), mul(c, d));
+    }
 }
-template <class B> ZL_HD Fp2L<B> inv(const Fp2L<B>& a) {
+template <class B, bool I> ZL_HD Fp2LT<B, I> inv(const Fp2LT<B, I>& a) {
     const B n = inv(add(sqr(a.c0), sqr(a.c1)));
-    return Fp2L<B>{mul(a.c0, n), mul(negk<4>(a.c1), n)};
+    return Fp2LT<B, I>{mul(a.c0, n), mul(negk<4>(a.c1), n)};
 }
 }  // namespace zl
-template <class B>
-struct FieldIO<Fp2L<B>> {
+template <class B, bool I>
+struct FieldIO<Fp2LT<B, I>> {
     static constexpr int WORDS = 2 * FieldIO<B>::WORDS;
-    ZL_HD static Fp2L<B> load_canon(const uint32_t* w) { return Fp2L<B>{FieldIO<B>::load_canon(w), FieldIO<B>::load_canon(w + FieldIO<B>::WORDS)}; }
-    ZL_HD static Fp2L<B> load_mont32(const uint32_t* w) { return Fp2L<B>{FieldIO<B>::load_mont32(w), FieldIO<B>::load_mont32(w + FieldIO<B>::WORDS)}; }
-    ZL_HD static void store_canon(uint32_t* w, const Fp2L<B>& a) { FieldIO<B>::store_canon(w, a.c0); FieldIO<B>::store_canon(w + FieldIO<B>::WORDS, a.c1); }
+    ZL_HD static Fp2LT<B, I> load_canon(const uint32_t* w) { return Fp2LT<B, I>{FieldIO<B>::load_canon(w), FieldIO<B>::load_canon(w + FieldIO<B>::WORDS)}; }
+    ZL_HD static Fp2LT<B, I> load_mont32(const uint32_t* w) { return Fp2LT<B, I>{FieldIO<B>::load_mont32(w), FieldIO<B>::load_mont32(w + FieldIO<B>::WORDS)}; }
+    ZL_HD static void store_canon(uint32_t* w, const Fp2LT<B, I>& a) { FieldIO<B>::store_canon(w, a.c0); FieldIO<B>::store_canon(w + FieldIO<B>::WORDS, a.c1); }
 };
 
 // ---- points ----------------------------------------------------------------------------------------------

@@ -600,10 +600,14 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
 #endif
 template <class G>
 __global__ void __launch_bounds__(64, ZL_ACC_WAVES) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
-                                                        const Affine<typename G::F>* __restrict__ bases,
-                                                        XYZZ<typename G::F>* __restrict__ bucket_sums,
-                                                        XYZZ<typename G::F>* __restrict__ partials, uint32_t ZL_CHUNK) {
-    using F = typename G::F;
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK) {
+    using F = typename HotField<typename G::F>::type;  // same layout as G::F; Fq2 on 28-bit limbs: the inlining flavour (zl_curve.h)
+    static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
+    const Affine<F>* __restrict__ bases = reinterpret_cast<const Affine<F>*>(bases_);
+    XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
+    XYZZ<F>* __restrict__ partials = reinterpret_cast<XYZZ<F>*>(partials_);
     const uint32_t E = offsets[NB];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
