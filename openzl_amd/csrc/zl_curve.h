@@ -259,4 +259,19 @@ ZL_HD XYZZ<F> mul_scalar(const XYZZ<F>& p, const uint32_t* k) {
     }
     return acc;
 }
+// k1*p + k2*q for two 256-bit little-endian scalars (Shamir's trick: one doubling chain, additions from {p, q, p+q}); host tails
+template <class F>
+ZL_HD XYZZ<F> mul_scalar2(const XYZZ<F>& p, const uint32_t* k1, const XYZZ<F>& q, const uint32_t* k2) {
+    XYZZ<F> pq = p;
+    add_full(pq, q);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = 255; i >= 0; i--) {
+        dbl_inplace(acc);
+        const int b1 = (k1[i >> 5] >> (i & 31)) & 1, b2 = (k2[i >> 5] >> (i & 31)) & 1;
+        if (b1 && b2) add_full(acc, pq);
+        else if (b1) add_full(acc, p);
+        else if (b2) add_full(acc, q);
+    }
+    return acc;
+}
 }  // namespace zl
