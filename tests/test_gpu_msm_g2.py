@@ -52,3 +52,23 @@ def test_g2_generate_and_known_discrete_log(backend, curve):
     assert (first == gu.g2_mul_gen(curve, ol.limbs_to_ints(k[:4]))).all()
     dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % curve.fr.p
     assert inf == 0 and (got == gu.g2_mul_gen(curve, [dot])[0]).all()
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_g2_precomputed_table_and_skew(backend, curve):
+    """zl_bases_precompute on a G2 handle (merged bucket set) + the scalar-1 bypass and a giant bucket, against the oracle."""
+    n = 2500
+    ks = ol.limbs_to_ints(ol.random_scalars(curve, n, 71))
+    B = gu.g2_mul_gen(curve, ks)
+    S = ol.random_scalars(curve, n, 72)
+    S[100:700] = ol.ints_to_limbs([1], 4)[0]
+    S[700:1500] = ol.ints_to_limbs([5], 4)[0]
+    S[1500:1600] = 0
+    exp, einf = _oracle_msm_g2(curve, B, S)
+    h = backend.bases_upload(curve.cid, B, group=ZL_G2)
+    plain, pinf = backend.msm(h, S)
+    backend.bases_precompute(h, 16)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    assert pinf == einf and (plain == exp).all()
+    assert inf == einf and (got == exp).all()
