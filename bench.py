@@ -350,6 +350,28 @@ def main():
         }
         keys.close()
         circ.close()
+        # SURVEY.md §8d config 5 also names the small circuits: k = 1 (N = 2^8) and k = 2^6 (N = 2^14); latency-bound, reported beside
+        small = []
+        for k_small in (1, 64):
+            if k_small >= args.groth16_k:
+                continue
+            c2 = Circuit(ZL_BLS12_381, k_small)
+            k2 = Groth16Keys(be, c2, seed=0x5EED0006)
+            k2.prove(seed=7)
+            ts2 = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pr, _, _ = k2.prove(seed=7)
+                ts2.append(time.perf_counter() - t0)
+            ok2 = k2.verify(pr, c2.arrays()["assignment"][1:2])
+            if not ok2:
+                raise SystemExit("Groth16 self-check failed on the small circuit")
+            small.append({"hashes": k_small, "constraints": c2.shape[0], "prove_ms": float(np.mean(ts2)) * 1e3,
+                          "constraints_per_s": c2.shape[0] / float(np.mean(ts2)), "verified": True})
+            k2.close()
+            c2.close()
+        g16_info["small_circuits"] = small
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
