@@ -181,6 +181,18 @@ int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_
  * polynomial in w, Fq12 = Fq[w]/(w^12 - 2 w^6 + 2) (BLS12-381) or (w^12 - 18 w^6 + 82) (BN254) */
 int zl_pairing(zl_curve_t curve, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out12);
 
+/* ---- wire formats: arkworks 0.3 CanonicalSerialize, compressed (replaces proof_as_bytes / HasSerialization,
+ * /root/reference/plugins/arkworks/src/groth16.rs:68-107).  x little-endian, flags in the top two bits of the last byte
+ * (bit 7: y is the larger root, bit 6: infinity); Fq2: c0 then c1 (flags on c1).  Proof = A || B || C: 192 bytes (BLS12-381) / 128 (BN254).
+ * Host only.  NOT verified against arkworks-produced bytes (the reference holds no vector): pinned to an independent restatement
+ * (oracle/pyoracle.py) and round trips.  from_bytes: ZL_EINVAL = malformed, ZL_ENOTCURVE = no such point / outside the subgroup. */
+size_t zl_point_bytes(zl_curve_t curve, zl_group_t group);
+int zl_point_to_bytes(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint8_t inf, uint8_t* out);
+int zl_point_from_bytes(zl_curve_t curve, zl_group_t group, const uint8_t* in, uint64_t* xy, uint8_t* inf);
+size_t zl_groth16_proof_bytes(zl_curve_t curve);
+int zl_groth16_proof_to_bytes(zl_curve_t curve, const zl_g16_proof* proof, uint8_t* out);
+int zl_groth16_proof_from_bytes(zl_curve_t curve, const uint8_t* in, size_t len, zl_g16_proof* proof);
+
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
 typedef struct zl_timing {
     float total_ms;      /* first kernel start -> last kernel end of the last zl_msm* / zl_ntt* call */

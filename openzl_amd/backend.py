@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
+    "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
 ]
 
 
@@ -110,6 +111,14 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_prove_circuit.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(G16ProofC), u64p, u64p]
     L.zl_groth16_verify.argtypes = [vp, u64p, C.c_size_t, C.POINTER(G16ProofC), C.POINTER(C.c_int)]
     L.zl_pairing.argtypes = [C.c_int, u64p, u64p, u64p]
+    L.zl_point_bytes.argtypes = [C.c_int, C.c_int]
+    L.zl_point_bytes.restype = C.c_size_t
+    L.zl_point_to_bytes.argtypes = [C.c_int, C.c_int, u64p, C.c_uint8, u8p]
+    L.zl_point_from_bytes.argtypes = [C.c_int, C.c_int, u8p, u64p, u8p]
+    L.zl_groth16_proof_bytes.argtypes = [C.c_int]
+    L.zl_groth16_proof_bytes.restype = C.c_size_t
+    L.zl_groth16_proof_to_bytes.argtypes = [C.c_int, C.POINTER(G16ProofC), u8p]
+    L.zl_groth16_proof_from_bytes.argtypes = [C.c_int, u8p, C.c_size_t, C.POINTER(G16ProofC)]
     if path is None:
         _lib = L
     return L
@@ -313,6 +322,65 @@ def pairing(curve: int, p_xy: np.ndarray, q_xy: np.ndarray) -> np.ndarray:
     return out
 
 
+def _proof_struct(proof) -> "G16ProofC":
+    pc = G16ProofC()
+    a, ai, b, bi, c, ci = proof
+    for i, v in enumerate(a):
+        pc.a[i] = int(v)
+    for i, v in enumerate(b):
+        pc.b[i] = int(v)
+    for i, v in enumerate(c):
+        pc.c[i] = int(v)
+    pc.a_inf, pc.b_inf, pc.c_inf = int(ai), int(bi), int(ci)
+    return pc
+
+
+def point_to_bytes(curve: int, group: int, xy: np.ndarray, inf: int = 0) -> bytes:
+    """arkworks CanonicalSerialize (compressed) of one affine point given as canonical limbs (host code, no GPU)."""
+    L = load_library()
+    out = (C.c_uint8 * L.zl_point_bytes(curve, group))()
+    rc = L.zl_point_to_bytes(curve, group, _p64(np.ascontiguousarray(xy, dtype=np.uint64)), int(inf), out)
+    if rc:
+        raise BackendError(rc, "zl_point_to_bytes")
+    return bytes(out)
+
+
+def point_from_bytes(curve: int, group: int, data: bytes):
+    L = load_library()
+    if len(data) != L.zl_point_bytes(curve, group):
+        raise BackendError(-1, "zl_point_from_bytes", "wrong length")
+    xy = np.zeros(2 * group * FQ_LIMBS[curve], dtype=np.uint64)
+    inf = C.c_uint8(0)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    rc = L.zl_point_from_bytes(curve, group, buf, _p64(xy), C.byref(inf))
+    if rc:
+        raise BackendError(rc, "zl_point_from_bytes")
+    return xy, inf.value
+
+
+def proof_to_bytes(curve: int, proof) -> bytes:
+    """proof = (a, a_inf, b, b_inf, c, c_inf) as returned by Groth16Keys.prove -> 192 (BLS12-381) / 128 (BN254) bytes"""
+    L = load_library()
+    out = (C.c_uint8 * L.zl_groth16_proof_bytes(curve))()
+    pc = _proof_struct(proof)
+    rc = L.zl_groth16_proof_to_bytes(curve, C.byref(pc), out)
+    if rc:
+        raise BackendError(rc, "zl_groth16_proof_to_bytes")
+    return bytes(out)
+
+
+def proof_from_bytes(curve: int, data: bytes):
+    L = load_library()
+    pc = G16ProofC()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    rc = L.zl_groth16_proof_from_bytes(curve, buf, len(data), C.byref(pc))
+    if rc:
+        raise BackendError(rc, "zl_groth16_proof_from_bytes")
+    nq = FQ_LIMBS[curve]
+    return (np.array(pc.a[: 2 * nq], dtype=np.uint64), pc.a_inf, np.array(pc.b[: 4 * nq], dtype=np.uint64), pc.b_inf,
+            np.array(pc.c[: 2 * nq], dtype=np.uint64), pc.c_inf)
+
+
 class Circuit:
     """R1CS<F> compiler in proof mode holding the config-5 Poseidon-chain circuit (host code, no GPU)."""
 
@@ -406,15 +474,7 @@ class Groth16Keys:
 
     def verify(self, proof, public_inputs: np.ndarray) -> bool:
         """Groth16::verify(vk, input, proof) with the host pairing; proof = (a, a_inf, b, b_inf, c, c_inf)"""
-        pc = G16ProofC()
-        a, ai, b, bi, c, ci = proof
-        for i, v in enumerate(a):
-            pc.a[i] = int(v)
-        for i, v in enumerate(b):
-            pc.b[i] = int(v)
-        for i, v in enumerate(c):
-            pc.c[i] = int(v)
-        pc.a_inf, pc.b_inf, pc.c_inf = int(ai), int(bi), int(ci)
+        pc = _proof_struct(proof)
         pub = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
         ok = C.c_int(0)
         self.backend._check(self.L.zl_groth16_verify(self._k, _p64(pub), pub.shape[0], C.byref(pc), C.byref(ok)), "zl_groth16_verify")

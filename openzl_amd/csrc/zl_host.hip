@@ -3,6 +3,7 @@
 #include <string.h>
 #include <new>
 #include "zl_host.h"
+#include "zl_serialize.h"
 
 namespace openzl {
 
@@ -488,6 +489,42 @@ int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_
         *ok = r.value ? 1 : 0;
     }
     return ZL_OK;
+}
+
+// ---- wire formats (arkworks CanonicalSerialize, compressed; zl_serialize.h) -----------------------------------------------------
+size_t zl_point_bytes(zl_curve_t curve, zl_group_t group) {
+    if ((curve != ZL_BLS12_381 && curve != ZL_BN254) || (group != ZL_G1 && group != ZL_G2)) return 0;
+    const size_t nb = curve == ZL_BLS12_381 ? 48 : 32;
+    return group == ZL_G1 ? nb : 2 * nb;
+}
+int zl_point_to_bytes(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint8_t inf, uint8_t* out) {
+    if (!xy || !out || !zl_point_bytes(curve, group)) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) { if (group == ZL_G1) serialize::BlsCodec::g1_to_bytes(xy, inf != 0, out); else serialize::BlsCodec::g2_to_bytes(xy, inf != 0, out); }
+    else { if (group == ZL_G1) serialize::BnCodec::g1_to_bytes(xy, inf != 0, out); else serialize::BnCodec::g2_to_bytes(xy, inf != 0, out); }
+    return ZL_OK;
+}
+int zl_point_from_bytes(zl_curve_t curve, zl_group_t group, const uint8_t* in, uint64_t* xy, uint8_t* inf) {
+    if (!xy || !in || !inf || !zl_point_bytes(curve, group)) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) return group == ZL_G1 ? serialize::BlsCodec::g1_from_bytes(in, xy, inf) : serialize::BlsCodec::g2_from_bytes(in, xy, inf);
+    return group == ZL_G1 ? serialize::BnCodec::g1_from_bytes(in, xy, inf) : serialize::BnCodec::g2_from_bytes(in, xy, inf);
+}
+size_t zl_groth16_proof_bytes(zl_curve_t curve) { return 2 * zl_point_bytes(curve, ZL_G1) + zl_point_bytes(curve, ZL_G2); }
+int zl_groth16_proof_to_bytes(zl_curve_t curve, const zl_g16_proof* proof, uint8_t* out) {
+    if (!proof || !out || !zl_groth16_proof_bytes(curve)) return ZL_EINVAL;
+    const size_t n1 = zl_point_bytes(curve, ZL_G1), n2 = zl_point_bytes(curve, ZL_G2);
+    int rc;
+    if ((rc = zl_point_to_bytes(curve, ZL_G1, proof->a, proof->a_inf, out))) return rc;
+    if ((rc = zl_point_to_bytes(curve, ZL_G2, proof->b, proof->b_inf, out + n1))) return rc;
+    return zl_point_to_bytes(curve, ZL_G1, proof->c, proof->c_inf, out + n1 + n2);
+}
+int zl_groth16_proof_from_bytes(zl_curve_t curve, const uint8_t* in, size_t len, zl_g16_proof* proof) {
+    if (!proof || !in || !zl_groth16_proof_bytes(curve) || len != zl_groth16_proof_bytes(curve)) return ZL_EINVAL;
+    const size_t n1 = zl_point_bytes(curve, ZL_G1), n2 = zl_point_bytes(curve, ZL_G2);
+    memset(proof, 0, sizeof *proof);
+    int rc;
+    if ((rc = zl_point_from_bytes(curve, ZL_G1, in, proof->a, &proof->a_inf))) return rc;
+    if ((rc = zl_point_from_bytes(curve, ZL_G2, in + n1, proof->b, &proof->b_inf))) return rc;
+    return zl_point_from_bytes(curve, ZL_G1, in + n1 + n2, proof->c, &proof->c_inf);
 }
 
 }  // extern "C"

@@ -1007,3 +1007,104 @@ def groth16_verify_pairing(c: CurveParams, vk: dict, public_inputs: Sequence[int
     lhs = pairing(c, A, B)
     rhs = ctx.mul(ctx.mul(pairing(c, vk["alpha_g1"], vk["beta_g2"]), pairing(c, acc, vk["gamma_g2"])), pairing(c, C_, vk["delta_g2"]))
     return lhs == rhs
+
+
+# ---- wire format: arkworks 0.3 CanonicalSerialize, compressed -------------------------------------------------
+# Restated from the published format of ark-serialize / ark-ec / ark-ff 0.3 (reached from /root/reference/plugins/arkworks/src/
+# groth16.rs:68-107): x as a little-endian canonical integer in ceil((MODULUS_BITS + 2) / 8) bytes, flags in the top two bits of the
+# last byte (bit 7: y > -y, bit 6: infinity), Fq2 = c0 then c1 with the flags on c1 and the order "c1 first, then c0".
+# UNPINNED: the reference holds no serialized vector; this is the checker for csrc/zl_serialize.h only.
+def _fq_bytes(c: CurveParams) -> int:
+    return (c.fq.bits + 2 + 7) // 8
+
+
+def g1_compress(c: CurveParams, P: Point) -> bytes:
+    nb = _fq_bytes(c)
+    if P is None:
+        return bytes(nb - 1) + bytes([0x40])
+    x, y = P
+    out = bytearray(x.to_bytes(nb, "little"))
+    if y > (c.fq.p - y) % c.fq.p:
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def fq_sqrt(p: int, a: int):
+    """Tonelli-free: p = 3 mod 4 for both curves"""
+    r = pow(a, (p + 1) // 4, p)
+    return r if r * r % p == a % p else None
+
+
+def g1_decompress(c: CurveParams, data: bytes) -> Point:
+    nb, p = _fq_bytes(c), c.fq.p
+    assert len(data) == nb
+    flags = data[-1] & 0xC0
+    x = int.from_bytes(data[:-1] + bytes([data[-1] & 0x3F]), "little")
+    if flags & 0x40:
+        return None
+    y = fq_sqrt(p, (x * x * x + c.b) % p)
+    assert y is not None
+    if (y > p - y) != bool(flags & 0x80):
+        y = p - y
+    return (x, y)
+
+
+def f2_gt(a: F2, b: F2) -> bool:  # ark-ff QuadExtField::cmp
+    return (a[1], a[0]) > (b[1], b[0])
+
+
+def g2_compress(c: CurveParams, P: Point2) -> bytes:
+    nb, p = _fq_bytes(c), c.fq.p
+    if P is None:
+        return bytes(2 * nb - 1) + bytes([0x40])
+    x, y = P
+    out = bytearray(x[0].to_bytes(nb, "little") + x[1].to_bytes(nb, "little"))
+    if f2_gt(y, ((p - y[0]) % p, (p - y[1]) % p)):
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def f2_sqrt(p: int, a: F2):
+    """Adj & Rodriguez-Henriquez, Alg. 9 (q = 3 mod 4, u^2 = -1) -- a different route than the backend's norm method"""
+    def f2_pow(b, e):
+        acc = (1, 0)
+        while e:
+            if e & 1:
+                acc = f2_mul(p, acc, b)
+            b = f2_mul(p, b, b)
+            e >>= 1
+        return acc
+    if a == (0, 0):
+        return (0, 0)
+    a1 = f2_pow(a, (p - 3) // 4)
+    alpha = f2_mul(p, a1, f2_mul(p, a1, a))
+    a0 = f2_mul(p, (alpha[0], (p - alpha[1]) % p), alpha)  # alpha^q * alpha (conjugate = Frobenius)
+    if a0 == (p - 1, 0):
+        return None
+    x0 = f2_mul(p, a1, a)
+    if alpha == (p - 1, 0):
+        r = ((p - x0[1]) % p, x0[0])  # u * x0
+    else:
+        b = f2_pow(((1 + alpha[0]) % p, alpha[1]), (p - 1) // 2)
+        r = f2_mul(p, b, x0)
+    return r if f2_mul(p, r, r) == a else None
+
+
+def g2_decompress(c: CurveParams, data: bytes) -> Point2:
+    nb, p = _fq_bytes(c), c.fq.p
+    assert len(data) == 2 * nb
+    flags = data[-1] & 0xC0
+    x = (int.from_bytes(data[:nb], "little"), int.from_bytes(data[nb:-1] + bytes([data[-1] & 0x3F]), "little"))
+    if flags & 0x40:
+        return None
+    rhs = f2_add(p, f2_mul(p, f2_mul(p, x, x), x), c.b2)
+    y = f2_sqrt(p, rhs)
+    assert y is not None
+    ny = ((p - y[0]) % p, (p - y[1]) % p)
+    if f2_gt(y, ny) != bool(flags & 0x80):
+        y = ny
+    return (x, y)
+
+
+def groth16_proof_bytes(c: CurveParams, A: Point, B: Point2, C_: Point) -> bytes:
+    return g1_compress(c, A) + g2_compress(c, B) + g1_compress(c, C_)

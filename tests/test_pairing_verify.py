@@ -46,6 +46,12 @@ def test_proof_system_compile_prove_verify(backend, curve):
         assert not np.array_equal(other[0], a) and keys.verify(other, pub) is True
         mixed = (a, ai, b, bi, other[4], ci)        # A, B of one proof with C of another
         assert keys.verify(mixed, pub) is False
+        # wire format round trip of a device-made proof: 192 / 128 bytes, decodes to the same points, still verifies
+        from openzl_amd.backend import proof_from_bytes, proof_to_bytes
+        wire = proof_to_bytes(curve.cid, proof)
+        assert len(wire) == (192 if curve.cid == 1 else 128)
+        back = proof_from_bytes(curve.cid, wire)
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(back, proof)) and keys.verify(back, pub) is True
         # cross-check with the definition-level verifier of the oracle (independent pairing implementation)
         td = po.Groth16Trapdoor(*keys.trapdoor())
         cs = po.poseidon_chain_circuit(curve.fr, 2)
