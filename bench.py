@@ -6,12 +6,18 @@
 
 A "step" is one variable-base MSM over 2^log_n random BLS12-381 G1 points and random scalars < r per GPU, bases and
 scalars already resident in HBM, through the C ABI (zl_msm_partial_dev); with N > 1 every rank owns its own shard of
-bases/scalars (weak scaling), the per-rank partial sums (144 B) are all-gathered over RCCL and folded
+bases/scalars (weak scaling), the per-rank partial sums (512 B) are all-gathered over RCCL and folded
 on every rank (zl_partials_sum).  Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline      HBM roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes (128 B / point, SURVEY.md
-                §8d) / its HIP-event duration on the backend's stream, vs 8 TB/s
-  cpu_baseline  the CPU oracle (arkworks-algorithm restatement, NOT the arkworks binary) timed on this box's cores
-  ntt           2^24 BLS12-381 Fr forward+inverse NTT throughput (second half of the BASELINE metric), 1 GPU
+                §8d) / its HIP-event duration on the backend's stream, vs 8 TB/s; .int_alu = the integer-multiply roofline
+                that actually binds; .traffic = PMC bytes of the same configuration (profiles/)
+  cpu_baseline  the CPU oracle (arkworks-algorithm restatement, NOT the arkworks binary) timed on this box's cores (N = 1 only)
+  msm_skewed_scalars  the same MSM on Groth16-witness-like scalars (N = 1 only)
+  ntt           2^24 BLS12-381 Fr forward+inverse NTT throughput (second half of the BASELINE metric); N > 1: per-GPU replicas
+                and .distributed = ONE 2^(24 + log2 N) transform over all ranks with a single RCCL all-to-all
+  groth16       config 5 (Poseidon-chain circuit, 958 465 constraints) prove time / constraints per second, proof verified;
+                N > 1: one independent proof per GPU (replicas)
+The secondary legs of an N > 1 run execute after the MSM measurement under a watchdog, so a stall there cannot cost the MSM line.
 """
 from __future__ import annotations
 
