@@ -98,7 +98,7 @@ struct zl_ctx {
     std::map<uint64_t, zl_bases> bases;
     std::map<uint64_t, zl_r1cs_dev> r1cs;
     uint64_t next_handle = 1;
-    zl_scratch scratch[10];
+    zl_scratch scratch[20];  // 0..9: first buffer set + shared; 10..13: second MSM buffer set (pipelined batches)
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 7)

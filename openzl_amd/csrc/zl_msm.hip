@@ -923,78 +923,110 @@ static int zl_pick_window_precomp(size_t n, int sc_bits) {
     return best_c;
 }
 
+// One MSM as three phases that only communicate through device buffers, so that consecutive MSMs can be pipelined on three streams
+// (sort of MSM i+2 | bucket accumulation of MSM i+1 | merge / reduction tail of MSM i): plan() sizes everything, alloc() binds one of
+// two buffer sets, sort() builds the bucket-sorted entry list, accumulate() is the dominant kernel, tail() leaves SETS window sums
+// (+ the sum of the scalar-1 bases) in host memory, finish() does the host Horner.
 template <class G>
-static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
+struct MsmJob {
     using F = typename G::F;
     using X = XYZZ<F>;
-    X total = X::inf();
-    ctx->timing = zl_timing{};
-    if (n > 0) {
-        const bool pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
-        int c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS));
+    // plan
+    bool pre = false;
+    int c = 0, W = 0;
+    uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, ZL_SEG = 0, segs_per_set = 0, total_segs = 0, scan_blocks = 0, max_big = 0, max_giant = 0,
+             SUMW = 256, stage1 = 0;
+    uint64_t maxE = 0;
+    size_t n = 0, first = 0;
+    const zl_bases* bsp = nullptr;
+    // buffers
+    uint32_t *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_entries = nullptr, *d_block_sums = nullptr, *d_big_list = nullptr,
+             *d_big_count = nullptr, *d_ones_count = nullptr, *d_giant_count = nullptr, *d_giant_list = nullptr, *d_ones_list = nullptr;
+    X *d_buckets = nullptr, *d_partials = nullptr, *d_segs = nullptr, *d_stage1 = nullptr, *d_sets = nullptr, *d_ones_parts = nullptr, *d_giant_tmp = nullptr;
+    const Affine<F>* d_bases = nullptr;
+    const uint32_t* sc = nullptr;
+    // host results (pinned when pipelined)
+    X* hw = nullptr;
+    uint32_t* hE = nullptr;
+    std::vector<X> hw_own;
+    uint32_t hE_own = 0;
+
+    int plan(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_) {
+        n = n_;
+        first = first_;
+        bsp = &bs;
+        pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
+        c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS));
         if (c < 2) c = 2;
         if (c > 24) c = 24;
-        const int W = (G::SC_BITS + 1 + c - 1) / c;
-        const uint32_t H = 1u << (c - 1);
-        const uint32_t SETS = pre ? 1u : (uint32_t)W;  // bucket sets
+        W = (G::SC_BITS + 1 + c - 1) / c;
+        H = 1u << (c - 1);
+        SETS = pre ? 1u : (uint32_t)W;  // bucket sets
         const uint64_t NB64 = (uint64_t)SETS * H;
-        const uint64_t maxE = (uint64_t)n * W;
+        maxE = (uint64_t)n * W;
         if (n >= (1ull << 31) || maxE >= (1ull << 32) || NB64 >= (1ull << 31)) return ZL_EINVAL;
         if (pre && (uint64_t)W * bs.n >= (1ull << 31)) return ZL_EINVAL;
-        const uint32_t NB = (uint32_t)NB64;
+        if (pre && (c < 16 || (H >> 15) < 1 || (H >> 15) > 256)) return ZL_EINVAL;
+        NB = (uint32_t)NB64;
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
-        uint32_t ZL_CHUNK = ZL_CHUNK_MAX;
+        ZL_CHUNK = ZL_CHUNK_MAX;
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
-        const uint32_t nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
+        nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         // segment length of the bucket reduction: long for the big merged set (amortises the k0 multiple), short otherwise so that
         // the kernel has at least one wave per SIMD (measured: 2^20 plain 4.18 -> 4.04 ms, 2^16 1.81 -> 1.49 ms)
-        uint32_t ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (NB >= (1u << 17) ? 8u : 4u);
+        ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (NB >= (1u << 17) ? 8u : 4u);
         ZL_SEG = (uint32_t)std::max(1, zl_tune("ZL_TUNE_SEG", (int)ZL_SEG));
-        const uint32_t segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
-        const uint32_t total_segs = segs_per_set * SETS;
-        const uint32_t scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-        const uint32_t max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
-        const uint32_t max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
+        segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
+        total_segs = segs_per_set * SETS;
+        scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+        max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
+        max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         // tree over the segment results: sets with many segments are summed in two stages
-        const uint32_t SUMW = 256;
-        const uint32_t stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
-
-        uint32_t *d_counts, *d_offsets, *d_cursor, *d_entries, *d_small;
-        X *d_buckets, *d_partials, *d_segs;
+        stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
+        d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
+        sc = reinterpret_cast<const uint32_t*>(d_scalars);
+        hw_own.assign(SETS + 1, X::inf());
+        hw = hw_own.data();
+        hE = &hE_own;
+        return ZL_OK;
+    }
+    // buffer set 0 or 1 (slots 0..3 / 10..13); the tail buffers (slot 4) and the sort temporaries (slots 5, 6) are shared: tails and sorts
+    // of consecutive jobs run in order on their own streams
+    int alloc(zl_ctx* ctx, int set) {
         void* p;
         int rc;
-        // slot 0: counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | big count
+        const int o = set ? 10 : 0;
+        // counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
         size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n;
-        if ((rc = zl_scratch_get(ctx, 0, small_words * 4, &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, o + 0, small_words * 4, &p))) return rc;
         d_counts = (uint32_t*)p;
         d_offsets = d_counts + (NB + 1);
         d_cursor = d_offsets + (NB + 1);
-        d_small = d_cursor + (NB + 1);
-        uint32_t* d_block_sums = d_small;
-        uint32_t* d_big_list = d_block_sums + scan_blocks + 1;
-        uint32_t* d_big_count = d_big_list + max_big;
-        uint32_t* d_ones_count = d_big_count + 1;
-        uint32_t* d_giant_count = d_big_count + 2;
-        uint32_t* d_giant_list = d_big_count + 16;
-        uint32_t* d_ones_list = d_giant_list + max_giant;
-        if ((rc = zl_scratch_get(ctx, 1, maxE * 4, &p))) return rc;
+        d_block_sums = d_cursor + (NB + 1);
+        d_big_list = d_block_sums + scan_blocks + 1;
+        d_big_count = d_big_list + max_big;
+        d_ones_count = d_big_count + 1;
+        d_giant_count = d_big_count + 2;
+        d_giant_list = d_big_count + 16;
+        d_ones_list = d_giant_list + max_giant;
+        if ((rc = zl_scratch_get(ctx, o + 1, maxE * 4, &p))) return rc;
         d_entries = (uint32_t*)p;
-        if ((rc = zl_scratch_get(ctx, 2, (size_t)NB * sizeof(X), &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, o + 2, (size_t)NB * sizeof(X), &p))) return rc;
         d_buckets = (X*)p;
-        if ((rc = zl_scratch_get(ctx, 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, o + 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
         d_partials = (X*)p;
         if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + (size_t)SETS * (stage1 + 1) + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
         d_segs = (X*)p;
-        X* d_stage1 = d_segs + total_segs;
-        X* d_sets = d_stage1 + (size_t)SETS * stage1;  // SETS window sums, then the sum of the scalar-1 bases
-        X* d_ones_parts = d_sets + SETS + 1;
-        X* d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
-
-        hipStream_t st = ctx->stream;
-        const Affine<F>* d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
-        const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
-        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+        d_stage1 = d_segs + total_segs;
+        d_sets = d_stage1 + (size_t)SETS * stage1;  // SETS window sums, then the sum of the scalar-1 bases
+        d_ones_parts = d_sets + SETS + 1;
+        d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
+        return ZL_OK;
+    }
+    int sort(zl_ctx* ctx, hipStream_t st) {
+        const zl_bases& bs = *bsp;
+        int rc;
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 12, st));  // big, ones, giant counts
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
@@ -1003,9 +1035,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (pre) {
             // ---- two-level counting sort over the merged bucket set ------------------------------------------------------
-            if (c < 16) return ZL_EINVAL;
             const uint32_t Gn = H >> 15;  // groups of 32768 fine buckets
-            if (Gn < 1 || Gn > 256) return ZL_EINVAL;
             uint32_t nslices = 64;
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
@@ -1093,9 +1123,15 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
             hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count);
         }
-        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        ZL_HIP(ctx, hipGetLastError());
+        return ZL_OK;
+    }
+    int accumulate(zl_ctx* ctx, hipStream_t st) {
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
-        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+        ZL_HIP(ctx, hipGetLastError());
+        return ZL_OK;
+    }
+    int tail(zl_ctx* ctx, hipStream_t st) {
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
@@ -1115,20 +1151,13 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         } else {
             hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, segs_per_set, segs_per_set, 1u, d_sets);
         }
-        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
         ZL_HIP(ctx, hipGetLastError());
-        std::vector<X> hw(SETS + 1);
-        uint32_t hE = 0;
-        ZL_HIP(ctx, hipMemcpyAsync(hw.data(), d_sets, sizeof(X) * (SETS + 1), hipMemcpyDeviceToHost, st));
-        ZL_HIP(ctx, hipMemcpyAsync(&hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
-        ZL_HIP(ctx, hipStreamSynchronize(st));
-        if (ctx->timing_on) {
-            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]));
-            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.dominant_ms, ctx->ev[1], ctx->ev[2]));
-        }
-        ctx->timing.launches = 1;
-        ctx->timing.window_bits = (uint32_t)c;
-        ctx->timing.entries = hE;
+        ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * (SETS + 1), hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
+        return ZL_OK;
+    }
+    X finish() const {
+        X total = X::inf();
         if (pre) {
             total = hw[0];  // the table already carries the 2^(c w) factors
         } else {
@@ -1139,6 +1168,37 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
             }
         }
         zl::add_full(total, hw[SETS]);
+        return total;
+    }
+};
+
+template <class G>
+static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
+    using X = XYZZ<typename G::F>;
+    X total = X::inf();
+    ctx->timing = zl_timing{};
+    if (n > 0) {
+        MsmJob<G> job;
+        int rc;
+        if ((rc = job.plan(ctx, bs, first, d_scalars, n))) return rc;
+        if ((rc = job.alloc(ctx, 0))) return rc;
+        hipStream_t st = ctx->stream;
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+        if ((rc = job.sort(ctx, st))) return rc;
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        if ((rc = job.accumulate(ctx, st))) return rc;
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+        if ((rc = job.tail(ctx, st))) return rc;
+        if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        ZL_HIP(ctx, hipStreamSynchronize(st));
+        if (ctx->timing_on) {
+            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]));
+            ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.dominant_ms, ctx->ev[1], ctx->ev[2]));
+        }
+        ctx->timing.launches = 1;
+        ctx->timing.window_bits = (uint32_t)job.c;
+        ctx->timing.entries = *job.hE;
+        total = job.finish();
     }
     static_assert(sizeof(X) <= ZL_PARTIAL_WORDS * 8, "partial too small");
     memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);
