@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-skew", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="issue the K steps as K separate calls instead of one pipelined batch")
     ap.add_argument("--scalars", choices=["uniform", "skewed"], default="uniform", help="skewed: 50%% zeros, 25%% ones, rest uniform (profiling aid)")
     ap.add_argument("--ntt-log-n", type=int, default=24)
     ap.add_argument("--groth16-k", type=int, default=4096, help="config 5: chained Poseidon hashes (4096 -> domain 2^20); 0 = skip")
@@ -243,31 +244,63 @@ def main():
     if inf or not (got == exp).all():
         raise SystemExit("MSM self-check failed: result != (sum s_i k_i) G")
 
-    from openzl_amd.sharded import sharded_msm
+    from openzl_amd.sharded import sharded_msm, sharded_msm_batch
+
+    gather_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
 
     def step():
         # local Pippenger -> 1 partial sum; N > 1: all_gather over RCCL + fold on every rank (openzl_amd/sharded.py)
-        gather_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
         return sharded_msm(lambda: be.msm_partial_dev(h, d_scalars.data_ptr(), n), ZL_BLS12_381, device=gather_dev)
+
+    def steps_pipelined(k):
+        # the K steps as ONE pipelined batch (zl_msm_batch_partial_dev: sort of step i+2 | accumulation of step i+1 | tail of step i on
+        # three streams), every step a complete MSM with its own result; N > 1: one all_gather of the K partials per rank, K folds
+        parts = be.msm_batch_partial_dev(h, [d_scalars.data_ptr()] * k, n)
+        return sharded_msm_batch(parts, ZL_BLS12_381, device=gather_dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    ref_xy, ref_inf = step()  # untimed: the full-size result through the plain single-call path, every timed step must reproduce it
+    pipelined = not args.no_pipeline and args.steps > 1
+    if pipelined:
+        # setup, untimed like the base upload: one 3-deep batch creates the side streams and grows all three buffer sets
+        for xy_k, inf_k in steps_pipelined(3):
+            if inf_k != ref_inf or not (np.asarray(xy_k) == np.asarray(ref_xy)).all():
+                raise SystemExit("MSM self-check failed: the pipelined path disagrees with the single-call result")
+        if args.warmup:
+            steps_pipelined(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            step()
     dom_ms, tot_ms = [], []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    if pipelined:
+        results = steps_pipelined(args.steps)
         tm = be.last_timing()
-        dom_ms.append(tm.dominant_ms)
-        tot_ms.append(tm.total_ms)
+        dom_ms.append(tm.dominant_ms)   # mean accumulation-kernel duration over the K steps (HIP events on its stream)
+        tot_ms.append(tm.total_ms)      # device time per step, pipelined
+    else:
+        results = []
+        for _ in range(args.steps):
+            results.append(step())
+            tm = be.last_timing()
+            dom_ms.append(tm.dominant_ms)
+            tot_ms.append(tm.total_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     tm = be.last_timing()
+    for xy_k, inf_k in results:
+        if inf_k != ref_inf or not (np.asarray(xy_k) == np.asarray(ref_xy)).all():
+            raise SystemExit("MSM self-check failed: a timed step disagrees with the single-call result")
+    # latency of one un-pipelined MSM call, for the record
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    be.msm_partial_dev(h, d_scalars.data_ptr(), n)
+    single_ms = (time.perf_counter() - t1) * 1e3
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -438,6 +471,9 @@ def main():
                        "precomputed_table": (f"2^(c w) P_i for all windows, c={int(tm.window_bits)} (one merged bucket set; built at upload)"
                                              if pre_c >= 0 else "none"),
                        "parallelism": f"shard{world}" if world > 1 else "single",
+                       "steps_issued_as": "one pipelined batch (zl_msm_batch_partial_dev): sort | accumulate | tail of consecutive steps overlap on three streams"
+                                          if pipelined else "separate calls",
+                       "single_call_latency_ms": single_ms,
                        "result_check": "known-discrete-log prefix check passed; bit-exact parity in tests/"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_final.json)",

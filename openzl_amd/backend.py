@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
     "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
     L.zl_msm_partial_dev.argtypes = [vp, C.c_uint64, C.c_size_t, vp, C.c_size_t, u64p]
     L.zl_partials_sum.argtypes = [C.c_int, C.c_int, u64p, C.c_size_t, u64p, u8p]
     L.zl_partial_from_affine.argtypes = [C.c_int, C.c_int, u64p, u64p]
+    L.zl_msm_batch_partial_dev.argtypes = [vp, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, u64p]
     L.zl_ntt.argtypes = [vp, C.c_int, u64p, C.c_uint, C.c_uint]
     L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
     L.zl_ntt_cross_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
@@ -230,6 +231,14 @@ class Backend:
     def msm_partial_dev(self, handle: int, d_scalars: int, n: int, first: int = 0) -> np.ndarray:
         out = np.zeros(ZL_PARTIAL_WORDS, dtype=np.uint64)
         self._check(self.L.zl_msm_partial_dev(self._ctx, handle, first, C.c_void_p(d_scalars), n, _p64(out)), "zl_msm_partial_dev")
+        return out
+
+    def msm_batch_partial_dev(self, handle: int, d_scalars, n: int, first: int = 0) -> np.ndarray:
+        """d_scalars: list of device pointers (one scalar vector per MSM) -> (count, ZL_PARTIAL_WORDS) partial sums; pipelined."""
+        count = len(d_scalars)
+        ptrs = (C.c_void_p * max(1, count))(*[int(p) for p in d_scalars])
+        out = np.zeros((count, ZL_PARTIAL_WORDS), dtype=np.uint64)
+        self._check(self.L.zl_msm_batch_partial_dev(self._ctx, handle, first, ptrs, n, count, _p64(out)), "zl_msm_batch_partial_dev")
         return out
 
     def partials_sum(self, curve: int, partials: np.ndarray, group: int = ZL_G1) -> Tuple[np.ndarray, int]:

@@ -50,6 +50,9 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     }
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
+    if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
+    if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux->stream);
@@ -157,6 +160,15 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     return ZL_OK;
 }
 
+int zl_msm_batch_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
+    if (!ctx || (count && (!out_partials || !d_scalars))) return ZL_EINVAL;
+    for (size_t i = 0; i < count; i++) if (!d_scalars[i] && n) return ZL_EINVAL;
+    auto it = ctx->bases.find(bases);
+    if (it == ctx->bases.end()) return ZL_EHANDLE;
+    if (first > it->second.n || n > it->second.n - first) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return ZL_DISPATCH(it->second.curve, it->second.group, zl_msm_run_batch, ctx, it->second, first, d_scalars, n, count, out_partials);
+}
 int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     if (!ctx || !out_partial || (!d_scalars && n)) return ZL_EINVAL;
     auto it = ctx->bases.find(bases);

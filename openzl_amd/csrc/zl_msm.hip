@@ -991,12 +991,12 @@ struct MsmJob {
         hE = &hE_own;
         return ZL_OK;
     }
-    // buffer set 0 or 1 (slots 0..3 / 10..13); the tail buffers (slot 4) and the sort temporaries (slots 5, 6) are shared: tails and sorts
+    // buffer set 0, 1 or 2 (slots 0..3 / 10..13 / 14..17); the tail buffers (slot 4) and the sort temporaries (slots 5, 6) are shared: tails and sorts
     // of consecutive jobs run in order on their own streams
     int alloc(zl_ctx* ctx, int set) {
         void* p;
         int rc;
-        const int o = set ? 10 : 0;
+        const int o = set == 0 ? 0 : (set == 1 ? 10 : 14);
         // counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
         size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n;
         if ((rc = zl_scratch_get(ctx, o + 0, small_words * 4, &p))) return rc;
@@ -1206,6 +1206,124 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
     return ZL_OK;
 }
 
+// `count` MSMs over the same bases, pipelined: sort of MSM i+2 (stream_sort) | accumulation of MSM i+1 (ctx->stream) | tail of MSM i
+// (stream_tail).  Three buffer sets rotate; a set is reused when the tail that reads it has finished.  The sort and tail phases are
+// memory- / latency-bound and fit into the issue slots the compute-bound accumulation leaves, so in steady state an MSM costs its
+// accumulation kernel only.
+template <class G>
+static int msm_run_batch_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
+    using X = XYZZ<typename G::F>;
+    ctx->timing = zl_timing{};
+    if (count == 0) return ZL_OK;
+    if (n == 0 || count == 1) {
+        for (size_t i = 0; i < count; i++) {
+            int rc = msm_run_t<G>(ctx, bs, first, d_scalars[i], n, out_partials + i * ZL_PARTIAL_WORDS);
+            if (rc) return rc;
+        }
+        return ZL_OK;
+    }
+    int rc;
+    if (!ctx->stream_sort) {
+        // highest priority: the short sort / tail kernels must get wave slots as the long accumulation kernel frees them
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, prio_hi));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_tail, hipStreamNonBlocking, prio_hi));
+    }
+    std::vector<MsmJob<G>> jobs(count);
+    for (size_t i = 0; i < count; i++) {
+        if ((rc = jobs[i].plan(ctx, bs, first, d_scalars[i], n))) return rc;
+    }
+    // all buffer sets up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i.  Three sets:
+    // the tail of job i runs beside the accumulation of job i+1 and is slow there, so the sort of job i+2 must not have to wait for it.
+    for (size_t i = 0; i < count; i++) {
+        if ((rc = jobs[i].alloc(ctx, (int)(i % 3)))) return rc;
+    }
+    const uint32_t SETS = jobs[0].SETS;
+    const size_t per = sizeof(X) * (SETS + 1) + 16;
+    if (ctx->pinned_cap < per * count) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+        ZL_HIP(ctx, hipHostMalloc(&ctx->pinned, per * count, hipHostMallocDefault));
+        ctx->pinned_cap = per * count;
+    }
+    for (size_t i = 0; i < count; i++) {
+        unsigned char* base = reinterpret_cast<unsigned char*>(ctx->pinned) + per * i;
+        jobs[i].hw = reinterpret_cast<X*>(base);
+        jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (SETS + 1));
+    }
+    hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
+    std::vector<hipEvent_t> ev_sorted(count), ev_acc(count), ev_tail(count), ev_acc0(ctx->timing_on ? count : 0);
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    auto cleanup = [&]() {
+        for (auto e : ev_sorted) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_acc) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_tail) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_acc0) if (e) (void)hipEventDestroy(e);
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+    };
+    hipError_t he = hipSuccess;
+    for (size_t i = 0; i < count && he == hipSuccess; i++) {
+        ev_sorted[i] = ev_acc[i] = ev_tail[i] = nullptr;
+        he = hipEventCreateWithFlags(&ev_sorted[i], hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_tail[i], hipEventDisableTiming);
+        if (he == hipSuccess) he = ctx->timing_on ? hipEventCreate(&ev_acc[i]) : hipEventCreateWithFlags(&ev_acc[i], hipEventDisableTiming);
+        if (he == hipSuccess && ctx->timing_on) he = hipEventCreate(&ev_acc0[i]);
+    }
+    if (he == hipSuccess) he = hipEventCreate(&ev_begin);
+    if (he == hipSuccess) he = hipEventCreate(&ev_end);
+    if (he != hipSuccess) { cleanup(); ctx->last_hip = (int)he; return ZL_EHIP; }
+    rc = ZL_OK;
+    // everything already queued on the caller's stream (e.g. the kernels that produced the scalars) comes first
+    he = hipEventRecord(ev_begin, s_acc);
+    if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
+    for (size_t i = 0; i < count && he == hipSuccess && rc == ZL_OK; i++) {
+        if (i >= 3) he = hipStreamWaitEvent(s_sort, ev_tail[i - 3], 0);  // buffer set i % 3 is free again
+        if (he != hipSuccess) break;
+        if ((rc = jobs[i].sort(ctx, s_sort))) break;
+        he = hipEventRecord(ev_sorted[i], s_sort);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s_acc, ev_sorted[i], 0);
+        if (he == hipSuccess && ctx->timing_on) he = hipEventRecord(ev_acc0[i], s_acc);
+        if (he != hipSuccess) break;
+        if ((rc = jobs[i].accumulate(ctx, s_acc))) break;
+        he = hipEventRecord(ev_acc[i], s_acc);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
+        if (he != hipSuccess) break;
+        if ((rc = jobs[i].tail(ctx, s_tail))) break;
+        he = hipEventRecord(ev_tail[i], s_tail);
+    }
+    if (he == hipSuccess) he = hipEventRecord(ev_end, s_tail);
+    // drain all three streams whatever happened, then report
+    (void)hipStreamSynchronize(s_sort);
+    (void)hipStreamSynchronize(s_acc);
+    const hipError_t hs = hipStreamSynchronize(s_tail);
+    if (he == hipSuccess) he = hs;
+    if (he == hipSuccess && rc == ZL_OK && ctx->timing_on) {
+        float tot = 0.f, acc_sum = 0.f, t = 0.f;
+        he = hipEventElapsedTime(&tot, ev_begin, ev_end);
+        for (size_t i = 0; i < count && he == hipSuccess; i++) {
+            he = hipEventElapsedTime(&t, ev_acc0[i], ev_acc[i]);
+            acc_sum += t;
+        }
+        ctx->timing.total_ms = tot / (float)count;          // per MSM, pipelined
+        ctx->timing.dominant_ms = acc_sum / (float)count;   // mean accumulation kernel
+    }
+    cleanup();
+    if (he != hipSuccess) { ctx->last_hip = (int)he; return ZL_EHIP; }
+    if (rc) return rc;
+    ctx->timing.launches = (uint32_t)count;
+    ctx->timing.window_bits = (uint32_t)jobs[0].c;
+    ctx->timing.entries = *jobs[count - 1].hE;
+    for (size_t i = 0; i < count; i++) {
+        const X total = jobs[i].finish();
+        memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
+        memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
+    }
+    return ZL_OK;
+}
+
 // table[w][i] = 2^(c w) P_i for every base of the handle (one-time, at upload)
 template <class G>
 static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
@@ -1230,6 +1348,9 @@ static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
 }
 int ZL_GNAME(zl_bases_precompute)(zl_ctx* ctx, zl_bases& b, int c) { return bases_precompute_t<ZL_G>(ctx, b, c); }
 
+int ZL_GNAME(zl_msm_run_batch)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
+    return msm_run_batch_t<ZL_G>(ctx, b, first, d_scalars, n, count, out_partials);
+}
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);
 }

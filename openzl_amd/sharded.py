@@ -58,6 +58,27 @@ def sharded_msm(local_partial: Callable[[], np.ndarray], curve: int, group: int 
     return fold_partials(curve, parts, group)
 
 
+def sharded_msm_batch(local_partials: np.ndarray, curve: int, group: int = ZL_G1, device=None):
+    """K pipelined local MSMs per rank (Backend.msm_batch_partial_dev -> (K, ZL_PARTIAL_WORDS)): ONE all_gather of K partials per rank,
+    then K folds on every rank.  Returns a list of K (xy, inf)."""
+    import torch
+    import torch.distributed as dist
+
+    parts = np.ascontiguousarray(local_partials).reshape(-1, ZL_PARTIAL_WORDS)
+    k = parts.shape[0]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        t = torch.from_numpy(parts.reshape(-1).view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+        allp = torch.empty(world * k * ZL_PARTIAL_WORDS, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(allp, t)
+        allparts = allp.cpu().numpy().view(np.uint64).reshape(world, k, ZL_PARTIAL_WORDS)
+    else:
+        allparts = parts.reshape(1, k, ZL_PARTIAL_WORDS)
+    return [fold_partials(curve, np.ascontiguousarray(allparts[:, j, :]), group) for j in range(k)]
+
+
 # ---- distributed NTT -------------------------------------------------------------------------------------------
 def block_column_slice(x: np.ndarray, log_g: int, rank: int) -> np.ndarray:
     """This rank's part of a natural-order vector x (N, 4) in the block-column layout: local[j1*B + c] = x[j1*M + rank*B + c]."""

@@ -244,3 +244,37 @@ def test_config4_eight_shards_of_2_23(backend):
         dot = (dot + _dot_mod_r_u64k(S, k64, r)) % r
     got, inf = backend.partials_sum(curve.cid, np.stack(parts))
     assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("table", [False, True], ids=["plain", "table"])
+def test_msm_pipelined_batch_equals_single_calls(backend, curve, table):
+    """zl_msm_batch_partial_dev (three-stream pipeline over two buffer sets) against one zl_msm_partial_dev per scalar vector, and the
+    oracle for the first one; 5 MSMs so that both buffer sets are reused."""
+    import torch
+
+    n = 6000
+    k, B = _bases(curve, n, 91)
+    h = backend.bases_upload(curve.cid, B)
+    if table:
+        backend.bases_precompute(h, 16)
+    vecs = []
+    for j in range(5):
+        S = ol.random_scalars(curve, n, 920 + j)
+        if j == 1:
+            S[: n // 2] = ol.ints_to_limbs([1], 4)[0]   # scalar-1 bypass list differs per job
+        if j == 3:
+            S[:] = 0                                      # an all-zero job in the middle of the pipeline
+        vecs.append(S)
+    dev = [torch.from_numpy(S.view(np.int64)).cuda() for S in vecs]
+    torch.cuda.synchronize()
+    batch = backend.msm_batch_partial_dev(h, [t.data_ptr() for t in dev], n)
+    for j in range(5):
+        single = backend.msm_partial_dev(h, dev[j].data_ptr(), n)
+        a, ai = backend.partials_sum(curve.cid, batch[j:j + 1])
+        b, bi = backend.partials_sum(curve.cid, single.reshape(1, -1))
+        assert ai == bi and (a == b).all(), j
+    exp, einf = ol.oracle_msm_g1(curve, B, vecs[0], algo=0, threads=8)
+    got, inf = backend.partials_sum(curve.cid, batch[0:1])
+    backend.bases_free(h)
+    assert inf == einf and (got == exp).all()
