@@ -233,10 +233,19 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             if (hipSetDevice(aux->device) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
             rc_g2 = ZL_DISPATCH(curve, ZL_G2, zl_msm_run, aux, *b2, 1, zc + 32, nv - 1, out2);
         });
-        rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[2], 0, d_h, (size_t)N - 1, part[2]);
-        if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[3], 0, zc + (size_t)ni * 32, nw, part[3]);
-        if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[0], 1, zc + 32, nv - 1, part[0]);
-        if (!rc) rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run, ctx, *bs[1], 1, zc + 32, nv - 1, part[1]);
+        // the four G1 MSMs as one pipeline (sort | accumulate | tail of consecutive MSMs overlap, zl_msm.hip): h, l, a, b1
+        {
+            const zl_bases* jb[4] = {bs[2], bs[3], bs[0], bs[1]};
+            const size_t jf[4] = {0, 0, 1, 1};
+            const void* js[4] = {d_h, zc + (size_t)ni * 32, zc + 32, zc + 32};
+            const size_t jn[4] = {(size_t)N - 1, (size_t)nw, (size_t)nv - 1, (size_t)nv - 1};
+            uint64_t jp[4][ZL_PARTIAL_WORDS];
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, 4, &jp[0][0]);
+            memcpy(part[2], jp[0], sizeof jp[0]);
+            memcpy(part[3], jp[1], sizeof jp[1]);
+            memcpy(part[0], jp[2], sizeof jp[2]);
+            memcpy(part[1], jp[3], sizeof jp[3]);
+        }
         g2.join();
     }
     pre.join();

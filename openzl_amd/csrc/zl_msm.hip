@@ -1024,6 +1024,34 @@ struct MsmJob {
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
         return ZL_OK;
     }
+    // sizes of the sort temporaries (slots 5 and 6), as sort() requests them: a heterogeneous pipeline grows the slots to the
+    // largest job before anything is in flight (a growing zl_scratch_get frees the old block)
+    void sort_tmp_sizes(size_t& s5, size_t& s6) const {
+        s5 = s6 = 0;
+        if (pre) {
+            const uint32_t Gn = H >> 15;
+            uint32_t nslices = 64;
+            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+            if (nslices > max_slices) nslices = max_slices;
+            const uint32_t P = Gn * W * nslices;
+            const uint32_t pscan_blocks = (P + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            const size_t b_lo = (((size_t)n * W * 2 + 255) / 256) * 256, b_hi = (((size_t)n * W + 255) / 256) * 256;
+            const size_t b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
+            const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256;
+            s5 = b_lo + b_hi + b_lo + b_pidx + b_pc + 256;
+            uint32_t fsl = 16;
+            while (fsl * Gn < 2048 && fsl < 128) fsl *= 2;
+            const uint32_t P2 = Gn * 128 * fsl;
+            const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            s6 = b_lo + b_pidx + (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256 + 256;
+        } else if (c <= 16) {
+            uint32_t nslices = (256 + W - 1) / W;
+            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+            if (nslices > max_slices) nslices = max_slices;
+            if (nslices < 1) nslices = 1;
+            s5 = (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256;
+        }
+    }
     int sort(zl_ctx* ctx, hipStream_t st) {
         const zl_bases& bs = *bsp;
         int rc;
@@ -1210,14 +1238,22 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
 // (stream_tail).  Three buffer sets rotate; a set is reused when the tail that reads it has finished.  The sort and tail phases are
 // memory- / latency-bound and fit into the issue slots the compute-bound accumulation leaves, so in steady state an MSM costs its
 // accumulation kernel only.
+struct MsmSpec {
+    const zl_bases* bs;
+    size_t first;
+    const void* d_scalars;
+    size_t n;
+};
 template <class G>
-static int msm_run_batch_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
+static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials) {
     using X = XYZZ<typename G::F>;
     ctx->timing = zl_timing{};
     if (count == 0) return ZL_OK;
-    if (n == 0 || count == 1) {
+    bool any_empty = false;
+    for (size_t i = 0; i < count; i++) any_empty = any_empty || specs[i].n == 0;
+    if (any_empty || count == 1) {
         for (size_t i = 0; i < count; i++) {
-            int rc = msm_run_t<G>(ctx, bs, first, d_scalars[i], n, out_partials + i * ZL_PARTIAL_WORDS);
+            int rc = msm_run_t<G>(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, out_partials + i * ZL_PARTIAL_WORDS);
             if (rc) return rc;
         }
         return ZL_OK;
@@ -1231,16 +1267,28 @@ static int msm_run_batch_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const 
         ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_tail, hipStreamNonBlocking, prio_hi));
     }
     std::vector<MsmJob<G>> jobs(count);
+    size_t t5 = 0, t6 = 0;
+    uint32_t max_sets = 0;
     for (size_t i = 0; i < count; i++) {
-        if ((rc = jobs[i].plan(ctx, bs, first, d_scalars[i], n))) return rc;
+        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n))) return rc;
+        size_t a5, a6;
+        jobs[i].sort_tmp_sizes(a5, a6);
+        t5 = std::max(t5, a5);
+        t6 = std::max(t6, a6);
+        max_sets = std::max(max_sets, jobs[i].SETS);
     }
-    // all buffer sets up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i.  Three sets:
-    // the tail of job i runs beside the accumulation of job i+1 and is slow there, so the sort of job i+2 must not have to wait for it.
-    for (size_t i = 0; i < count; i++) {
-        if ((rc = jobs[i].alloc(ctx, (int)(i % 3)))) return rc;
+    // all buffers up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i: the first pass
+    // grows every slot to its largest user, the second binds the final pointers.  Three sets: the tail of job i runs beside the
+    // accumulation of job i+1 and is slow there, so the sort of job i+2 must not have to wait for it.
+    void* dummy;
+    if (t5 && (rc = zl_scratch_get(ctx, 5, t5, &dummy))) return rc;
+    if (t6 && (rc = zl_scratch_get(ctx, 6, t6, &dummy))) return rc;
+    for (int pass = 0; pass < 2; pass++) {
+        for (size_t i = 0; i < count; i++) {
+            if ((rc = jobs[i].alloc(ctx, (int)(i % 3)))) return rc;
+        }
     }
-    const uint32_t SETS = jobs[0].SETS;
-    const size_t per = sizeof(X) * (SETS + 1) + 16;
+    const size_t per = sizeof(X) * (max_sets + 1) + 16;
     if (ctx->pinned_cap < per * count) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
@@ -1251,7 +1299,7 @@ static int msm_run_batch_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const 
     for (size_t i = 0; i < count; i++) {
         unsigned char* base = reinterpret_cast<unsigned char*>(ctx->pinned) + per * i;
         jobs[i].hw = reinterpret_cast<X*>(base);
-        jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (SETS + 1));
+        jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (max_sets + 1));
     }
     hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
     std::vector<hipEvent_t> ev_sorted(count), ev_acc(count), ev_tail(count), ev_acc0(ctx->timing_on ? count : 0);
@@ -1349,7 +1397,16 @@ static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
 int ZL_GNAME(zl_bases_precompute)(zl_ctx* ctx, zl_bases& b, int c) { return bases_precompute_t<ZL_G>(ctx, b, c); }
 
 int ZL_GNAME(zl_msm_run_batch)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
-    return msm_run_batch_t<ZL_G>(ctx, b, first, d_scalars, n, count, out_partials);
+    std::vector<MsmSpec> specs(count);
+    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{&b, first, d_scalars[i], n};
+    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials);
+}
+// heterogeneous pipeline: job i = (bases[i], first[i], d_scalars[i], n[i]) (Groth16: the four G1 MSMs of one proof)
+int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, size_t count,
+                              uint64_t* out_partials) {
+    std::vector<MsmSpec> specs(count);
+    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{bases[i], first[i], d_scalars[i], n[i]};
+    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials);
 }
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);
