@@ -1,5 +1,7 @@
 """Randomised parity sweep of the MSM paths (plain / forced window / precomputed table, uniform and skewed scalars, infinity
 bases, duplicated points) against the CPU oracle.  Sizes are small so that the oracle stays fast; seeds are fixed."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,7 +31,7 @@ def _case(curve, rng, n):
     return B, S
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ZL_FUZZ_SEEDS", "12"))))  # ZL_FUZZ_SEEDS=200 for a longer soak
 def test_msm_fuzz(backend, seed):
     rng = np.random.default_rng(1000 + seed)
     curve = po.BLS12_381 if seed % 3 else po.BN254
