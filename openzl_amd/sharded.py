@@ -131,17 +131,21 @@ def sharded_ntt(engine, local, log_n: int, inverse: bool = False, coset: bool = 
     base = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0)
     plain = ZL_INVERSE if inverse else 0
     out = torch.empty_like(local)
-    if not inverse:
-        engine.cross(local, log_n, log_g, rank, base | (ZL_MONT if mont else ZL_MONT_OUT))
+
+    def exchange():
+        # the legs run on the backend's stream, the collective on torch's: fence on both sides of it
         engine.sync()
         dist.all_to_all_single(out.view(-1), local.view(-1), group=group)
+        if out.is_cuda:
+            torch.cuda.current_stream(out.device).synchronize()
+
+    if not inverse:
+        engine.cross(local, log_n, log_g, rank, base | (ZL_MONT if mont else ZL_MONT_OUT))
+        exchange()
         engine.local(out, log_n - log_g, plain | (ZL_MONT if mont else ZL_MONT_IN))
     else:
         engine.local(local, log_n - log_g, plain | (ZL_MONT if mont else ZL_MONT_OUT))
-        engine.sync()
-        dist.all_to_all_single(out.view(-1), local.view(-1), group=group)
+        exchange()
         engine.cross(out, log_n, log_g, rank, base | (ZL_MONT if mont else ZL_MONT_IN))
-    if out.is_cuda:
-        torch.cuda.current_stream(out.device).synchronize()  # the collective ran on torch's stream, the legs on the ctx stream
     engine.sync()
     return out
