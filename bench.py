@@ -223,7 +223,7 @@ def main():
     k = random_scalars_lt_r(n, 1000 + rank)          # discrete logs of the bases: P_i = k_i * G (device generator)
     h = be.bases_generate(ZL_BLS12_381, k)
     pre_c = args.precompute if args.precompute >= 0 and not args.window else -1
-    if pre_c >= 0 and args.log_n < 20:
+    if pre_c >= 0 and args.log_n < 24:
         pre_c = 0  # let the library pick c for small inputs
     if pre_c >= 0:
         be.bases_precompute(h, pre_c)
