@@ -54,13 +54,16 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
-    if (ctx->aux) {
-        (void)hipStreamSynchronize(ctx->aux->stream);
-        for (auto& sc : ctx->aux->scratch) if (sc.p) (void)hipFree(sc.p);
-        for (auto& ev : ctx->aux->ev) if (ev) (void)hipEventDestroy(ev);
-        if (ctx->aux->own_stream) (void)hipStreamDestroy(ctx->aux->own_stream);
-        delete ctx->aux;
-        ctx->aux = nullptr;
+    for (zl_ctx** ax : {&ctx->aux, &ctx->aux2}) {
+        zl_ctx* a = *ax;
+        if (!a) continue;
+        (void)hipStreamSynchronize(a->stream);
+        for (auto& sc : a->scratch) if (sc.p) (void)hipFree(sc.p);
+        zl_ntt_free(a);
+        for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);
+        if (a->own_stream) (void)hipStreamDestroy(a->own_stream);
+        delete a;
+        *ax = nullptr;
     }
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -103,6 +103,7 @@ struct zl_ctx {
     hipStream_t stream_sort = nullptr, stream_tail = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     void* pinned = nullptr;  // pinned host staging for pipelined results
     size_t pinned_cap = 0;
+    zl_ctx* aux2 = nullptr;  // second auxiliary context (Groth16: the witness map runs beside the witness-only MSMs)
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 7)
     size_t g16_h_n = 0;
@@ -132,7 +133,7 @@ inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
 #define ZL_DECL_GROUP(G)                                                                                                   \
     int zl_msm_run_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial); \
     int zl_msm_run_batch_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials); \
-    int zl_msm_run_jobs_##G(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, size_t count, uint64_t* out_partials); \
+    int zl_msm_run_jobs_##G(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait, size_t count, uint64_t* out_partials); \
     int zl_partial_to_affine_##G(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf);                              \
     int zl_partials_fold_##G(const uint64_t* partials, size_t count, uint64_t* out_partial);                                \
     int zl_partial_from_affine_##G(const uint64_t* xy, uint64_t* out_partial);                                \

@@ -168,45 +168,56 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     }
     Fr *d_a = (Fr*)(d + off_a), *d_b = (Fr*)(d + off_b), *d_c = (Fr*)(d + off_c), *d_h = (Fr*)(d + off_h);
     Fr* dv[3] = {d_a, d_b, d_c};
+    // ---- witness map on its own context / stream: spmv, 3 x (ifft, coset fft), pointwise, coset ifft -> h -------------------------
+    // It only needs z, like four of the five MSMs, so it runs beside them (memory- and latency-bound kernels in the shadow of the
+    // bucket accumulation); the h MSM waits for ev_h inside the pipeline.
+    for (zl_ctx** ax : {&ctx->aux, &ctx->aux2}) {
+        if (*ax) continue;
+        zl_ctx* a = new (std::nothrow) zl_ctx();
+        if (!a) return ZL_ENOMEM;
+        a->device = ctx->device;
+        // aux (G2 MSM): lowest priority, its long accumulate kernel must not starve the short kernels of the other streams (measured: a
+        // 5 us G1 kernel waited 13 ms behind it at equal priority); aux2 (witness map): highest, h gates the last MSM
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? prio_lo : prio_hi);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
+        a->stream = a->own_stream;
+        *ax = a;  // owned by ctx from here on (zl_ctx_destroy)
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+    }
+    zl_ctx* wm = ctx->aux2;
+    hipStream_t s_wm = wm->stream;
+    hipEvent_t ev_z = wm->ev[0], ev_h = wm->ev[1];
+    ZL_HIP(ctx, hipEventRecord(ev_z, st));
+    ZL_HIP(ctx, hipStreamWaitEvent(s_wm, ev_z, 0));
     for (int m = 0; m < 3; m++)
-        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
+        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
                            (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
     ZL_HIP(ctx, hipGetLastError());
-    // ---- witness map: 3 x (ifft, coset fft), pointwise, coset ifft --------------------------------------------------
     const int timing_saved = ctx->timing_on;
     ctx->timing_on = 0;  // inner calls must not sync / overwrite the prover's events
+    wm->timing_on = 0;
+    auto wm_fail = [&](int code) { (void)hipStreamSynchronize(s_wm); ctx->timing_on = timing_saved; return code; };
     for (int m = 0; m < 3; m++) {
-        if ((rc = zl_ntt_run(ctx, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) { ctx->timing_on = timing_saved; return rc; }
-        if ((rc = zl_ntt_run(ctx, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) { ctx->timing_on = timing_saved; return rc; }
+        if ((rc = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) return wm_fail(rc);
+        if ((rc = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) return wm_fail(rc);
     }
     Fr g;
     for (int i = 0; i < Fr::N; i++) g.l[i] = FrP::generator(i);
     Fr gN = g;
     for (unsigned i = 0; i < log_n; i++) gN = zl::sqr(gN);
     const Fr zinv = zl::inv(zl::sub(gN, Fr::one()));
-    hipLaunchKernelGGL((k_qap_pointwise<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, d_a, d_b, d_c, zinv, N);
-    if ((rc = zl_ntt_run(ctx, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE | ZL_COSET))) { ctx->timing_on = timing_saved; return rc; }
-    hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((N + 255) / 256), dim3(256), 0, st, d_a, d_h, N);
-    ZL_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((k_qap_pointwise<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_b, d_c, zinv, N);
+    if ((rc = zl_ntt_run(wm, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE | ZL_COSET))) return wm_fail(rc);
+    hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_h, N);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(ev_h, s_wm) != hipSuccess) return wm_fail(ZL_EHIP);
     // ---- the five MSMs ----------------------------------------------------------------------------------------------
     uint64_t part[5][ZL_PARTIAL_WORDS];
     const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
     // The G2 MSM (Fq2: one wave per SIMD, half of the issue slots idle) runs on an auxiliary stream with its own scratch
     // while the four G1 MSMs run on the main stream: the two streams fill each other's gaps (54 -> ~35 ms at 2^20).
-    ZL_HIP(ctx, hipStreamSynchronize(st));  // z / h are complete before the second stream reads them
-    if (!ctx->aux) {
-        ctx->aux = new (std::nothrow) zl_ctx();
-        if (!ctx->aux) return ZL_ENOMEM;
-        ctx->aux->device = ctx->device;
-        // lowest priority: the long G2 accumulate kernel must not starve the short kernels of the main stream (measured: a 5 us
-        // G1 kernel waited 13 ms behind it at equal priority)
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hipError_t e = hipStreamCreateWithPriority(&ctx->aux->own_stream, hipStreamNonBlocking, prio_lo);
-        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->aux->ev[i]);
-        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
-        ctx->aux->stream = ctx->aux->own_stream;
-    }
+    ZL_HIP(ctx, hipStreamSynchronize(st));  // z is complete before the other streams / threads read it
     // host work that does not depend on the MSMs (r*delta1, s*delta1, r*s*delta1, s*delta2: ~1300 group operations) runs on a third
     // thread while the device is busy
     uint32_t rw[8], sw[8];
@@ -233,19 +244,22 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             if (hipSetDevice(aux->device) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
             rc_g2 = ZL_DISPATCH(curve, ZL_G2, zl_msm_run, aux, *b2, 1, zc + 32, nv - 1, out2);
         });
-        // the four G1 MSMs as one pipeline (sort | accumulate | tail of consecutive MSMs overlap, zl_msm.hip): h, l, a, b1
+        // the four G1 MSMs as one pipeline (sort | accumulate | tail of consecutive MSMs overlap, zl_msm.hip): l, a, b1 need only z;
+        // the h job waits for the witness map's event
         {
-            const zl_bases* jb[4] = {bs[2], bs[3], bs[0], bs[1]};
-            const size_t jf[4] = {0, 0, 1, 1};
-            const void* js[4] = {d_h, zc + (size_t)ni * 32, zc + 32, zc + 32};
-            const size_t jn[4] = {(size_t)N - 1, (size_t)nw, (size_t)nv - 1, (size_t)nv - 1};
+            const zl_bases* jb[4] = {bs[3], bs[0], bs[1], bs[2]};
+            const size_t jf[4] = {0, 1, 1, 0};
+            const void* js[4] = {zc + (size_t)ni * 32, zc + 32, zc + 32, d_h};
+            const size_t jn[4] = {(size_t)nw, (size_t)nv - 1, (size_t)nv - 1, (size_t)N - 1};
+            const hipEvent_t jw[4] = {nullptr, nullptr, nullptr, ev_h};
             uint64_t jp[4][ZL_PARTIAL_WORDS];
-            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, 4, &jp[0][0]);
-            memcpy(part[2], jp[0], sizeof jp[0]);
-            memcpy(part[3], jp[1], sizeof jp[1]);
-            memcpy(part[0], jp[2], sizeof jp[2]);
-            memcpy(part[1], jp[3], sizeof jp[3]);
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0]);
+            memcpy(part[3], jp[0], sizeof jp[0]);
+            memcpy(part[0], jp[1], sizeof jp[1]);
+            memcpy(part[1], jp[2], sizeof jp[2]);
+            memcpy(part[2], jp[3], sizeof jp[3]);
         }
+        (void)hipStreamSynchronize(s_wm);  // also on the error path: nothing of this proof may still be running
         g2.join();
     }
     pre.join();

@@ -1243,6 +1243,7 @@ struct MsmSpec {
     size_t first;
     const void* d_scalars;
     size_t n;
+    hipEvent_t wait;  // optional: the scalars of this job are ready when this event (recorded on another stream) has fired
 };
 template <class G>
 static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials) {
@@ -1253,6 +1254,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     for (size_t i = 0; i < count; i++) any_empty = any_empty || specs[i].n == 0;
     if (any_empty || count == 1) {
         for (size_t i = 0; i < count; i++) {
+            if (specs[i].wait) ZL_HIP(ctx, hipEventSynchronize(specs[i].wait));
             int rc = msm_run_t<G>(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, out_partials + i * ZL_PARTIAL_WORDS);
             if (rc) return rc;
         }
@@ -1329,6 +1331,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
     for (size_t i = 0; i < count && he == hipSuccess && rc == ZL_OK; i++) {
         if (i >= 3) he = hipStreamWaitEvent(s_sort, ev_tail[i - 3], 0);  // buffer set i % 3 is free again
+        if (he == hipSuccess && specs[i].wait) he = hipStreamWaitEvent(s_sort, specs[i].wait, 0);
         if (he != hipSuccess) break;
         if ((rc = jobs[i].sort(ctx, s_sort))) break;
         he = hipEventRecord(ev_sorted[i], s_sort);
@@ -1398,14 +1401,14 @@ int ZL_GNAME(zl_bases_precompute)(zl_ctx* ctx, zl_bases& b, int c) { return base
 
 int ZL_GNAME(zl_msm_run_batch)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
     std::vector<MsmSpec> specs(count);
-    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{&b, first, d_scalars[i], n};
+    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{&b, first, d_scalars[i], n, nullptr};
     return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials);
 }
 // heterogeneous pipeline: job i = (bases[i], first[i], d_scalars[i], n[i]) (Groth16: the four G1 MSMs of one proof)
-int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, size_t count,
-                              uint64_t* out_partials) {
+int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n,
+                              const hipEvent_t* wait, size_t count, uint64_t* out_partials) {
     std::vector<MsmSpec> specs(count);
-    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{bases[i], first[i], d_scalars[i], n[i]};
+    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{bases[i], first[i], d_scalars[i], n[i], wait ? wait[i] : nullptr};
     return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials);
 }
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
