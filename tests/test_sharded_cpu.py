@@ -22,6 +22,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
+    import numpy as np
     import torch.distributed as dist
 
     import oracle_lib as ol
@@ -46,6 +47,19 @@ def _worker(rank, world, port, q):
     xy, inf = sharded_msm(local_partial, curve.cid)
     full, finf = ol.oracle_msm_g1(curve, B, S, 0, 1)
     ok = bool((xy == full).all() and inf == finf)
+    # K steps per rank folded after ONE gather (what bench.py's pipelined batch does): step j uses the scalars rotated by j
+    from openzl_amd.sharded import sharded_msm_batch
+
+    K = 3
+    parts, fulls = [], []
+    for j in range(K):
+        Sj = np.roll(S, j, axis=0)
+        pxy, pinf = ol.oracle_msm_g1(curve, B[lo:hi], Sj[lo:hi], 0, 1)
+        parts.append(_partial_from_affine(curve, ol.limbs_to_point(curve, pxy, pinf)))
+        fulls.append(ol.oracle_msm_g1(curve, B, Sj, 0, 1))
+    res = sharded_msm_batch(np.stack(parts), curve.cid)
+    for (gxy, ginf), (fxy, finf2) in zip(res, fulls):
+        ok = ok and bool((gxy == fxy).all() and ginf == finf2)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
