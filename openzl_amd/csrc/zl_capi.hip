@@ -59,6 +59,9 @@ void zl_ctx_destroy(zl_ctx* ctx) {
         if (!a) continue;
         (void)hipStreamSynchronize(a->stream);
         for (auto& sc : a->scratch) if (sc.p) (void)hipFree(sc.p);
+        if (a->stream_sort) (void)hipStreamDestroy(a->stream_sort);
+        if (a->stream_tail) (void)hipStreamDestroy(a->stream_tail);
+        if (a->pinned) (void)hipHostFree(a->pinned);
         zl_ntt_free(a);
         for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);
         if (a->own_stream) (void)hipStreamDestroy(a->own_stream);
