@@ -1,5 +1,6 @@
 // zl_host.hip -- implementation of the host-side plugin mirror (zl_host.h) + its C-ABI hooks (include/zl_backend.h,
 // "host mirror" section).  Host code only; compiled by hipcc because it shares zl_field.h with the kernels.
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "zl_host.h"
@@ -139,6 +140,17 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G2, eb.data(), nv, &pc.b_g2_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eh.data(), N - 1, &pc.h_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, el.data(), nw, &pc.l_query);
+    // Window tables for the queries of a large proving key (static per circuit, like the key itself): the five MSMs of every proof then
+    // run on one merged bucket set each.  Measured at N = 2^20 (958 465 constraints): prove 33.5 -> 29.2 ms with c = 20 for the G1
+    // queries (13 windows) and c = 16 for the G2 query; c = 19 / 21 are worse (14 windows / twice the buckets for the same 13).
+    // Memory: 13 x 128 B per G1 point, 16 x 256 B per G2 point (about 11 GB for this key).  Small keys stay on the plain path.
+    if (!rc) {
+        const size_t big = (size_t)1 << 19;
+        const struct { uint64_t h; size_t n; int c; } q[5] = {
+            {pc.a_query, (size_t)nv, 20}, {pc.b_g1_query, (size_t)nv, 20}, {pc.h_query, (size_t)N - 1, 20}, {pc.l_query, (size_t)nw, 20}, {pc.b_g2_query, (size_t)nv, 16}};
+        for (const auto& e : q)
+            if (!rc && e.n >= big) rc = zl_bases_precompute(ctx, e.h, e.c);
+    }
     if (!rc) {
         R1csExport<FrP> ex;
         ex.build(cs);

@@ -68,3 +68,25 @@ def test_proof_system_compile_prove_verify(backend, curve):
     finally:
         keys.close()
         circ.close()
+
+
+@pytest.mark.gpu
+def test_large_key_uses_window_tables_and_still_verifies(backend):
+    """A key above 2^19 variables: Groth16::compile builds window tables for all five queries (merged bucket sets, sub-range first = 1);
+    the proof must verify, a tampered public input must not, and the proof must be reproducible."""
+    curve = po.BLS12_381
+    circ = Circuit(curve.cid, 2300)  # 538 201 constraints, domain 2^20
+    keys = Groth16Keys(backend, circ, seed=0x5EED)
+    try:
+        assert circ.shape[0] > (1 << 19)
+        proof, r, s = keys.prove(seed=5)
+        again, _, _ = keys.prove(seed=5)
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(proof, again))
+        pub = circ.arrays()["assignment"][1:2]
+        assert keys.verify(proof, pub) is True
+        bad = pub.copy()
+        bad[0, 0] ^= np.uint64(1)
+        assert keys.verify(proof, bad) is False
+    finally:
+        keys.close()
+        circ.close()
