@@ -911,8 +911,10 @@ static int zl_pick_window(size_t n, int sc_bits) {
 
 static int zl_pick_window_precomp(size_t n, int sc_bits) {
     // merged windows: n*W mixed adds + ONE bucket set of 2^(c-1) buckets (merge + reduce ~6 add-equivalents per bucket)
-    // measured at 2^20: c = 16 and c = 20 tie (4.9 ms), 17..19 are slower (half-filled staging blocks); below 2^21 keep one group
-    if (n < ((size_t)1 << 21)) return 16;
+    // measured at 2^20: c = 16 and c = 20 tie for a single call (4.9 ms), 17..19 are slower (half-filled staging blocks), and inside a
+    // pipeline (Groth16's five MSMs) c = 20 wins clearly: fewer additions, and the larger sort / tail are hidden
+    if (n < (size_t)700000) return 16;
+    if (n < ((size_t)1 << 21)) return 20;
     double best = 1e300;
     int best_c = 16;
     for (int c = 20; c <= 23; c++) {
