@@ -9,6 +9,7 @@
 // The R1CS arrives already synthesised (the reference moves a pre-built constraint system into arkworks the same way,
 // plugins/arkworks/src/constraint/mod.rs:179-197); sparse mat-vec, pointwise ops and Montgomery entry/exit are small
 // elementwise kernels around zl_ntt_run / zl_msm_run; the window Horner and the final few group operations run on host.
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -176,11 +177,12 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         zl_ctx* a = new (std::nothrow) zl_ctx();
         if (!a) return ZL_ENOMEM;
         a->device = ctx->device;
-        // aux (G2 MSM): lowest priority, its long accumulate kernel must not starve the short kernels of the other streams (measured: a
-        // 5 us G1 kernel waited 13 ms behind it at equal priority); aux2 (witness map): highest, h gates the last MSM
+        // aux (G2 MSM): default priority, like the G1 accumulation stream (the short sort / tail kernels of both run on highest-priority
+        // streams, so nothing waits behind the long G2 accumulate any more; lowest priority measured 1 ms slower); aux2 (witness map):
+        // highest, h gates the last MSM
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? prio_lo : prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : prio_hi);
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
         a->stream = a->own_stream;
         *ax = a;  // owned by ctx from here on (zl_ctx_destroy)
