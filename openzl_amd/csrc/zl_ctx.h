@@ -69,6 +69,7 @@ struct zl_bases {
     int precomp_c = 0;
     size_t n = 0;
     int curve = 0, group = 0;
+    mutable std::vector<uint64_t> first_xy;  // canonical affine words of point 0, fetched once (Groth16: the z_0 = 1 term of a / b queries)
 };
 struct zl_scratch {
     void* p = nullptr;

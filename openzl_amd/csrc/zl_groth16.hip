@@ -270,9 +270,19 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     if (rc) return rc;
     // first points of the a / b queries (index 0 pairs with z[0] = 1)
     uint64_t a0_xy[12], b0_xy[12], b20_xy[24];
-    if ((rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_bases_download, ctx, *bs[0], 0, 1, a0_xy))) return rc;
-    if ((rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_bases_download, ctx, *bs[1], 0, 1, b0_xy))) return rc;
-    if ((rc = ZL_DISPATCH(pk->curve, ZL_G2, zl_bases_download, ctx, *bs[4], 0, 1, b20_xy))) return rc;
+    {
+        // static per key: fetched from the device on the first proof only
+        const struct { const zl_bases* b; int group; uint64_t* out; size_t words; } firsts[3] = {
+            {bs[0], ZL_G1, a0_xy, 12}, {bs[1], ZL_G1, b0_xy, 12}, {bs[4], ZL_G2, b20_xy, 24}};
+        for (const auto& f : firsts) {
+            if (f.b->first_xy.empty()) {
+                uint64_t tmp[24] = {0};
+                if ((rc = ZL_DISPATCH(pk->curve, f.group, zl_bases_download, ctx, *f.b, 0, 1, tmp))) return rc;
+                f.b->first_xy.assign(tmp, tmp + f.words);
+            }
+            memcpy(f.out, f.b->first_xy.data(), f.words * 8);
+        }
+    }
     if (ctx->timing_on) {
         ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         ZL_HIP(ctx, hipStreamSynchronize(st));
