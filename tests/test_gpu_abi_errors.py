@@ -73,3 +73,39 @@ def test_groth16_rejects_mismatched_handles(backend):
         backend.bases_free(short["h_query"])
     finally:
         gu.free_pk(backend, dpk)
+
+
+def test_batch_edge_cases(backend):
+    """zl_msm_batch_partial_dev: empty batch, empty MSMs, a single job, bad handle / range / null scalars -- return codes only."""
+    import torch
+
+    curve = po.BLS12_381
+    n = 300
+    k = ol.random_scalars(curve, n, 3)
+    S = ol.random_scalars(curve, n, 4)
+    h = backend.bases_generate(curve.cid, k)
+    d = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    assert backend.msm_batch_partial_dev(h, [], n).shape == (0, 64)                       # count = 0
+    empty = backend.msm_batch_partial_dev(h, [d.data_ptr()] * 3, 0)                         # n = 0: three points at infinity
+    for j in range(3):
+        assert backend.partials_sum(curve.cid, empty[j:j + 1])[1] == 1
+    one = backend.msm_batch_partial_dev(h, [d.data_ptr()], n)                               # a batch of one = a single call
+    exp = ol.oracle_msm_g1(curve, ol.oracle_g1_mul_gen(curve, k), S)
+    got = backend.partials_sum(curve.cid, one)
+    assert got[1] == exp[1] and (got[0] == exp[0]).all()
+    sub = backend.msm_batch_partial_dev(h, [d.data_ptr()] * 4, 100, first=50)               # sub-range, four jobs
+    e2 = ol.oracle_msm_g1(curve, ol.oracle_g1_mul_gen(curve, k)[50:150], S[:100])
+    for j in range(4):
+        g2 = backend.partials_sum(curve.cid, sub[j:j + 1])
+        assert g2[1] == e2[1] and (g2[0] == e2[0]).all()
+    with pytest.raises(BackendError) as e:
+        backend.msm_batch_partial_dev(h, [d.data_ptr()] * 2, n, first=10)                   # range runs past the end
+    assert e.value.code == EINVAL
+    with pytest.raises(BackendError) as e:
+        backend.msm_batch_partial_dev(h, [d.data_ptr(), 0], n)                              # a null scalar vector
+    assert e.value.code == EINVAL
+    with pytest.raises(BackendError) as e:
+        backend.msm_batch_partial_dev(987654, [d.data_ptr()], n)
+    assert e.value.code == EHANDLE
+    backend.bases_free(h)
