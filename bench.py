@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-FQ_MUL_PEAK_G = 66.8  # measured: tools/fbench28.hip, 2 waves/SIMD, MI355X (profiles/r01_fbench_field_mul.log)
+FQ_MUL_PEAK_G = 74.3  # measured: the multiplier of zl_field28.h alone, 2 waves/SIMD, MI355X (tools/fbench28_asm.hip, profiles/r01_fbench_field_mul_asm.log)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
@@ -482,7 +482,7 @@ def main():
                                      "frac": float(tm.entries) * 9.5 / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
                                      "note": "the roofline that actually binds: (point, window) pairs x 9.5 multiplication-equivalents per mixed add "
                                              "(8M + 2S = 10 product scans, two of them sharing one Montgomery reduction: 3724 mads = 9.5 x 392) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
-                                             "at the kernel's occupancy (tools/fbench28.hip; profiles/r01_fbench_field_mul.log)"},
+                                             "at the kernel's occupancy (tools/fbench28_asm.hip; profiles/r01_fbench_field_mul_asm.log)"},
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
