@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-FQ_MUL_PEAK_G = 74.3  # measured: the multiplier of zl_field28.h alone, 2 waves/SIMD, MI355X (tools/fbench28_asm.hip, profiles/r01_fbench_field_mul_asm.log)
+FQ_MUL_PEAK_G = 74.3  # measured: the multiplier of zl_field28.h alone, 2 waves/SIMD, MI355X (71.6 - 74.3 over two boxes of the pool; the higher one) (tools/fbench28_asm.hip, profiles/r01_fbench_field_mul_asm.log)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
