@@ -16,7 +16,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 FLAGS += [f for f in os.environ.get("ZL_EXTRA_FLAGS", "").split() if f]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
-HEADERS = ["zl_field.h", "zl_field28.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_ctx.h", "zl_host.h", "zl_pairing.h", "zl_serialize.h", os.path.join("..", "..", "include", "zl_backend.h")]
+HEADERS = ["zl_field.h", "zl_field28.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_mul28_gfx950.h", "zl_ctx.h", "zl_host.h", "zl_pairing.h", "zl_serialize.h", os.path.join("..", "..", "include", "zl_backend.h")]
 
 
 def _hipcc() -> str:

@@ -91,7 +91,7 @@ template <class B, bool I> ZL_HD Fp2LT<B, I> wred(const Fp2LT<B, I>& a) { return
 template <class B, bool I> ZL_HD Fp2LT<B, I> canon(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{canon(a.c0), canon(a.c1)}; }
 template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> mul(const Fp2LT<Fp28<A, P>, I>& a, const Fp2LT<Fp28<A, P>, I>& b) {
     if constexpr (I) {
-        return Fp2LT<Fp28<A, P>, I>{muladd_body28(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd_body28(a.c0, b.c1, a.c1, b.c0)};
+        return Fp2LT<Fp28<A, P>, I>{muladd(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
     } else {
         Fp2LT<Fp28<A, P>, I> r;
         unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
@@ -100,7 +100,7 @@ template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> mul(const Fp2LT<F
 }
 template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> sqr(const Fp2LT<Fp28<A, P>, I>& a) {
     if constexpr (I) {
-        return Fp2LT<Fp28<A, P>, I>{mul_body28(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul_body28(dbl(a.c0), a.c1)};
+        return Fp2LT<Fp28<A, P>, I>{mul(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
     } else {
         Fp2LT<Fp28<A, P>, I> r;
         unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);

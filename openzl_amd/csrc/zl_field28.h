@@ -15,6 +15,7 @@
 // intermediate.  Memory / ABI formats are unchanged: load_* / store_* convert from / to arkworks' 32-bit-word layouts.
 #pragma once
 #include "zl_field.h"
+#include "zl_mul28_gfx950.h"  // single-chain inline-asm product scans for 14 limbs (device only; gen_mul28.py)
 
 template <class P28, class P32>
 struct alignas(16) Fp28 {
@@ -203,6 +204,13 @@ ZL_NOINLINE_HD Fp28<A, B> muladd_call28(Fp28<A, B> a, Fp28<A, B> b, Fp28<A, B> c
 // a*b + c*d (Montgomery), needs B(a) B(b) + B(c) B(d) <= 2500 -> < 2q
 template <class A, class B>
 ZL_HD Fp28<A, B> muladd(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, B>& c, const Fp28<A, B>& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_ASM_MUL28)
+    if constexpr (A::L == 14) {
+        Fp28<A, B> r = a;
+        muladd28_asm<A>(r.l, a.l, b.l, c.l, d.l);
+        return r;
+    }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_INLINE_MUL28)
     return muladd_body28(a, b, c, d);
 #else
@@ -215,6 +223,13 @@ ZL_NOINLINE_HD Fp28<A, B> mul_call28(Fp28<A, B> a, Fp28<A, B> b) {
 }
 template <class A, class B>
 ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_ASM_MUL28)
+    if constexpr (A::L == 14) {
+        Fp28<A, B> r = a;
+        mul28_asm<A>(r.l, a.l, b.l);
+        return r;
+    }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_INLINE_MUL28)
     return mul_body28(a, b);  // device: inline (4 KB per site, a mixed addition stays inside the instruction cache)
 #else
@@ -223,6 +238,13 @@ ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
 }
 template <class A, class B>
 ZL_HD Fp28<A, B> sqr(const Fp28<A, B>& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_ASM_MUL28)
+    if constexpr (A::L == 14) {
+        Fp28<A, B> r = a;
+        sqr28_asm<A>(r.l, a.l);
+        return r;
+    }
+#endif
     return mul(a, a);
 }
 // weak reduction: value < 2000 q -> < 4q.  t = floor(top_limb * floor(2^44 / (qtop+1)) / 2^44) <= floor(a / q), short by <= 2
@@ -368,13 +390,13 @@ ZL_NOINLINE_HD Pair28 fq2_mul_call28(ZL_P14(wa), ZL_P14(wb), ZL_P14(wc), ZL_P14(
     Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
     ZL_S14(a0, wa); ZL_S14(a1, wb); ZL_S14(b0, wc); ZL_S14(b1, wd);
     const Fp28<A, B> nb1 = negk<4>(b1);
-    return pair28(muladd_body28(a0, b0, a1, nb1), muladd_body28(a0, b1, a1, b0));
+    return pair28(muladd(a0, b0, a1, nb1), muladd(a0, b1, a1, b0));
 }
 template <class A, class B>
 ZL_NOINLINE_HD Pair28 fq2_sqr_call28(ZL_P14(wa), ZL_P14(wb)) {  // (a + b u)^2 = (a + b)(a - b) + 2ab u, components < 16q
     Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0;
     ZL_S14(a0, wa); ZL_S14(a1, wb);
-    return pair28(mul_body28(add(a0, a1), subk<4>(a0, a1)), mul_body28(dbl(a0), a1));
+    return pair28(mul(add(a0, a1), subk<4>(a0, a1)), mul(dbl(a0), a1));
 }
 }  // namespace zl
 

@@ -32,6 +32,13 @@
 #define ZL_GCAT(a, b) ZL_GCAT_(a, b)
 #define ZL_GNAME(f) ZL_GCAT(f, ZL_G)
 
+// Wave issue priority of the sort / tail kernels: in a pipeline they share every SIMD with two waves of the accumulation kernel, which would
+// otherwise win most issue slots (a 1-ms sort kernel then takes 5-9 ms); their own VALU demand is tiny.
+#ifdef ZL_NO_SIDE_PRIO
+#define ZL_SIDE_PRIO() ((void)0)
+#else
+#define ZL_SIDE_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
 #define ZL_CHUNK_MAX 64    // entries per lane in msm_accumulate (smaller for small inputs: more lanes, shorter chains)
 #define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
 #define ZL_GIANT_SPAN 4096 // ... and into more than this by ZL_GIANT_PARTS blocks (two stages)
@@ -104,6 +111,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
 static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits,
                                                              uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+    ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
@@ -133,6 +141,7 @@ static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __res
 // block (slice, w): private LDS histogram of window w over a slice of the scalars -> counts[slice][w*H + bin]
 static __global__ void __launch_bounds__(1024) k_msm_hist_lds(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t per_slice, uint32_t NB,
                                                         uint32_t* __restrict__ counts) {
+    ZL_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
     const uint32_t slice = blockIdx.x, w = blockIdx.y;
@@ -150,6 +159,7 @@ static __global__ void __launch_bounds__(1024) k_msm_hist_lds(const uint16_t* __
 }
 // lane per bucket: counts[slice][bucket] -> exclusive prefix over slices (in place), tot[bucket] = sum
 static __global__ void __launch_bounds__(256) k_msm_slice_prefix(uint32_t* __restrict__ counts, uint32_t NB, uint32_t nslices, uint32_t* __restrict__ tot) {
+    ZL_SIDE_PRIO();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
     uint32_t run = 0;
@@ -165,6 +175,7 @@ static __global__ void __launch_bounds__(256) k_msm_slice_prefix(uint32_t* __res
 // so partial-sector writes merge in L2 (the slice-owned variant measured 8.5 GB of HBM writes for 1 GB of entries).
 static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t RB,
                                                                      const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+    ZL_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
     const uint32_t range = blockIdx.x, w = blockIdx.y;
@@ -206,6 +217,7 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
                                                                   uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
                                                                   uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+    ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
@@ -237,6 +249,7 @@ static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* 
 // block (slice, w): histogram of the group ids of window w over a slice of scalars -> counts[(g*W + w)*nslices + slice]
 static __global__ void __launch_bounds__(256) k_msm_part_hist(const uint8_t* __restrict__ hi8, uint32_t n, uint32_t W, uint32_t G, uint32_t per_slice,
                                                                 uint32_t nslices, uint32_t* __restrict__ counts) {
+    ZL_SIDE_PRIO();
     __shared__ uint32_t hist[256];
     const uint32_t slice = blockIdx.x, w = blockIdx.y;
     hist[threadIdx.x] = 0;
@@ -278,6 +291,7 @@ __device__ __forceinline__ void zl_group_range(const uint32_t* __restrict__ part
 static __global__ void __launch_bounds__(256) k_msm_sub_hist(const uint16_t* __restrict__ part_lo, const uint32_t* __restrict__ part_off, uint32_t G,
                                                                uint32_t stride, const uint32_t* __restrict__ total, uint32_t fslices,
                                                                uint32_t* __restrict__ counts) {
+    ZL_SIDE_PRIO();
     __shared__ uint32_t hist[128];
     const uint32_t slice = blockIdx.x, g = blockIdx.y;
     if (threadIdx.x < 128) hist[threadIdx.x] = 0;
@@ -354,6 +368,7 @@ static __global__ void __launch_bounds__(256) k_msm_part_scatter_st(const uint16
                                                                       uint32_t G, uint32_t per_slice, uint32_t nslices, const uint32_t* __restrict__ part_off,
                                                                       uint32_t table_stride, uint32_t first, uint16_t* __restrict__ out_lo,
                                                                       uint32_t* __restrict__ out_idx) {
+    ZL_SIDE_PRIO();
     __shared__ PartStage st;
     __shared__ uint8_t grp[ZL_PT];
     const uint32_t slice = blockIdx.x, w = blockIdx.y;
@@ -419,6 +434,7 @@ static __global__ void __launch_bounds__(256) k_msm_sub_scatter_st(const uint16_
                                                                      const uint32_t* __restrict__ part_off, uint32_t G, uint32_t stride,
                                                                      const uint32_t* __restrict__ total, uint32_t fslices, const uint32_t* __restrict__ sub_off,
                                                                      uint16_t* __restrict__ out_lo, uint32_t* __restrict__ out_idx) {
+    ZL_SIDE_PRIO();
     __shared__ PartStage st;
     const uint32_t slice = blockIdx.x, g = blockIdx.y;
     st.gcur[threadIdx.x] = threadIdx.x < 128 ? sub_off[((size_t)g * 128 + threadIdx.x) * fslices + slice] : 0u;
@@ -474,6 +490,7 @@ static __global__ void __launch_bounds__(256) k_msm_sub_scatter_st(const uint16_
 // block per sub-group: histogram of its 256 buckets -> counts[sg*256 + bin]  (sg*256 + bin IS the bucket index)
 static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ sub_off, uint32_t SG,
                                                                 uint32_t fslices, const uint32_t* __restrict__ total, uint32_t* __restrict__ counts) {
+    ZL_SIDE_PRIO();
     __shared__ uint32_t hist[256];
     const uint32_t sg = blockIdx.x;
     hist[threadIdx.x] = 0;
@@ -499,6 +516,7 @@ static __global__ void __launch_bounds__(1024) k_msm_fine_sort(const uint16_t* _
                                                                 const uint32_t* __restrict__ sub_off, uint32_t SG, uint32_t fslices,
                                                                 const uint32_t* __restrict__ total, const uint32_t* __restrict__ offsets, uint32_t cap,
                                                                 uint32_t* __restrict__ entries) {
+    ZL_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [256]
     uint32_t* stage = cur + 256;                        // [cap]
@@ -525,6 +543,7 @@ static __global__ void __launch_bounds__(1024) k_msm_fine_sort(const uint16_t* _
 #define SCAN_ITEMS 16
 #define SCAN_BLOCK 256
 static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t count, uint32_t* __restrict__ block_sums) {
+    ZL_SIDE_PRIO();
     __shared__ uint32_t sh[SCAN_BLOCK];
     uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
@@ -538,6 +557,7 @@ static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block_sums(const uin
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
+    ZL_SIDE_PRIO();
     // single block: exclusive scan of block_sums in place
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
@@ -564,6 +584,7 @@ static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__
 }
 static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t count, const uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
+    ZL_SIDE_PRIO();
     __shared__ uint32_t sh[SCAN_BLOCK];
     uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
@@ -598,8 +619,11 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
 #ifndef ZL_ACC_WAVES
 #define ZL_ACC_WAVES 2  // waves per SIMD the accumulate kernel is register-budgeted for
 #endif
+#ifndef ZL_ACC_BLOCK
+#define ZL_ACC_BLOCK 64
+#endif
 template <class G>
-__global__ void __launch_bounds__(64, ZL_ACC_WAVES) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases_,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums_,
                                                         XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK) {
@@ -646,6 +670,7 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
                                                    uint32_t ZL_CHUNK) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
@@ -687,6 +712,7 @@ template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
                                                         const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -709,6 +735,7 @@ template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ giant_tmp,
                                                           const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ giant_list,
                                                           const uint32_t* __restrict__ giant_count, uint32_t ZL_CHUNK) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -731,6 +758,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint3
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __restrict__ bucket_sums, const XYZZ<typename G::F>* __restrict__ giant_tmp,
                                                           const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= *giant_count) return;
@@ -747,6 +775,7 @@ __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __restrict__ ones_list, const uint32_t* __restrict__ ones_count,
                                                    const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -765,6 +794,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>* __restrict__ bucket_sums, uint32_t H, uint32_t segs_per_window,
                                                         uint32_t total_segs, XYZZ<typename G::F>* __restrict__ seg_out, uint32_t ZL_SEG) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_segs) return;
@@ -794,6 +824,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
                                                          uint32_t parts, XYZZ<typename G::F>* __restrict__ out) {
+    ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
@@ -1157,7 +1188,7 @@ struct MsmJob {
         return ZL_OK;
     }
     int accumulate(zl_ctx* ctx, hipStream_t st) {
-        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
         ZL_HIP(ctx, hipGetLastError());
         return ZL_OK;
     }
