@@ -27,5 +27,5 @@ for name, cid, r, bits in (("bls12_381", ZL_BLS12_381, None, 255), ("bn254", ZL_
     be.ntt_dev(cid, x.data_ptr(), ln); be.ntt_dev(cid, x.data_ptr(), ln)
     t_ntt = be.last_timing().total_ms
     print(f"{name} 2^{ln}: MSM resident {t_dev*1e3:.2f} ms ({n/t_dev/1e6:.0f} Mpts/s), host scalars (PCIe-inclusive) {t_host*1e3:.2f} ms, "
-          f"with table {t_pre*1e3:.2f} ms ({n/t_pre/1e6:.0f} Mpts/s); NTT {t_ntt:.3f} ms ({n/t_ntt/1e3/1e6:.2f} Gel/s)", flush=True)
+          f"with table {t_pre*1e3:.2f} ms ({n/t_pre/1e6:.0f} Mpts/s); NTT {t_ntt:.3f} ms ({n/(t_ntt*1e-3)/1e9:.2f} Gel/s)", flush=True)
     be.bases_free(h)
