@@ -97,7 +97,7 @@ int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_
 /* `count` MSMs over the same bases range (e.g. the several scalar vectors of one proof, or a stream of proofs against one proving key):
  * d_scalars[i] points to n x 4 u64 canonical scalars in HBM; out_partials receives count x ZL_PARTIAL_WORDS words.  The calls are
  * pipelined on three streams -- the sort of MSM i+2, the bucket accumulation of MSM i+1 and the merge / reduction tail of MSM i
- * overlap -- so that in steady state an MSM costs its accumulation kernel only; results are identical to `count` separate calls. */
+ * overlap -- so that in steady state an MSM costs little more than its accumulation kernel; results are identical to `count` separate calls. */
 int zl_msm_batch_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials);
 int zl_partials_sum(zl_curve_t curve, zl_group_t group, const uint64_t* partials, size_t count, uint64_t* out_xy, uint8_t* out_inf);
 /* wrap a canonical affine point (all-zero = infinity) as a partial, e.g. to fold an extra term into zl_partials_sum */
