@@ -1270,8 +1270,8 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
 
 // `count` MSMs over the same bases, pipelined: sort of MSM i+2 (stream_sort) | accumulation of MSM i+1 (ctx->stream) | tail of MSM i
 // (stream_tail).  Three buffer sets rotate; a set is reused when the tail that reads it has finished.  The sort and tail phases are
-// memory- / latency-bound and fit into the issue slots the compute-bound accumulation leaves, so in steady state an MSM costs its
-// accumulation kernel only.
+// memory- / latency-bound and mostly fit into the issue slots the compute-bound accumulation leaves: in steady state an MSM costs its
+// accumulation kernel + ~2.5 ms (measured: 2^24, tools/batch_overlap.py).
 struct MsmSpec {
     const zl_bases* bs;
     size_t first;
