@@ -6,7 +6,7 @@
  * /root/reference/plugins/arkworks/src/groth16.rs:405-467).  One level below `Groth16::prove`
  * (groth16.rs:445-457) the work is done by two upstream entry points that the plugin re-exports
  * (`pub use ec;` lib.rs:28-29, `pub use poly;` lib.rs:70-71, `pub use ff::*;` ff.rs:6):
- *     ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) -> Projective      -> zl_msm_g1 / zl_msm_g2
+ *     ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars) -> Projective      -> zl_msm (group chosen by the bases handle)
  *     ark_poly::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place(&mut Vec<F>)    -> zl_ntt
  * and the whole prover call                                                               -> zl_groth16_prove
  * These are the symbols a Rust shim (`extern "C"` block) binds.  Plain pointers and sizes only.
@@ -77,7 +77,8 @@ int zl_bases_upload(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const void*
  * for tests and benches: gives MSM inputs with known discrete logs. */
 int zl_bases_generate(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const uint64_t* k, size_t n, uint64_t* handle_out);
 /* Optional, MI355X-sized trade of HBM for work: store 2^(c w) P_i for every window w next to the bases (W x the memory:
- * 19 GB for 2^24 BLS12-381 G1 points at c = 22) so that all windows share ONE bucket set and c can grow to 22: 12 instead of
+ * 12 x 2^24 x 128 B = 25.8 GB for 2^24 BLS12-381 G1 points at c = 22; building it takes ~50 plain MSMs' worth of time, so it pays
+ * only for a key that is used many times, like a Groth16 proving key) so that all windows share ONE bucket set and c can grow to 22: 12 instead of
  * 16 mixed additions per point.  c = 0 picks c from n.  MSMs on the handle then use the table; results are unchanged. */
 int zl_bases_precompute(zl_ctx* ctx, uint64_t handle, int c);
 /* copy bases back as canonical affine x||y (tests) */
@@ -155,7 +156,8 @@ int zl_r1cs_free(zl_ctx* ctx, uint64_t handle);
 /* flags: ZL_MONT = the assignment is in arkworks' in-memory Montgomery form (no host-side into_repr pass needed) */
 int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, unsigned flags,
                               const uint64_t* r, const uint64_t* s, zl_g16_proof* out);
-/* the quotient polynomial h of the last zl_groth16_prove call (N x 4 u64 canonical), for tests */
+/* the quotient polynomial h of the last successful zl_groth16_prove* call on this ctx (N x 4 u64 canonical), for tests;
+ * ZL_EINVAL when there is none (it lives in scratch slot 8 and is invalidated when the next proof starts) */
 int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n);
 
 /* ---- host mirror of the plugin interface (C hooks over the C++ classes of openzl_amd/csrc/zl_host.h) ------------
@@ -173,14 +175,16 @@ int zl_circuit_is_satisfied(const zl_circuit* c); /* 1 / 0 */
 int zl_poseidon_permute(zl_curve_t curve, uint64_t* state);
 /* Groth16::compile with rng = SplitMix64(seed): trapdoor setup, proving key generated on the device */
 int zl_groth16_compile(zl_ctx* ctx, const zl_circuit* c, uint64_t seed, zl_g16_keys** out);
-void zl_groth16_keys_free(zl_g16_keys* k);
+void zl_groth16_keys_free(zl_g16_keys* k); /* must be called BEFORE zl_ctx_destroy of the ctx the keys were compiled on (they hold handles of it) */
 int zl_groth16_keys_pk(const zl_g16_keys* k, zl_g16_pk* pk);
 int zl_groth16_keys_trapdoor(const zl_g16_keys* k, uint64_t* out20); /* alpha, beta, gamma, delta, tau (canonical) */
 /* Groth16::prove with rng = SplitMix64(seed); r_out / s_out (optional) receive the sampled blinding scalars */
 int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* c, uint64_t seed, zl_g16_proof* proof,
                              uint64_t* r_out, uint64_t* s_out);
 
-/* Groth16::verify (host pairing; public_inputs: n x 4 u64 canonical, without the leading ONE): *ok = 1 accepted, 0 rejected */
+/* The proof points are taken as given: callers that accept proofs from outside deserialize them with zl_groth16_proof_from_bytes, which
+ * checks curve membership and the subgroup (as arkworks' deserialization does); A or B at infinity is rejected here.
+ * Groth16::verify (host pairing; public_inputs: n x 4 u64 canonical, without the leading ONE): *ok = 1 accepted, 0 rejected */
 int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_t n, const zl_g16_proof* proof, int* ok);
 /* e(P, Q) in GT after the final exponentiation: 12 canonical Fq coefficients (BLS12-381: 12 x 6 u64, BN254: 12 x 4 u64) of the
  * polynomial in w, Fq12 = Fq[w]/(w^12 - 2 w^6 + 2) (BLS12-381) or (w^12 - 18 w^6 + 82) (BN254) */

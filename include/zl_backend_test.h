@@ -1,0 +1,41 @@
+/* zl_backend_test.h -- TEST-ONLY hooks of libzl_backend.so (not part of the drop-in boundary of zl_backend.h).
+ *
+ * They expose the device (and host) field / group arithmetic below the MSM / NTT entry points so that tests can
+ *   - pin the device Montgomery multiplier to the one known-answer vector the reference holds: the Poseidon permutation of
+ *     [3, 1, 2] over BLS12-381 Fr (/root/reference/openzl-tutorials/src/poseidon.rs:364-405, same numbers in
+ *     /root/reference/plugins/arkworks/src/poseidon/permutation_hardcoded_test/width3), and
+ *   - drive the lazily reduced 14 x 28-bit field (openzl_amd/csrc/zl_field28.h) and the point formulas built on it with operands AT
+ *     their contract bounds, which random MSM inputs never produce.
+ * Nothing in the product path calls them.
+ */
+#ifndef ZL_BACKEND_TEST_H
+#define ZL_BACKEND_TEST_H
+#include "zl_backend.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Poseidon permutation, width 3, tutorial schedule (8 full + 55 partial rounds, x^5), computed ON THE DEVICE by one wavefront with
+ * the device Fr multiplier the NTT uses; round constants / MDS come from the host mirror (Grain LFSR, Cauchy matrix).
+ * state: 3 x 4 u64 canonical, in place.  All 64 lanes compute the same permutation; ZL_EHIP if they disagree. */
+int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state);
+
+/* Raw-limb access to the 14 x 28-bit BLS12-381 Fq (values are NOT reduced: the caller chooses them anywhere inside a contract).
+ * ctx == NULL runs the host code path (7 x 56-bit fast path), otherwise the device path (inline-asm product scans).
+ * in: n records of 4 operands (a, b, c, d) x 14 u32 limbs; out: n x 14 u32 limbs (predicates: out[0] = 0 / 1).
+ * op: 0 mul(a,b)  1 sqr(a)  2 muladd(a,b,c,d)  3 add(a,b)  4 dbl(a)  5..10 subk<1..6>(a,b)  11 wred(a)  12 canon(a)
+ *     13 is_zero(a)  14 a == b  15 muladd4(a,b,c,d,a,d,c,b)  16 load_mont32 . store_canon round trip is op 17/18:
+ *     17 load_canon(12 words in a) -> limbs   18 store_canon(a) -> 12 words */
+int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out);
+
+/* Point formulas of zl_curve.h over that field.  group: ZL_G1 (coordinate = 14 words) or ZL_G2 (coordinate = 2 x 14 words);
+ * hot != 0 selects, for G2, the flavour with inlined product scans that the bucket accumulation kernel uses.
+ * in: n records of two XYZZ points p, q (x, y, zz, zzz each), raw limbs, zz == 0 encodes infinity; out: n XYZZ points.
+ * op: 0 add_mixed(p, q.x, q.y, +)  1 add_mixed(p, q.x, q.y, -)  2 add_full(p, q)  3 dbl_inplace(p)  4 dbl_affine(p.x, p.y)
+ *     5 neg_inplace(p)  6 to_affine(p) (x, y in the first two coordinates) */
+int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint32_t* in, size_t n, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

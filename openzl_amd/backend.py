@@ -120,6 +120,11 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_proof_bytes.restype = C.c_size_t
     L.zl_groth16_proof_to_bytes.argtypes = [C.c_int, C.POINTER(G16ProofC), u8p]
     L.zl_groth16_proof_from_bytes.argtypes = [C.c_int, u8p, C.c_size_t, C.POINTER(G16ProofC)]
+    # test-only hooks (include/zl_backend_test.h)
+    u32p = C.POINTER(C.c_uint32)
+    L.zl_test_poseidon_permute_dev.argtypes = [vp, C.c_int, u64p]
+    L.zl_test_fp28_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     if path is None:
         _lib = L
     return L
@@ -310,6 +315,46 @@ class Backend:
         out = np.zeros((n, 4), dtype=np.uint64)
         self._check(self.L.zl_groth16_last_h(self._ctx, _p64(out), n), "zl_groth16_last_h")
         return out
+
+
+# ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op"]
+
+
+def _p32(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def hook_poseidon_permute_dev(be: "Backend", curve: int, state: np.ndarray) -> np.ndarray:
+    """width-3 Poseidon permutation computed on the device with the device Fr arithmetic (canonical (3,4) uint64 in / out)"""
+    st = np.ascontiguousarray(state.copy(), dtype=np.uint64)
+    be._check(be.L.zl_test_poseidon_permute_dev(be._ctx, curve, _p64(st)), "zl_test_poseidon_permute_dev")
+    return st
+
+
+def hook_fp28_op(be: Optional["Backend"], op: int, operands: np.ndarray) -> np.ndarray:
+    """operands: (n, 4, 14) uint32 raw limbs -> (n, 14); be = None runs the host code path"""
+    a = np.ascontiguousarray(operands, dtype=np.uint32)
+    n = a.shape[0]
+    out = np.zeros((n, 14), dtype=np.uint32)
+    L = load_library()
+    rc = L.zl_test_fp28_op(be._ctx if be is not None else None, op, _p32(a), n, _p32(out))
+    if rc:
+        raise BackendError(rc, "zl_test_fp28_op")
+    return out
+
+
+def hook_point_op(be: Optional["Backend"], group: int, hot: bool, op: int, pq: np.ndarray) -> np.ndarray:
+    """pq: (n, 8, W) uint32 raw limbs of two XYZZ points (W = 14 for G1, 28 for G2) -> (n, 4, W)"""
+    a = np.ascontiguousarray(pq, dtype=np.uint32)
+    n, W = a.shape[0], a.shape[2]
+    out = np.zeros((n, 4, W), dtype=np.uint32)
+    L = load_library()
+    rc = L.zl_test_point_op(be._ctx if be is not None else None, group, int(hot), op, _p32(a), n, _p32(out))
+    if rc:
+        raise BackendError(rc, "zl_test_point_op")
+    return out
 
 
 # ---- host mirror (openzl::R1CS / poseidon / Groth16<E>, csrc/zl_host.h) through its C hooks ---------------------------

@@ -16,7 +16,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 FLAGS += [f for f in os.environ.get("ZL_EXTRA_FLAGS", "").split() if f]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
-HEADERS = ["zl_field.h", "zl_field28.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_mul28_gfx950.h", "zl_ctx.h", "zl_host.h", "zl_pairing.h", "zl_serialize.h", os.path.join("..", "..", "include", "zl_backend.h")]
+HEADERS = ["zl_field.h", "zl_field28.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_mul28_gfx950.h", "zl_bounds.h", "zl_ctx.h", "zl_host.h", "zl_pairing.h", "zl_serialize.h", os.path.join("..", "..", "include", "zl_backend.h"), os.path.join("..", "..", "include", "zl_backend_test.h")]
 
 
 def _hipcc() -> str:
@@ -35,7 +35,7 @@ def _digest(paths, extra="") -> str:
 
 
 def _units():
-    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", [])]
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", [])]
     for g in GROUPS:
         # Fq2 accumulators: 1 wave/SIMD register budget avoids scratch spills
         extra = ["-DZL_ACC_WAVES=1"] if g.endswith("G2") else []

@@ -29,9 +29,17 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
     if (!ctx) return ZL_ENOMEM;
     ctx->device = device_id;
     hipError_t e = hipSetDevice(device_id);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // the kernels are built for gfx950 only
+        delete ctx;
+        return ZL_ENODEV;
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
+        for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return ZL_EHIP;
     }

@@ -106,7 +106,7 @@ struct zl_ctx {
     size_t pinned_cap = 0;
     zl_ctx* aux2 = nullptr;  // second auxiliary context (Groth16: the witness map runs beside the witness-only MSMs)
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
-    void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 7)
+    void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 8; reset when the next proof starts)
     size_t g16_h_n = 0;
 };
 

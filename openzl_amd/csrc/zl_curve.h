@@ -69,10 +69,10 @@ struct FieldIO<Fp2<P>> {
 template <class B, bool INL>
 struct Fp2LT {
     B c0, c1;
-    ZL_HD static Fp2LT zero() { return Fp2LT{B::zero(), B::zero()}; }
-    ZL_HD static Fp2LT one() { return Fp2LT{B::one(), B::zero()}; }
-    ZL_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-    ZL_HD bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
+    ZL_HD static constexpr Fp2LT zero() { return Fp2LT{B::zero(), B::zero()}; }
+    ZL_HD static constexpr Fp2LT one() { return Fp2LT{B::one(), B::zero()}; }
+    ZL_HD constexpr bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    ZL_HD constexpr bool raw_zero() const { return c0.raw_zero() && c1.raw_zero(); }
     ZL_HD bool operator==(const Fp2LT& o) const { return c0 == o.c0 && c1 == o.c1; }
     ZL_HD bool operator!=(const Fp2LT& o) const { return !(*this == o); }
 };
@@ -81,44 +81,46 @@ template <class B> using Fp2L = Fp2LT<B, false>;
 template <class F> struct HotField { using type = F; };
 template <class B> struct HotField<Fp2LT<B, false>> { using type = Fp2LT<B, true>; };
 namespace zl {
-template <class B, bool I> ZL_HD Fp2LT<B, I> add(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{add(a.c0, b.c0), add(a.c1, b.c1)}; }
-template <class B, bool I> ZL_HD Fp2LT<B, I> dbl(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{dbl(a.c0), dbl(a.c1)}; }
-template <int J, class B, bool I> ZL_HD Fp2LT<B, I> subk(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{subk<J>(a.c0, b.c0), subk<J>(a.c1, b.c1)}; }
-template <int J, class B, bool I> ZL_HD Fp2LT<B, I> negk(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{negk<J>(a.c0), negk<J>(a.c1)}; }
-template <class B, bool I> ZL_HD Fp2LT<B, I> sub(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return subk<4>(a, b); }
-template <class B, bool I> ZL_HD Fp2LT<B, I> neg(const Fp2LT<B, I>& a) { return negk<4>(a); }
-template <class B, bool I> ZL_HD Fp2LT<B, I> wred(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{wred(a.c0), wred(a.c1)}; }
-template <class B, bool I> ZL_HD Fp2LT<B, I> canon(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{canon(a.c0), canon(a.c1)}; }
-template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> mul(const Fp2LT<Fp28<A, P>, I>& a, const Fp2LT<Fp28<A, P>, I>& b) {
-    if constexpr (I) {
-        return Fp2LT<Fp28<A, P>, I>{muladd(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
-    } else {
-        Fp2LT<Fp28<A, P>, I> r;
-        unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
-        return r;
-    }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> add(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> dbl(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{dbl(a.c0), dbl(a.c1)}; }
+template <int J, class B, bool I> ZL_HD constexpr Fp2LT<B, I> subk(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return Fp2LT<B, I>{subk<J>(a.c0, b.c0), subk<J>(a.c1, b.c1)}; }
+template <int J, class B, bool I> ZL_HD constexpr Fp2LT<B, I> negk(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{negk<J>(a.c0), negk<J>(a.c1)}; }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> sub(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) { return subk<4>(a, b); }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> neg(const Fp2LT<B, I>& a) { return negk<4>(a); }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> wred(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{wred(a.c0), wred(a.c1)}; }
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> canon(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{canon(a.c0), canon(a.c1)}; }
+// out-of-line Fq2 products (the INL = false flavour): one call per product, operands as scalar words (zl_field28.h)
+template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_mul_called(const Fp2LT<Fp28<A, P>, false>& a, const Fp2LT<Fp28<A, P>, false>& b) {
+    Fp2LT<Fp28<A, P>, false> r;
+    unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
+    return r;
 }
-template <class A, class P, bool I> ZL_HD Fp2LT<Fp28<A, P>, I> sqr(const Fp2LT<Fp28<A, P>, I>& a) {
-    if constexpr (I) {
-        return Fp2LT<Fp28<A, P>, I>{mul(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
-    } else {
-        Fp2LT<Fp28<A, P>, I> r;
-        unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
-        return r;
-    }
+template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_sqr_called(const Fp2LT<Fp28<A, P>, false>& a) {
+    Fp2LT<Fp28<A, P>, false> r;
+    unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
+    return r;
 }
-// a b + c d.  Inlined flavour: each component is ONE four-product scan (980 mads) -> components < 2q; operands' components < 16q.
+// (a0 + a1 u)(b0 + b1 u): each component ONE dual product scan; operand components <= 16q, result components < 2q
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> mul(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) {
+    if constexpr (I) return Fp2LT<B, I>{muladd(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
+    else return fq2_mul_called(a, b);
+}
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> sqr(const Fp2LT<B, I>& a) {
+    if constexpr (I) return Fp2LT<B, I>{mul(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+    else return fq2_sqr_called(a);
+}
+// a b + c d.  Inlined flavour: each component is ONE four-product scan (980 mads) -> components < 2q; operands' components <= 16q.
 // Called flavour: two calls and a lazy add (components < 4q; a four-product call would need 112 argument words).
-template <class A, class P, bool I>
-ZL_HD Fp2LT<Fp28<A, P>, I> muladd(const Fp2LT<Fp28<A, P>, I>& a, const Fp2LT<Fp28<A, P>, I>& b, const Fp2LT<Fp28<A, P>, I>& c, const Fp2LT<Fp28<A, P>, I>& d) {
+template <class B, bool I>
+ZL_HD constexpr Fp2LT<B, I> muladd(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b, const Fp2LT<B, I>& c, const Fp2LT<B, I>& d) {
     if constexpr (I) {
-        return Fp2LT<Fp28<A, P>, I>{muladd4_body28(a.c0, b.c0, a.c1, negk<4>(b.c1), c.c0, d.c0, c.c1, negk<4>(d.c1)),
-                                   muladd4_body28(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
+        return Fp2LT<B, I>{muladd4(a.c0, b.c0, a.c1, negk<4>(b.c1), c.c0, d.c0, c.c1, negk<4>(d.c1)),
+                           muladd4(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
     } else {
         return add(mul(a, b), mul(c, d));
     }
 }
-template <class B, bool I> ZL_HD Fp2LT<B, I> inv(const Fp2LT<B, I>& a) {
+template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> inv(const Fp2LT<B, I>& a) {
     const B n = inv(add(sqr(a.c0), sqr(a.c1)));
     return Fp2LT<B, I>{mul(a.c0, n), mul(negk<4>(a.c1), n)};
 }
@@ -136,17 +138,17 @@ struct FieldIO<Fp2LT<B, I>> {
 template <class F>
 struct Affine {
     F x, y;
-    ZL_HD bool is_inf() const { return x.raw_zero() && y.raw_zero(); }  // stored points are canonical: all-zero limbs
-    ZL_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
+    ZL_HD constexpr bool is_inf() const { return x.raw_zero() && y.raw_zero(); }  // stored points are canonical: all-zero limbs
+    ZL_HD static constexpr Affine inf() { return Affine{F::zero(), F::zero()}; }
 };
 template <class F>
 struct XYZZ {
     F x, y, zz, zzz;
     // exact-zero limbs: infinity is only ever written as zero(); a computed zz is a product of non-zero factors (P == 0 and
     // y == 0 are branched away before multiplying; both curves have odd order, so no point has y == 0)
-    ZL_HD bool is_inf() const { return zz.raw_zero(); }
-    ZL_HD static XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
-    ZL_HD static XYZZ from_affine(const Affine<F>& a) {
+    ZL_HD constexpr bool is_inf() const { return zz.raw_zero(); }
+    ZL_HD static constexpr XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
+    ZL_HD static constexpr XYZZ from_affine(const Affine<F>& a) {
         if (a.is_inf()) return inf();
         return XYZZ{a.x, a.y, F::one(), F::one()};
     }
@@ -158,21 +160,18 @@ namespace zl {
 // subk<J> / wred spellings are plain sub / identity.  Contract of every routine: coordinates < 8q in, < 8q out.
 // 2*(x,y) for an affine, non-infinity point (mdbl-2008-s-1, a = 0)
 template <class F>
-ZL_HD XYZZ<F> dbl_affine(const F& x, const F& y) {          // x, y < 8
+ZL_HD constexpr XYZZ<F> dbl_affine(const F& x, const F& y) {          // x, y < 8
     const F u = dbl(y);                                       // < 16
     const F v = sqr(u), w = mul(u, v), s = mul(x, v);         // 256, 32, 16 -> < 2
     const F xx = sqr(x);                                      // 64 -> < 2
     const F m = add(dbl(xx), xx);                             // < 6
-    XYZZ<F> r;
-    r.x = subk<2>(sqr(m), dbl(s));                            // 36 -> 2; dbl(s) < 4 -> < 6
-    r.y = muladd(m, subk<3>(s, r.x), w, negk<3>(y));          // m (s - x3) - w y, one reduction: 6*10 + 2*8 -> < 2
-    r.zz = v;
-    r.zzz = w;
-    return r;  // y == 0 -> zz == 0 -> infinity (does not occur on these curves)
+    const F x3 = subk<2>(sqr(m), dbl(s));                     // 36 -> 2; dbl(s) < 4 -> < 6
+    const F y3 = muladd(m, subk<3>(s, x3), w, negk<3>(y));    // m (s - x3) - w y, one reduction: 6*10 + 2*8 -> < 2
+    return XYZZ<F>{x3, y3, v, w};  // y == 0 -> zz == 0 -> infinity (does not occur on these curves)
 }
 // p = 2p (dbl-2008-s-1, a = 0)
 template <class F>
-ZL_HD void dbl_inplace(XYZZ<F>& p) {
+ZL_HD constexpr void dbl_inplace(XYZZ<F>& p) {
     if (p.is_inf()) return;
     const F u = dbl(p.y);                                     // < 16
     const F v = sqr(u), w = mul(u, v), s = mul(p.x, v);       // < 2
@@ -186,7 +185,7 @@ ZL_HD void dbl_inplace(XYZZ<F>& p) {
 }
 // p += (qx, qy) (affine, canonical or < 2q, q must not be infinity); neg_q selects p -= q.   madd-2008-s
 template <class F>
-ZL_HD void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
+ZL_HD constexpr void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
     const F qy = neg_q ? negk<1>(qy_in) : qy_in;              // < 2
     if (p.is_inf()) {
         p.x = qx; p.y = qy; p.zz = F::one(); p.zzz = F::one();
@@ -208,7 +207,7 @@ ZL_HD void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
 }
 // p += q (add-2008-s)
 template <class F>
-ZL_HD void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
+ZL_HD constexpr void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
     if (q.is_inf()) return;
     if (p.is_inf()) { p = q; return; }
     const F u1 = mul(p.x, q.zz), u2 = mul(q.x, p.zz);         // 64 -> < 2
@@ -228,11 +227,11 @@ ZL_HD void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
 }
 // p = -p
 template <class F>
-ZL_HD void neg_inplace(XYZZ<F>& p) {
+ZL_HD constexpr void neg_inplace(XYZZ<F>& p) {
     p.y = wred(negk<3>(p.y));                                 // y < 8 -> 8q - y -> weakly reduced < 4
 }
 template <class F>
-ZL_HD Affine<F> to_affine(const XYZZ<F>& p) {
+ZL_HD constexpr Affine<F> to_affine(const XYZZ<F>& p) {
     if (p.is_inf()) return Affine<F>::inf();
     const F izzz = inv(p.zzz);
     const F t = mul(p.zz, izzz);  // zz/zzz = 1/z
@@ -275,3 +274,4 @@ ZL_HD XYZZ<F> mul_scalar2(const XYZZ<F>& p, const uint32_t* k1, const XYZZ<F>& q
     return acc;
 }
 }  // namespace zl
+#include "zl_bounds.h"  // compile-time proof of the lazy-reduction contracts of the formulas above

@@ -300,6 +300,12 @@ ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
     return mul_call28<A, B>(a, b);
 #endif
 }
+// a*b + c*d + e*f + g*h (Montgomery), needs the four bound products to sum to <= 2500 -> < 2q
+template <class A, class B>
+ZL_HD Fp28<A, B> muladd4(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, B>& c, const Fp28<A, B>& d, const Fp28<A, B>& e, const Fp28<A, B>& f,
+                         const Fp28<A, B>& g, const Fp28<A, B>& h) {
+    return muladd4_body28(a, b, c, d, e, f, g, h);
+}
 template <class A, class B>
 ZL_HD Fp28<A, B> sqr(const Fp28<A, B>& a) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_ASM_MUL28)

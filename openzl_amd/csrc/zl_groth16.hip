@@ -143,6 +143,8 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     if (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw) return ZL_EINVAL;
 
     hipStream_t st = ctx->stream;
+    ctx->g16_h = nullptr;  // the quotient of an earlier proof may live in a scratch block this call re-allocates
+    ctx->g16_h_n = 0;
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     // ---- assignment + work vectors on the device (the matrices are already resident, zl_r1cs_upload) ------------------
     size_t bytes = 0;
@@ -219,7 +221,10 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
     // The G2 MSM (Fq2: one wave per SIMD, half of the issue slots idle) runs on an auxiliary stream with its own scratch
     // while the four G1 MSMs run on the main stream: the two streams fill each other's gaps (54 -> ~35 ms at 2^20).
-    ZL_HIP(ctx, hipStreamSynchronize(st));  // z is complete before the other streams / threads read it
+    {
+        const hipError_t e_z = hipStreamSynchronize(st);  // z is complete before the other streams / threads read it
+        if (e_z != hipSuccess) { ctx->last_hip = (int)e_z; return wm_fail(ZL_EHIP); }
+    }
     // host work that does not depend on the MSMs (r*delta1, s*delta1, r*s*delta1, s*delta2: ~1300 group operations) runs on a third
     // thread while the device is busy
     uint32_t rw[8], sw[8];
@@ -316,10 +321,22 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     return ZL_OK;
 }
 
+// Full structural validation of a caller-supplied CSR, once per upload (O(nnz) on the host): row_ptr starts at 0 and is monotone,
+// every column index names a variable.  k_r1cs_spmv then never reads val / z out of bounds, whatever the caller passed.
 static bool r1cs_view_ok(const zl_r1cs* cs) {
     if (!cs || cs->n_instance < 1) return false;
-    for (int m = 0; m < 3; m++)
-        if (!cs->row_ptr[m] || (cs->row_ptr[m][cs->n_constraints] && (!cs->col[m] || !cs->val[m]))) return false;
+    const uint64_t nv = (uint64_t)cs->n_instance + cs->n_witness;
+    if (nv >= (1ull << 31)) return false;
+    for (int m = 0; m < 3; m++) {
+        const uint32_t* rp = cs->row_ptr[m];
+        if (!rp || rp[0] != 0) return false;
+        for (uint32_t i = 0; i < cs->n_constraints; i++)
+            if (rp[i + 1] < rp[i]) return false;
+        const uint32_t nnz = rp[cs->n_constraints];
+        if (nnz && (!cs->col[m] || !cs->val[m])) return false;
+        for (uint32_t k = 0; k < nnz; k++)
+            if (cs->col[m][k] >= nv) return false;
+    }
     return true;
 }
 extern "C" int zl_r1cs_upload(zl_ctx* ctx, zl_curve_t curve, const zl_r1cs* cs, uint64_t* handle_out) {

@@ -1,0 +1,242 @@
+// zl_testhooks.hip -- the TEST-ONLY hooks declared in include/zl_backend_test.h: device Poseidon known-answer run, raw-limb access to the
+// lazily reduced 28-bit field and to the point formulas (host and device).  Nothing in the product path calls into this file.
+#include <string.h>
+#include <vector>
+#include "../../include/zl_backend_test.h"
+#include "zl_ctx.h"
+#include "zl_host.h"
+
+using namespace openzl;
+
+// ------------------------------------------------------------------------------------------------ Poseidon on the device
+// One wavefront; every lane runs the whole width-3 permutation (schedule: openzl-tutorials/src/poseidon.rs:165-222) with the device
+// Fr arithmetic: canonical -> Montgomery conversion of the state AND of the round constants, the Cauchy MDS entries 1 / (i + 3 + j)
+// by Fermat inversion, 63 rounds of add / x^5 / MDS, Montgomery -> canonical.  Only the LFSR bit stream comes from the host.
+template <class FrP>
+__global__ void __launch_bounds__(64) k_test_poseidon(const uint32_t* __restrict__ keys_canon, int full_rounds, int partial_rounds, uint32_t* __restrict__ state,
+                                                       uint32_t* __restrict__ disagree) {
+    using F = Fp<FrP>;
+    F st[3], mds[3][3];
+    for (int i = 0; i < 3; i++) {
+        F c;
+        for (int k = 0; k < FrP::N; k++) c.l[k] = state[i * FrP::N + k];
+        st[i] = zl::to_mont(c);
+        for (int j = 0; j < 3; j++) mds[i][j] = zl::inv(zl::from_u64<FrP>((uint64_t)(i + 3 + j)));
+    }
+    const int half = full_rounds / 2;
+    for (int rnd = 0; rnd < full_rounds + partial_rounds; rnd++) {
+        for (int i = 0; i < 3; i++) {
+            F c;
+            for (int k = 0; k < FrP::N; k++) c.l[k] = keys_canon[(3 * rnd + i) * FrP::N + k];
+            st[i] = zl::add(st[i], zl::to_mont(c));
+        }
+        const int lanes = (rnd < half || rnd >= half + partial_rounds) ? 3 : 1;
+        for (int i = 0; i < lanes; i++) {
+            const F x2 = zl::sqr(st[i]), x4 = zl::sqr(x2);
+            st[i] = zl::mul(x4, st[i]);
+        }
+        F nx[3];
+        for (int i = 0; i < 3; i++) {
+            F acc = zl::mul(mds[i][0], st[0]);
+            acc = zl::add(acc, zl::mul(mds[i][1], st[1]));
+            nx[i] = zl::add(acc, zl::mul(mds[i][2], st[2]));
+        }
+        for (int i = 0; i < 3; i++) st[i] = nx[i];
+    }
+    uint32_t bad = 0;
+    for (int i = 0; i < 3; i++) {
+        const F c = zl::from_mont(st[i]);
+        for (int k = 0; k < FrP::N; k++) {
+            const uint32_t v0 = __shfl(c.l[k], 0);
+            bad |= v0 ^ c.l[k];
+        }
+        if (threadIdx.x == 0) for (int k = 0; k < FrP::N; k++) state[i * FrP::N + k] = c.l[k];
+    }
+    if (bad) atomicOr(disagree, 1u);
+}
+
+template <class FrP>
+static int poseidon_dev_t(zl_ctx* ctx, uint64_t* state) {
+    using C = poseidon::Constants<FrP>;
+    static const C cst;  // host mirror: Grain LFSR stream -> canonical integers are recovered below
+    std::vector<uint32_t> keys(cst.round_keys.size() * FrP::N);
+    for (size_t i = 0; i < cst.round_keys.size(); i++) {
+        const Fp<FrP> c = zl::from_mont(cst.round_keys[i]);  // back to the LFSR's integer: the device redoes the conversion
+        memcpy(&keys[i * FrP::N], c.l, FrP::N * 4);
+    }
+    void* d = nullptr;
+    const size_t kb = keys.size() * 4, sb = 3 * FrP::N * 4;
+    int rc = zl_scratch_get(ctx, 9, kb + sb + 64, &d);
+    if (rc) return rc;
+    uint32_t* d_keys = (uint32_t*)d;
+    uint32_t* d_state = d_keys + keys.size();
+    uint32_t* d_bad = d_state + 3 * FrP::N;
+    hipStream_t st = ctx->stream;
+    ZL_HIP(ctx, hipMemcpyAsync(d_keys, keys.data(), kb, hipMemcpyHostToDevice, st));
+    ZL_HIP(ctx, hipMemcpyAsync(d_state, state, sb, hipMemcpyHostToDevice, st));
+    ZL_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
+    hipLaunchKernelGGL((k_test_poseidon<FrP>), dim3(1), dim3(64), 0, st, d_keys, C::FULL_ROUNDS, C::PARTIAL_ROUNDS, d_state, d_bad);
+    ZL_HIP(ctx, hipGetLastError());
+    uint32_t bad = 0;
+    ZL_HIP(ctx, hipMemcpyAsync(state, d_state, sb, hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipStreamSynchronize(st));
+    return bad ? ZL_EHIP : ZL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ raw-limb field / point access
+using F28 = BlsG1::F;
+static_assert(F28::L == 14, "test hooks are written for the 14-limb field");
+
+ZL_HD static F28 raw_load(const uint32_t* w) {
+    F28 r = F28::zero();
+    for (int i = 0; i < 14; i++) r.l[i] = w[i];
+    return r;
+}
+ZL_HD static void raw_store(uint32_t* w, const F28& a) {
+    for (int i = 0; i < 14; i++) w[i] = a.l[i];
+}
+ZL_HD static void fp28_op(int op, const uint32_t* in, uint32_t* out) {
+    const F28 a = raw_load(in), b = raw_load(in + 14), c = raw_load(in + 28), d = raw_load(in + 42);
+    F28 r = F28::zero();
+    switch (op) {
+    case 0: r = zl::mul(a, b); break;
+    case 1: r = zl::sqr(a); break;
+    case 2: r = zl::muladd(a, b, c, d); break;
+    case 3: r = zl::add(a, b); break;
+    case 4: r = zl::dbl(a); break;
+    case 5: r = zl::subk<1>(a, b); break;
+    case 6: r = zl::subk<2>(a, b); break;
+    case 7: r = zl::subk<3>(a, b); break;
+    case 8: r = zl::subk<4>(a, b); break;
+    case 9: r = zl::subk<5>(a, b); break;
+    case 10: r = zl::subk<6>(a, b); break;
+    case 11: r = zl::wred(a); break;
+    case 12: r = zl::canon(a); break;
+    case 13: r.l[0] = a.is_zero() ? 1u : 0u; break;
+    case 14: r.l[0] = (a == b) ? 1u : 0u; break;
+    case 15: r = zl::muladd4(a, b, c, d, a, d, c, b); break;
+    case 17: r = FieldIO<F28>::load_canon(in); break;
+    case 18: {
+        uint32_t w[12];
+        FieldIO<F28>::store_canon(w, a);
+        for (int i = 0; i < 12; i++) r.l[i] = w[i];
+        break;
+    }
+    default: break;
+    }
+    raw_store(out, r);
+}
+static __global__ void __launch_bounds__(64) k_test_fp28(int op, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fp28_op(op, in + (size_t)i * 56, out + (size_t)i * 14);
+}
+
+template <class F> struct RawIO;
+template <> struct RawIO<F28> {
+    static constexpr int W = 14;
+    ZL_HD static F28 load(const uint32_t* w) { return raw_load(w); }
+    ZL_HD static void store(uint32_t* w, const F28& a) { raw_store(w, a); }
+};
+template <bool I> struct RawIO<Fp2LT<F28, I>> {
+    static constexpr int W = 28;
+    ZL_HD static Fp2LT<F28, I> load(const uint32_t* w) { return Fp2LT<F28, I>{raw_load(w), raw_load(w + 14)}; }
+    ZL_HD static void store(uint32_t* w, const Fp2LT<F28, I>& a) { raw_store(w, a.c0); raw_store(w + 14, a.c1); }
+};
+template <class F>
+ZL_HD static void point_op(int op, const uint32_t* in, uint32_t* out) {
+    constexpr int W = RawIO<F>::W;
+    XYZZ<F> p{RawIO<F>::load(in), RawIO<F>::load(in + W), RawIO<F>::load(in + 2 * W), RawIO<F>::load(in + 3 * W)};
+    const XYZZ<F> q{RawIO<F>::load(in + 4 * W), RawIO<F>::load(in + 5 * W), RawIO<F>::load(in + 6 * W), RawIO<F>::load(in + 7 * W)};
+    switch (op) {
+    case 0: zl::add_mixed(p, q.x, q.y, false); break;
+    case 1: zl::add_mixed(p, q.x, q.y, true); break;
+    case 2: zl::add_full(p, q); break;
+    case 3: zl::dbl_inplace(p); break;
+    case 4: p = zl::dbl_affine(p.x, p.y); break;
+    case 5: zl::neg_inplace(p); break;
+    case 6: {
+        const Affine<F> a = zl::to_affine(p);
+        p.x = a.x; p.y = a.y; p.zz = F::one(); p.zzz = F::one();
+        if (a.is_inf()) { p.zz = F::zero(); p.zzz = F::zero(); }
+        break;
+    }
+    default: break;
+    }
+    RawIO<F>::store(out, p.x);
+    RawIO<F>::store(out + W, p.y);
+    RawIO<F>::store(out + 2 * W, p.zz);
+    RawIO<F>::store(out + 3 * W, p.zzz);
+}
+template <class F>
+static __global__ void __launch_bounds__(64) k_test_point(int op, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int W = RawIO<F>::W;
+    point_op<F>(op, in + (size_t)i * 8 * W, out + (size_t)i * 4 * W);
+}
+
+template <class Launch>
+static int run_dev(zl_ctx* ctx, const uint32_t* in, size_t in_words, uint32_t* out, size_t out_words, Launch launch) {
+    void* d = nullptr;
+    int rc = zl_scratch_get(ctx, 9, (in_words + out_words) * 4 + 64, &d);
+    if (rc) return rc;
+    uint32_t* d_in = (uint32_t*)d;
+    uint32_t* d_out = d_in + in_words;
+    hipStream_t st = ctx->stream;
+    ZL_HIP(ctx, hipMemcpyAsync(d_in, in, in_words * 4, hipMemcpyHostToDevice, st));
+    launch(d_in, d_out, st);
+    ZL_HIP(ctx, hipGetLastError());
+    ZL_HIP(ctx, hipMemcpyAsync(out, d_out, out_words * 4, hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipStreamSynchronize(st));
+    return ZL_OK;
+}
+
+extern "C" {
+
+int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state) {
+    if (!ctx || !state) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    if (curve == ZL_BLS12_381) return poseidon_dev_t<BLS12_381_Fr>(ctx, state);
+    if (curve == ZL_BN254) return poseidon_dev_t<BN254_Fr>(ctx, state);
+    return ZL_EINVAL;
+}
+
+int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) {
+    if ((!in || !out) && n) return ZL_EINVAL;
+    if (op < 0 || op > 18 || op == 16 || n >= (1u << 24)) return ZL_EINVAL;
+    if (!n) return ZL_OK;
+    if (!ctx) {
+        for (size_t i = 0; i < n; i++) fp28_op(op, in + i * 56, out + i * 14);
+        return ZL_OK;
+    }
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return run_dev(ctx, in, n * 56, out, n * 14, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
+        hipLaunchKernelGGL(k_test_fp28, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, op, d_in, (uint32_t)n, d_out);
+    });
+}
+
+int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint32_t* in, size_t n, uint32_t* out) {
+    if ((!in || !out) && n) return ZL_EINVAL;
+    if (op < 0 || op > 6 || n >= (1u << 22) || (group != ZL_G1 && group != ZL_G2)) return ZL_EINVAL;
+    if (!n) return ZL_OK;
+    const size_t W = group == ZL_G1 ? 14 : 28;
+    if (!ctx) {
+        for (size_t i = 0; i < n; i++) {
+            if (group == ZL_G1) point_op<F28>(op, in + i * 8 * W, out + i * 4 * W);
+            else if (hot) point_op<Fp2LT<F28, true>>(op, in + i * 8 * W, out + i * 4 * W);
+            else point_op<Fp2LT<F28, false>>(op, in + i * 8 * W, out + i * 4 * W);
+        }
+        return ZL_OK;
+    }
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return run_dev(ctx, in, n * 8 * W, out, n * 4 * W, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
+        const dim3 grid((uint32_t)((n + 63) / 64)), block(64);
+        if (group == ZL_G1) hipLaunchKernelGGL((k_test_point<F28>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
+        else if (hot) hipLaunchKernelGGL((k_test_point<Fp2LT<F28, true>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
+        else hipLaunchKernelGGL((k_test_point<Fp2LT<F28, false>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
+    });
+}
+
+}  // extern "C"

@@ -18,8 +18,9 @@ def pytest_sessionstart(session):
     checkout can run `pytest -m "not gpu"` (hipcc cross-compiles gfx950 without a GPU)."""
     from openzl_amd import build as zb
 
-    if not os.path.exists(zb.LIB):
-        zb.build(verbose=False)
+    # always: build() is incremental (sha stamps over sources + headers), so an up-to-date tree costs milliseconds and a
+    # stale library after a source edit cannot be tested by accident
+    zb.build(verbose=False)
     import oracle_lib
 
     oracle_lib.build_oracle()

@@ -20,8 +20,9 @@ u8p = C.POINTER(C.c_uint8)
 
 def build_oracle(force: bool = False) -> str:
     so = os.path.join(ORACLE_DIR, "libzl_oracle.so")
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "all"])
+    if force:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "clean"])
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "all"])  # make is incremental: a stale oracle cannot be loaded by accident
     return so
 
 

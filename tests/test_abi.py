@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as ol
 from oracle_lib import po
-from openzl_amd.backend import ABI_SYMBOLS, ZL_PARTIAL_WORDS, load_library
+from openzl_amd.backend import ABI_SYMBOLS, TEST_ABI_SYMBOLS, ZL_PARTIAL_WORDS, load_library
 from openzl_amd.sharded import fold_partials
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,18 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(ABI_SYMBOLS)
     for sym in declared:
         assert getattr(L, sym) is not None
+
+
+def test_library_exports_every_declared_test_hook():
+    """include/zl_backend_test.h: test-only hooks (device field KAT, raw-limb field / point access); host paths run without a GPU"""
+    L = load_library()
+    hdr = open(os.path.join(ROOT, "include", "zl_backend_test.h")).read()
+    declared = set(re.findall(r"^\s*(?:const char\*|int|void|size_t)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared == set(TEST_ABI_SYMBOLS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert L.zl_test_fp28_op(None, 99, None, 0, None) == -1
+    assert L.zl_test_poseidon_permute_dev(None, 1, None) == -1
 
 
 def test_strerror_and_argument_checks():

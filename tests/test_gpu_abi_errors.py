@@ -109,3 +109,36 @@ def test_batch_edge_cases(backend):
         backend.msm_batch_partial_dev(987654, [d.data_ptr()], n)
     assert e.value.code == EHANDLE
     backend.bases_free(h)
+
+
+def test_groth16_rejects_malformed_csr(backend):
+    """zl_r1cs_upload validates the caller's CSR once (monotone row_ptr starting at 0, column indices < n_instance + n_witness): a
+    malformed matrix is ZL_EINVAL, never an out-of-bounds read in the sparse mat-vec kernel."""
+    curve = po.BLS12_381
+    import groth16_util as gu
+
+    cs = po.poseidon_chain_circuit(curve.fr, 1)
+    td = po.Groth16Trapdoor(3, 5, 7, 11, 13)
+    pk = gu.setup_with_trapdoor(curve, cs, td)
+    dpk = gu.upload_pk(backend, curve, pk)
+    z = ol.ints_to_limbs(cs.assignment(), 4)
+    r = ol.ints_to_limbs([1], 4)[0]
+    try:
+        good = gu.r1cs_arrays(cs)
+        backend.groth16_prove(curve.cid, dpk, good, z, r, r)  # sanity: the well-formed system proves
+        nv = good["n_instance"] + good["n_witness"]
+        for key, mutate in (("A", "col"), ("B", "ptr_nonmonotone"), ("C", "ptr_start")):
+            bad = dict(good)
+            ptr, col, val = (a.copy() for a in good[key])
+            if mutate == "col":
+                col[len(col) // 2] = nv  # one past the last variable
+            elif mutate == "ptr_nonmonotone":
+                ptr[3] = ptr[4] + 1
+            else:
+                ptr[0] = 1
+            bad[key] = (ptr, col, val)
+            with pytest.raises(BackendError) as e:
+                backend.groth16_prove(curve.cid, dpk, bad, z, r, r)
+            assert e.value.code == EINVAL, mutate
+    finally:
+        gu.free_pk(backend, dpk)

@@ -199,6 +199,47 @@ def test_msm_precomputed_known_discrete_log_2_20(backend):
     assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
 
 
+@pytest.mark.parametrize("mode", ["table_c22", "plain"])
+def test_msm_known_discrete_log_2_24(backend, mode):
+    """The exact configurations bench.py times (BASELINE metric: 2^24 BLS12-381 G1 points), checked exactly, not on a prefix:
+    table_c22 = zl_bases_precompute(h, 22) (12 windows, ONE merged set of 2^21 buckets, 64 sort groups, 128-entry chunks);
+    plain = no per-key work (what multi_scalar_mul(bases, scalars) is).  Expected point = (sum s_i k_i mod r) G, one O(n) dot product."""
+    import torch
+
+    from openzl_amd.selfcheck import dot_mod_r, expected_point
+
+    curve = po.BLS12_381
+    n = 1 << 24
+    k = ol.random_scalars(curve, n, 2401)
+    S = ol.random_scalars(curve, n, 2402)
+    S[5] = 0
+    S[6] = ol.ints_to_limbs([1], 4)[0]
+    S[7] = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]
+    h = backend.bases_generate(curve.cid, k)
+    if mode == "table_c22":
+        backend.bases_precompute(h, 22)
+    d_s = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+    # a second, different scalar vector through the pipelined batch entry point (three streams, rotating buffer sets): a cross-job
+    # buffer race cannot hide behind identical inputs
+    S2 = np.ascontiguousarray(S[::-1])
+    d_s2 = torch.from_numpy(S2.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    parts = backend.msm_batch_partial_dev(h, [d_s.data_ptr(), d_s2.data_ptr(), d_s.data_ptr(), d_s2.data_ptr()], n)
+    tm = backend.last_timing()
+    backend.bases_free(h)
+    r = curve.fr.p
+    exp1 = expected_point(backend, curve.cid, dot_mod_r(S, k, r))
+    exp2 = expected_point(backend, curve.cid, dot_mod_r(S2, k, r))
+    assert not inf and (got == exp1).all()
+    for j, e in enumerate((exp1, exp2, exp1, exp2)):
+        xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1])
+        assert not pinf and (xy == e).all(), j
+    if mode == "table_c22":
+        assert tm.window_bits == 22
+
+
 def _dot_mod_r_u64k(S: np.ndarray, k64: np.ndarray, r: int) -> int:
     """sum_i S_i * k_i mod r for (n,4) u64 scalars and u64 multipliers, exact, vectorised (32-bit limb products split into halves
     so that 2^26 of them sum inside a u64)."""
