@@ -214,7 +214,10 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 // Every (scalar i, window w) digit d contributes d * (2^(c w) P_i), and 2^(c w) P_i is a table entry, so all windows
 // share the buckets: n*W mixed adds into 2^(c-1) buckets and a single bucket reduction.  The bucket index has up to 23
 // bits, so the counting sort is two-level: partition by the high bits (group = bucket >> 15), then the LDS sort per group.
-static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+// spread_t >= 0 (plain wide windows only): the top window holds just spread_t + 1 bits, so its 2^spread_t magnitudes would crowd n entries
+// into 2^spread_t buckets (one sort group) while its bucket set has 2^(c-1).  It is spread over the whole set instead: bucket =
+// (low bits of the point index) << spread_t | (magnitude - 1); the reduction weights those buckets by their low spread_t bits only.
+static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint32_t gw, int spread_t,
                                                                   uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
                                                                   uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
     ZL_SIDE_PRIO();
@@ -241,9 +244,10 @@ static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* 
         uint32_t neg = 0;
         carry = 0;
         if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
-        const uint32_t b = d - 1;  // bucket (d != 0)
+        uint32_t b = d - 1;  // bucket (d != 0)
+        if (spread_t >= 0 && w == W - 1) b |= (i & ((1u << (c - 1 - spread_t)) - 1u)) << spread_t;
         lo16[(size_t)w * n + i] = (uint16_t)((b & 0x7FFFu) | (neg << 15));
-        hi8[(size_t)w * n + i] = d == 0 ? (uint8_t)0xFF : (uint8_t)(b >> 15);
+        hi8[(size_t)w * n + i] = d == 0 ? (uint8_t)0xFF : (uint8_t)((uint32_t)w * gw + (b >> 15));  // gw = groups per window (0: merged set)
     }
 }
 // block (slice, w): histogram of the group ids of window w over a slice of scalars -> counts[(g*W + w)*nslices + slice]
@@ -510,12 +514,16 @@ static __global__ void __launch_bounds__(256) k_msm_fine_hist(const uint16_t* __
     counts[(size_t)sg * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 // block per sub-group: sort the sub-group's entries by bucket inside LDS (cursors = bucket offsets relative to the sub-group),
-// then copy the staged run to the entry list with consecutive lanes writing consecutive words.  Oversized sub-groups (skewed
-// scalars) fall back to direct scattered stores.
+// then copy the staged run to the entry list with consecutive lanes writing consecutive words.  Oversized sub-groups (the narrow top
+// window concentrates its entries in few buckets; skewed scalars) are cut into tiles of ZL_BT entries and queued for
+// k_msm_fine_sort_big: (sub-group, first tile, tiles) records, index and tile base reserved with ONE 64-bit atomic so that the
+// record order is the tile order.
+#define ZL_BT 16384
 static __global__ void __launch_bounds__(1024) k_msm_fine_sort(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ idx2,
                                                                 const uint32_t* __restrict__ sub_off, uint32_t SG, uint32_t fslices,
                                                                 const uint32_t* __restrict__ total, const uint32_t* __restrict__ offsets, uint32_t cap,
-                                                                uint32_t* __restrict__ entries) {
+                                                                uint32_t* __restrict__ entries, unsigned long long* __restrict__ big_head,
+                                                                uint32_t* __restrict__ big_items) {
     ZL_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [256]
@@ -524,18 +532,104 @@ static __global__ void __launch_bounds__(1024) k_msm_fine_sort(const uint16_t* _
     const uint32_t s = sub_off[(size_t)sg * fslices], e = (sg + 1 < SG) ? sub_off[(size_t)(sg + 1) * fslices] : *total;
     const uint32_t base = offsets[(size_t)sg * 256];  // first entry slot of this sub-group (= s: same count, same order of groups)
     const uint32_t len = e - s;
-    const bool staged = len <= cap;
-    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) cur[b] = offsets[(size_t)sg * 256 + b] - (staged ? base : 0u);
+    if (len > cap) {
+        if (threadIdx.x == 0) {
+            const uint32_t tiles = (len + ZL_BT - 1) / ZL_BT;
+            const unsigned long long old = atomicAdd(big_head, (1ull << 32) | tiles);
+            const uint32_t item = (uint32_t)(old >> 32);
+            big_items[2 * item] = sg;
+            big_items[2 * item + 1] = (uint32_t)old;  // first tile
+        }
+        return;
+    }
+    for (uint32_t b = threadIdx.x; b < 256; b += blockDim.x) cur[b] = offsets[(size_t)sg * 256 + b] - base;
     __syncthreads();
     for (uint32_t j = s + threadIdx.x; j < e; j += blockDim.x) {
         const uint32_t code = lo2[j];
         const uint32_t pos = atomicAdd(&cur[code & 0xFFu], 1u);
-        const uint32_t v = idx2[j] | ((code >> 15) << 31);
-        if (staged) stage[pos] = v; else entries[pos] = v;
+        stage[pos] = idx2[j] | ((code >> 15) << 31);
     }
-    if (!staged) return;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < len; k += blockDim.x) entries[base + k] = stage[k];
+}
+// tiles of the oversized sub-groups, any number of blocks: a tile is sorted by bucket inside LDS, every bucket's run reserves its
+// place in the entry list with one atomic on the bucket's global cursor (initialised to the bucket offsets), and the runs are copied
+// out by consecutive lanes.  Which tile lands first inside a bucket is not deterministic; a bucket's SUM does not depend on the
+// order of its entries (group law), so results are unchanged.
+static __global__ void __launch_bounds__(1024) k_msm_fine_sort_big(const uint16_t* __restrict__ lo2, const uint32_t* __restrict__ idx2,
+                                                                    const uint32_t* __restrict__ sub_off, uint32_t SG, uint32_t fslices,
+                                                                    const uint32_t* __restrict__ total, const unsigned long long* __restrict__ big_head,
+                                                                    const uint32_t* __restrict__ big_items, uint32_t* __restrict__ cursor,
+                                                                    uint32_t* __restrict__ entries) {
+    ZL_SIDE_PRIO();
+    __shared__ uint32_t hist[256], start[257], gbase[256], wsum[4], item_sg, item_tile0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem);  // [ZL_BT]
+    const unsigned long long head = *big_head;
+    const uint32_t items = (uint32_t)(head >> 32), tiles = (uint32_t)head;
+    constexpr int EPT = ZL_BT / 1024;
+    for (uint32_t g = blockIdx.x; g < tiles; g += gridDim.x) {
+        if (threadIdx.x == 0) {  // record with the largest first-tile <= g (records are in tile order)
+            uint32_t lo = 0, hi = items;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (big_items[2 * mid + 1] <= g) lo = mid; else hi = mid;
+            }
+            item_sg = big_items[2 * lo];
+            item_tile0 = big_items[2 * lo + 1];
+        }
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t sg = item_sg;
+        const uint32_t s = sub_off[(size_t)sg * fslices], e = (sg + 1 < SG) ? sub_off[(size_t)(sg + 1) * fslices] : *total;
+        const uint32_t t0 = s + (g - item_tile0) * ZL_BT, t1 = min(e, t0 + ZL_BT), cnt = t1 - t0;
+        uint32_t val[EPT], bin[EPT], rank[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const uint32_t j = t0 + k * 1024 + threadIdx.x;
+            bin[k] = 0xFFFFFFFFu;
+            if (j < t1) {
+                const uint32_t code = lo2[j];
+                val[k] = idx2[j] | ((code >> 15) << 31);
+                bin[k] = code & 0xFFu;
+                rank[k] = atomicAdd(&hist[bin[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {  // exclusive scan of the 256 counts (4 waves) + run reservation
+            const uint32_t v = hist[threadIdx.x];
+            uint32_t x = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off);
+                if ((threadIdx.x & 63) >= (uint32_t)off) x += y;
+            }
+            if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+            gbase[threadIdx.x] = v ? atomicAdd(&cursor[(size_t)sg * 256 + threadIdx.x], v) : 0u;
+            hist[threadIdx.x] = x - v;  // exclusive inside the wave; wave bases are added below
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t wb = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wb += wsum[w];
+            start[threadIdx.x] = hist[threadIdx.x] + wb;
+            if (threadIdx.x == 255) start[256] = cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; k++)
+            if (bin[k] != 0xFFFFFFFFu) stage[start[bin[k]] + rank[k]] = val[k];
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < cnt; j += 1024) {
+            uint32_t lo = 0, hi = 256;  // bin with start[bin] <= j < start[bin + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (start[mid] <= j) lo = mid; else hi = mid;
+            }
+            entries[gbase[lo] + (j - start[lo])] = stage[j];
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -790,33 +884,86 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------ bucket reduction
-// lane (w, seg): buckets k = k0+1 .. k0+ZL_SEG of window w (bucket index k-1).  sum k*B_k = sum (k-k0) B_k + k0 * sum B_k
+// sum_{k=1..H} k * B_k per bucket set, hierarchically and without any scalar multiple.  A block of L consecutive buckets is summarised by
+// the pair (A, R): A = sum_j j * B_{k0+j} (weights local to the block), R = sum_j B_{k0+j}.  G consecutive blocks of equal length L
+// combine to  A = sum_i A_i + L * sum_i i * R_i,  R = sum_i R_i  (i = 0..G-1): one running-sum pass over the R_i (2 additions per
+// element), one addition per A_i, and log2(L) doublings + 1 addition per lane for the factor L.  Level 0 (L = 1) reads the buckets
+// themselves (A_i = R_i = B_i: the classic running sum, 2 additions per bucket).  Every level is one launch with one lane per output
+// block, so the lane count falls by G per level and no lane ever runs a double-and-add ladder for its offset (the former k0 * run
+// term cost more than the segment's own additions).  The root block's A is the window sum.
+// in_a == nullptr: level 0 (elements are single buckets).  Elements of set s live at [s * in_stride, s * in_stride + count).
+// Above level 0 a block is shared by a lane pair: the even lane sums the A_i, the odd lane runs the weighted chain over the R_i and
+// hands its result over by shuffles, so the dependent chain per level is 2 * group additions instead of 3 * group.
+// flat_set / flat_log: blocks of set flat_set whose inputs are at least 2^flat_log buckets long carry no offset weight (the spread
+// top window, k_msm_recode_wide): A = sum A_i there.
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_reduce_seg(const XYZZ<typename G::F>* __restrict__ bucket_sums, uint32_t H, uint32_t segs_per_window,
-                                                        uint32_t total_segs, XYZZ<typename G::F>* __restrict__ seg_out, uint32_t ZL_SEG) {
+__global__ void __launch_bounds__(64) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ in_r, uint32_t in_stride, uint32_t count, uint32_t group,
+                                                           uint32_t blocks_per_set, uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
+                                                           XYZZ<typename G::F>* __restrict__ out_a, XYZZ<typename G::F>* __restrict__ out_r) {
+    ZL_SIDE_PRIO();
+    using X = XYZZ<typename G::F>;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_blocks) return;
+    const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
+    const uint32_t i0 = blk * group, i1 = min(count, i0 + group);
+    const size_t base = (size_t)set * in_stride;
+    const bool flat = set == flat_set && flat_log == 0;
+    // wsum = sum (i - i0 + 1) * B_i, run = sum B_i
+    X run = X::inf(), wsum = X::inf();
+    for (uint32_t i = i1; i > i0; i--) {
+        const X B = in_r[base + (i - 1)];
+        zl::add_full(run, B);
+        if (!flat) zl::add_full(wsum, run);
+    }
+    out_a[t] = flat ? run : wsum;
+    out_r[t] = run;
+}
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_reduce_level(const XYZZ<typename G::F>* __restrict__ in_a, const XYZZ<typename G::F>* __restrict__ in_r,
+                                                          uint32_t in_stride, uint32_t count, uint32_t group, uint32_t log_len, uint32_t blocks_per_set,
+                                                          uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
+                                                          XYZZ<typename G::F>* __restrict__ out_a, XYZZ<typename G::F>* __restrict__ out_r) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_segs) return;
-    const uint32_t w = t / segs_per_window, seg = t % segs_per_window;
-    const uint32_t k0 = seg * ZL_SEG;
-    const uint32_t hi = min(H, k0 + ZL_SEG);
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-    for (uint32_t k = hi; k > k0; k--) {
-        const XYZZ<F> B = bucket_sums[(size_t)w * H + (k - 1)];
-        zl::add_full(run, B);
-        zl::add_full(acc, run);
-    }
-    if (k0 != 0 && !run.is_inf()) {
-        // k0 * run, k0 < 2^23
-        XYZZ<F> m = XYZZ<F>::inf();
-        for (int i = 31 - __clz(k0); i >= 0; i--) {
-            zl::dbl_inplace(m);
-            if ((k0 >> i) & 1) zl::add_full(m, run);
+    using X = XYZZ<F>;
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = lane >> 1, role = lane & 1u;
+    const bool live = t < total_blocks;
+    const uint32_t tt = live ? t : 0u;
+    const uint32_t set = tt / blocks_per_set, blk = tt % blocks_per_set;
+    const uint32_t i0 = blk * group, i1 = live ? min(count, i0 + group) : i0;
+    const size_t base = (size_t)set * in_stride;
+    const bool flat = set == flat_set && log_len >= flat_log;
+    X acc = X::inf(), run = X::inf();
+    if (role == 0) {
+        for (uint32_t i = i0; i < i1; i++) {  // sum A_i
+            const X A = in_a[base + i];
+            zl::add_full(acc, A);
         }
-        zl::add_full(acc, m);
+    } else {
+        // acc = sum (i - i0) * R_i (the first element has weight 0), run = sum R_i
+        for (uint32_t i = i1; i > i0; i--) {
+            const X R = in_r[base + (i - 1)];
+            zl::add_full(run, R);
+            if (i - 1 > i0 && !flat) zl::add_full(acc, run);
+        }
+        if (!flat) for (uint32_t k = 0; k < log_len; k++) zl::dbl_inplace(acc);  // * L (a power of two)
     }
-    seg_out[t] = acc;
+    // the odd lane's weighted sum travels to the even lane (all lanes of the wave take part in the shuffles)
+    X other;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(X) / 4; k++) dst[k] = __shfl_xor(src[k], 1);
+    }
+    if (!live) return;
+    if (role == 0) {
+        zl::add_full(acc, other);
+        out_a[t] = acc;
+    } else {
+        out_r[t] = run;
+    }
 }
 // tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
 // set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
@@ -928,13 +1075,16 @@ static int zl_tune(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 static int zl_pick_window(size_t n, int sc_bits) {
-    // accumulate: n mixed adds per window; per-bucket overhead (merge + segmented reduce) measured at ~2 add-equivalents
-    // (tools/msm_sweep.py: c = 16 wins from 2^18 up, c = 13 at 2^16).  c <= 16 keeps the LDS counting sort.
+    // accumulate: n mixed adds per window; per-bucket overhead (merge of cut buckets + hierarchical reduce, measured at 2^24: ~7) in
+    // mixed-add equivalents.  c <= 16: one-level LDS counting sort; 17..20: the three-level sort over W bucket sets (tools/msm_sweep.py).
+    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 70) / 10.0;
     double best = 1e300;
     int best_c = 2;
-    for (int c = 2; c <= 16; c++) {
+    for (int c = 2; c <= 20; c++) {
         int W = (sc_bits + 1 + c - 1) / c;
-        double cost = (double)n * W + 2.0 * W * (double)(1u << (c - 1));
+        if (c > 16 && (((uint64_t)W << (c - 1)) >> 15) > 255) continue;
+        double cost = (double)n * W + per_bucket * W * (double)(1u << (c - 1));
+        if (c > 16) cost += 0.04 * (double)n * W;  // the wider sort costs more per entry
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
@@ -967,14 +1117,20 @@ struct MsmJob {
     // plan
     bool pre = false;
     int c = 0, W = 0;
-    uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, ZL_SEG = 0, segs_per_set = 0, total_segs = 0, scan_blocks = 0, max_big = 0, max_giant = 0,
-             SUMW = 256, stage1 = 0;
+    int spread_t = -1;  // >= 0: the top window's entries are spread over its bucket set, weights = low spread_t bits + 1
+    bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
+    uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, scan_blocks = 0, max_big = 0, max_giant = 0, Gn = 0;
+    struct RedLevel { uint32_t count, group, log_len, blocks; size_t out_off; };
+    std::vector<RedLevel> red;  // hierarchical bucket reduction: level 0 reads the buckets, the last level leaves one point per set
+    size_t red_elems = 0;       // (A, R) pairs of all levels
     uint64_t maxE = 0;
     size_t n = 0, first = 0;
     const zl_bases* bsp = nullptr;
     // buffers
     uint32_t *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_entries = nullptr, *d_block_sums = nullptr, *d_big_list = nullptr,
-             *d_big_count = nullptr, *d_ones_count = nullptr, *d_giant_count = nullptr, *d_giant_list = nullptr, *d_ones_list = nullptr;
+             *d_big_count = nullptr, *d_ones_count = nullptr, *d_giant_count = nullptr, *d_giant_list = nullptr, *d_ones_list = nullptr,
+             *d_bigsg_items = nullptr;
+    unsigned long long* d_bigsg_head = nullptr;
     X *d_buckets = nullptr, *d_partials = nullptr, *d_segs = nullptr, *d_stage1 = nullptr, *d_sets = nullptr, *d_ones_parts = nullptr, *d_giant_tmp = nullptr;
     const Affine<F>* d_bases = nullptr;
     const uint32_t* sc = nullptr;
@@ -999,25 +1155,52 @@ struct MsmJob {
         maxE = (uint64_t)n * W;
         if (n >= (1ull << 31) || maxE >= (1ull << 32) || NB64 >= (1ull << 31)) return ZL_EINVAL;
         if (pre && (uint64_t)W * bs.n >= (1ull << 31)) return ZL_EINVAL;
-        if (pre && (c < 16 || (H >> 15) < 1 || (H >> 15) > 256)) return ZL_EINVAL;
         NB = (uint32_t)NB64;
+        Gn = NB >> 15;  // sort groups of 32768 (window, bucket) ids; the group id travels in a byte, 0xFF = zero digit
+        if (pre && (c < 16 || Gn < 1 || Gn > 255)) return ZL_EINVAL;
+        wide = pre || (c > 16 && Gn <= 255);  // plain windows beyond that (c >= 21) fall back to the global-atomics sort
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         // (128 once there are >= 2^20 lanes of that length: half as many cut buckets to merge; 32.8 -> 32.2 ms per pipelined 2^24 MSM)
         ZL_CHUNK = (maxE >> 7) >= (1u << 20) ? 128u : (uint32_t)ZL_CHUNK_MAX;
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
-        // segment length of the bucket reduction: long for the big merged set (amortises the k0 multiple), short otherwise so that
-        // the kernel has at least one wave per SIMD (measured: 2^20 plain 4.18 -> 4.04 ms, 2^16 1.81 -> 1.49 ms)
-        ZL_SEG = (SETS == 1 && H >= (1u << 19)) ? 32u : (NB >= (1u << 17) ? 8u : 4u);
-        ZL_SEG = (uint32_t)std::max(1, zl_tune("ZL_TUNE_SEG", (int)ZL_SEG));
-        segs_per_set = (H + ZL_SEG - 1) / ZL_SEG;
-        total_segs = segs_per_set * SETS;
+        // hierarchical bucket reduction (k_msm_reduce_level): groups of 8 (4 for small inputs: more lanes, shorter chains) per level
+        {
+            uint32_t g0 = NB >= (1u << 17) ? 8u : 4u;
+            g0 = (uint32_t)std::max(2, zl_tune("ZL_TUNE_SEG", (int)g0));
+            const uint32_t gk = (uint32_t)std::max(2, zl_tune("ZL_TUNE_GRP", 4));
+            // plain wide windows: spread the narrow top window over its whole bucket set (k_msm_recode_wide); its low spread_t bits
+            // carry the weight, so a level boundary must fall on block length 2^spread_t
+            spread_t = -1;
+            if (wide && !pre) {
+                const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
+                if (top_bits - 1 < c - 1) spread_t = top_bits - 1;
+            }
+            red.clear();
+            red_elems = 0;
+            uint32_t count = H, log_len = 0;
+            for (;;) {
+                uint32_t g = red.empty() ? g0 : gk;
+                while (g & (g - 1)) g &= g - 1;  // power of two (block lengths stay powers of two)
+                if (spread_t > 0 && (int)log_len < spread_t) {
+                    while (g > 2 && log_len + 31 - __builtin_clz(g) > (uint32_t)spread_t) g >>= 1;
+                    if (log_len + 31 - __builtin_clz(g) > (uint32_t)spread_t) g = 1u << ((uint32_t)spread_t - log_len);
+                }
+                if (g > count) g = count;
+                const uint32_t blocks = (count + g - 1) / g;
+                red.push_back(RedLevel{count, g, log_len, blocks, red_elems});
+                red_elems += (size_t)SETS * blocks;
+                if (blocks == 1) break;
+                uint32_t lg = 0;
+                while ((1u << lg) < g) lg++;
+                log_len += lg;
+                count = blocks;
+            }
+        }
         scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
         max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
         max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
-        // tree over the segment results: sets with many segments are summed in two stages
-        stage1 = segs_per_set > 2 * SUMW ? (segs_per_set + SUMW - 1) / SUMW : 0;  // partial sums per set (0 = single stage)
         d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         sc = reinterpret_cast<const uint32_t*>(d_scalars);
         hw_own.assign(SETS + 1, X::inf());
@@ -1032,7 +1215,8 @@ struct MsmJob {
         int rc;
         const int o = set == 0 ? 0 : (set == 1 ? 10 : 14);
         // counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
-        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n;
+        const size_t max_bigsg = (size_t)(maxE / 1024) + 2;  // oversized sub-groups hold > cap >= 1024 entries each
+        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n + 2 * max_bigsg;
         if ((rc = zl_scratch_get(ctx, o + 0, small_words * 4, &p))) return rc;
         d_counts = (uint32_t*)p;
         d_offsets = d_counts + (NB + 1);
@@ -1044,16 +1228,18 @@ struct MsmJob {
         d_giant_count = d_big_count + 2;
         d_giant_list = d_big_count + 16;
         d_ones_list = d_giant_list + max_giant;
+        d_bigsg_items = d_ones_list + n;
+        d_bigsg_head = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(d_big_count + 4) + 7) & ~(uintptr_t)7);  // inside words 4..7
         if ((rc = zl_scratch_get(ctx, o + 1, maxE * 4, &p))) return rc;
         d_entries = (uint32_t*)p;
         if ((rc = zl_scratch_get(ctx, o + 2, (size_t)NB * sizeof(X), &p))) return rc;
         d_buckets = (X*)p;
         if ((rc = zl_scratch_get(ctx, o + 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
         d_partials = (X*)p;
-        if ((rc = zl_scratch_get(ctx, 4, ((size_t)total_segs + (size_t)SETS * (stage1 + 1) + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
-        d_segs = (X*)p;
-        d_stage1 = d_segs + total_segs;
-        d_sets = d_stage1 + (size_t)SETS * stage1;  // SETS window sums, then the sum of the scalar-1 bases
+        if ((rc = zl_scratch_get(ctx, 4, ((size_t)2 * red_elems + (size_t)SETS + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
+        d_segs = (X*)p;                    // A parts of all reduction levels
+        d_stage1 = d_segs + red_elems;     // R parts
+        d_sets = d_stage1 + red_elems;     // SETS window sums, then the sum of the scalar-1 bases
         d_ones_parts = d_sets + SETS + 1;
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
         return ZL_OK;
@@ -1062,8 +1248,7 @@ struct MsmJob {
     // largest job before anything is in flight (a growing zl_scratch_get frees the old block)
     void sort_tmp_sizes(size_t& s5, size_t& s6) const {
         s5 = s6 = 0;
-        if (pre) {
-            const uint32_t Gn = H >> 15;
+        if (wide) {
             uint32_t nslices = 64;
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
@@ -1078,7 +1263,7 @@ struct MsmJob {
             const uint32_t P2 = Gn * 128 * fsl;
             const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
             s6 = b_lo + b_pidx + (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256 + 256;
-        } else if (c <= 16) {
+        } else {
             uint32_t nslices = (256 + W - 1) / W;
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
@@ -1090,14 +1275,13 @@ struct MsmJob {
         const zl_bases& bs = *bsp;
         int rc;
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
-        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 12, st));  // big, ones, giant counts
+        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 32, st));  // big, ones, giant counts; [4..5]: oversized sub-group queue head (u64)
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
         // per call, not once per process: the attribute is per device and a process may own several contexts
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (pre) {
-            // ---- two-level counting sort over the merged bucket set ------------------------------------------------------
-            const uint32_t Gn = H >> 15;  // groups of 32768 fine buckets
+        if (wide) {
+            // ---- three-level counting sort over (window, bucket) ids: the merged set of a table, or W sets of plain wide windows ------
             uint32_t nslices = 64;
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
@@ -1117,13 +1301,13 @@ struct MsmJob {
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_lo16, d_hi8, d_ones_list, d_ones_count);
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
             hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
             hipLaunchKernelGGL(k_msm_part_scatter_st, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
-                               (uint32_t)bs.n, (uint32_t)first, d_part_lo, d_part_idx);
+                               pre ? (uint32_t)bs.n : 0u, pre ? (uint32_t)first : 0u, d_part_lo, d_part_idx);  // plain: d_bases already starts at `first`
             const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
             // level 2: 128 sub-groups (256 buckets each) per group; level 3: LDS-staged sort per sub-group
             const uint32_t SG = Gn * 128;
@@ -1150,10 +1334,16 @@ struct MsmJob {
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            const uint32_t cap = 36 * 1024;  // staged entries per block: 144 KiB + 1 KiB of cursors (1 block per CU); typical sub-group: n*W/SG
+            // staged entries per block: at most 144 KiB + 1 KiB of cursors (1 block per CU); sub-groups average n*W/SG entries, so many small
+            // sub-groups (plain wide windows) get a smaller stage and two blocks per CU
+            uint32_t cap = (uint32_t)std::min<uint64_t>(36 * 1024, std::max<uint64_t>(4096, (maxE / SG) * 22 / 10));
+            cap = (uint32_t)std::max(1024, zl_tune("ZL_TUNE_FS_CAP", (int)cap));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(zl_tune("ZL_TUNE_FS", 1024)), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
-                               d_entries);
+                               d_entries, d_bigsg_head, d_bigsg_items);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize, ZL_BT * 4);
+            hipLaunchKernelGGL(k_msm_fine_sort_big, dim3(512), dim3(1024), (size_t)ZL_BT * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_bigsg_head,
+                               d_bigsg_items, d_cursor, d_entries);
         } else if (c <= 16) {
             // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
             uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
@@ -1205,13 +1395,19 @@ struct MsmJob {
                            pre ? d_bases + first : d_bases, d_ones_parts);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
                            (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + SETS);
-        hipLaunchKernelGGL((k_msm_reduce_seg<G>), dim3((total_segs + 63) / 64), dim3(64), 0, st, d_buckets, H, segs_per_set, total_segs, d_segs, ZL_SEG);
-        if (stage1) {
-            // (set, part) partial sums of SUMW segment results each, then one block per set over the partials
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS * stage1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, SUMW, segs_per_set, stage1, d_stage1);
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_stage1, stage1, stage1, 1u, d_sets);
-        } else {
-            hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(SETS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_segs, segs_per_set, segs_per_set, 1u, d_sets);
+        for (size_t l = 0; l < red.size(); l++) {
+            const RedLevel& L = red[l];
+            const uint32_t total = SETS * L.blocks;
+            const X* in_a = l == 0 ? (const X*)nullptr : d_segs + red[l - 1].out_off;
+            const X* in_r = l == 0 ? d_buckets : d_stage1 + red[l - 1].out_off;
+            X* out_a = l + 1 == red.size() ? d_sets : d_segs + L.out_off;  // root blocks: the window sums
+            const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
+            if (l == 0)
+                hipLaunchKernelGGL((k_msm_reduce_level0<G>), dim3((total + 63) / 64), dim3(64), 0, st, in_r, H, L.count, L.group, L.blocks, total, fset, flog, out_a,
+                                   d_stage1 + L.out_off);
+            else
+                hipLaunchKernelGGL((k_msm_reduce_level<G>), dim3((2 * total + 63) / 64), dim3(64), 0, st, in_a, in_r, red[l - 1].blocks, L.count, L.group, L.log_len,
+                                   L.blocks, total, fset, flog, out_a, d_stage1 + L.out_off);
         }
         ZL_HIP(ctx, hipGetLastError());
         ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * (SETS + 1), hipMemcpyDeviceToHost, st));

@@ -182,6 +182,36 @@ def test_msm_precomputed_table_matches_plain(backend, curve, c):
     assert sinf == e2inf and (sub == e2).all()
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("c", [17, 18, 19, 20])
+def test_msm_plain_wide_windows_match_oracle(backend, curve, c):
+    """plain (no table) windows wider than 16 bits: every window keeps its own bucket set and the three-level sort runs over
+    (window, bucket) ids; the hierarchical bucket reduction has 6-7 levels here.  Must not change any result."""
+    n = 4000
+    k, B = _bases(curve, n, 171)
+    S = ol.random_scalars(curve, n, 172)
+    S[0] = 0
+    S[1] = ol.ints_to_limbs([1], 4)[0]
+    S[2] = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]
+    S[3] = ol.ints_to_limbs([(1 << (c - 1))], 4)[0]      # digit exactly at the sign boundary
+    S[4] = ol.ints_to_limbs([(1 << (c - 1)) + 1], 4)[0]  # first negative digit with a carry
+    S[100:300] = S[100]
+    B[5] = 0
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=8)
+    h = backend.bases_upload(curve.cid, B)
+    backend.set_msm_window(c)
+    try:
+        got, inf = backend.msm(h, S)
+        assert backend.last_timing().window_bits == c
+        sub, sinf = backend.msm(h, S[500:1500], first=500)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
+    assert inf == einf and (got == exp).all()
+    e2, e2inf = ol.oracle_msm_g1(curve, B[500:1500], S[500:1500], algo=0, threads=8)
+    assert sinf == e2inf and (sub == e2).all()
+
+
 def test_msm_precomputed_known_discrete_log_2_20(backend):
     curve = po.BLS12_381
     n = 1 << 20

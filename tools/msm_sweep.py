@@ -51,3 +51,11 @@ for ln in sizes:
             torch.cuda.synchronize(); t0 = time.perf_counter(); be.msm_dev(h, s.data_ptr(), n); ts.append(time.perf_counter() - t0)
         tm = be.last_timing()
         print(f"2^{ln} c={tm.window_bits:2d}: wall {min(ts)*1e3:8.3f} ms  dev {tm.total_ms:8.3f} ms  acc {tm.dominant_ms:8.3f} ms  {n/min(ts)/1e6:8.1f} Mpts/s", flush=True)
+        nb = int(os.environ.get("BATCH", "0"))
+        if nb:
+            be.msm_batch_partial_dev(h, [s.data_ptr()] * nb, n)
+            tb = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0b = time.perf_counter(); be.msm_batch_partial_dev(h, [s.data_ptr()] * nb, n); tb.append((time.perf_counter() - t0b) / nb)
+            tmb = be.last_timing()
+            print(f"2^{ln} c={tmb.window_bits:2d} BATCH {nb}: wall/MSM {min(tb)*1e3:8.3f} ms  dev/MSM {tmb.total_ms:8.3f} ms  acc {tmb.dominant_ms:8.3f} ms  {n/min(tb)/1e6:8.1f} Mpts/s", flush=True)

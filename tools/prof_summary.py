@@ -25,5 +25,16 @@ def main(path):
         print(f"{name:<70} {r[1]:>6} {r[2]/1e3:>12.1f} {r[3]/1e3:>11.1f} {r[4]/1e3:>11.1f} {r[5]/1e3:>11.1f} {big[r[0]][0]:>5} {big[r[0]][1]/1e3:>11.1f} {100*r[2]/total:>6.2f} {r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>7} {r[11]:>10} {r[12]:>5}")
 
 
+def launches(path, substr, limit=40):
+    """individual launches of the kernels whose name contains `substr`, in start order (e.g. the levels of the bucket reduction)"""
+    db = sqlite3.connect(path)
+    rows = db.cursor().execute("select name, start, duration, grid_x, workgroup_x from kernels where name like ? order by start limit ?", (f"%{substr}%", limit)).fetchall()
+    print(f"# launches of *{substr}* in start order")
+    for name, start, dur, grid, wg in rows:
+        print(f"{name.split('(')[0].replace('void ', ''):<60} {dur/1e3:>10.1f} us  grid {grid:>9} wg {wg}")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    for sub in sys.argv[2:]:
+        launches(sys.argv[1], sub)
