@@ -5,17 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one variable-base MSM over 2^log_n random BLS12-381 G1 points and random scalars < r per GPU, bases and
-scalars already resident in HBM, through the C ABI (zl_msm_partial_dev); with N > 1 every rank owns its own shard of
+scalars already resident in HBM, through the C ABI (zl_msm_batch_partial_dev / zl_msm_partial_dev), with NO per-key precomputation:
+`value` is what multi_scalar_mul(bases, scalars) is.  Every timed step is checked exactly at full size against (sum s_i k_i) G
+(the bases have known discrete logs).  With N > 1 every rank owns its own shard of
 bases/scalars (weak scaling), the per-rank partial sums (512 B) are all-gathered over RCCL and folded
 on every rank (zl_partials_sum).  Rank 0 prints ONE JSON line.  Extra objects on that line:
   roofline      HBM roofline of the dominant kernel (k_msm_accumulate): algorithmic bytes (128 B / point, SURVEY.md
                 §8d) / its HIP-event duration on the backend's stream, vs 8 TB/s; .int_alu = the integer-multiply roofline
                 that actually binds; .traffic = PMC bytes of the same configuration (profiles/)
-  cpu_baseline  the CPU oracle (arkworks-algorithm restatement, NOT the arkworks binary) timed on this box's cores (N = 1 only)
+  cpu_baseline  the CPU oracle (arkworks-algorithm restatement, NOT the arkworks binary) timed on this box's cores on the same input
+                (N = 1 only): all-core (chunk x window) grid on the complete input (value; must equal the GPU result bit for bit), window-parallel
+                (arkworks `parallel`) and single-threaded (the reference's configuration) on bounded samples
+  pcie_inclusive    the same MSM with the scalars coming from host memory (zl_msm); never `value`
+  msm_fixed_key     the precomputed-table mode (zl_bases_precompute, c = 22) with its build time, bytes and break-even count; never `value`
   msm_skewed_scalars  the same MSM on Groth16-witness-like scalars (N = 1 only)
-  ntt           2^24 BLS12-381 Fr forward+inverse NTT throughput (second half of the BASELINE metric); N > 1: per-GPU replicas
+  ntt           2^24 BLS12-381 Fr forward+inverse NTT throughput (second half of the BASELINE metric) + its own roofline and cpu_baseline
+                (the CPU oracle's transform of the same vector must equal the GPU's bit for bit); N > 1: per-GPU replicas
                 and .distributed = ONE 2^(24 + log2 N) transform over all ranks with a single RCCL all-to-all
-  groth16       config 5 (Poseidon-chain circuit, 958 465 constraints) prove time / constraints per second, proof verified;
+  groth16       config 5 (Poseidon-chain circuit, 958 465 constraints) prove time / constraints per second, proof verified, + cpu_baseline
+                (the CPU oracle's proof from the same key / witness / (r, s) must equal the GPU proof bit for bit);
                 N > 1: one independent proof per GPU (replicas)
 The secondary legs of an N > 1 run execute after the MSM measurement under a watchdog, so a stall there cannot cost the MSM line.
 """
@@ -63,40 +71,107 @@ def limbs_to_int(row) -> int:
     return sum(int(v) << (64 * j) for j, v in enumerate(row))
 
 
-def cpu_baseline(log_n_sample: int, threads_req: int):
-    """Time the CPU oracle (oracle/libzl_oracle.so, 'port' of the arkworks 0.3.0 algorithm) on a bounded sample of the
-    same workload.  Checker code used as a *reported baseline* only -- never on the product path."""
+def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
+    """Time the CPU oracle (oracle/libzl_oracle.so: plain-C restatement of the arkworks 0.3.0 algorithm, 'port') on the host cores of this
+    box, on the SAME bases and scalars the GPU was timed on (bases downloaded from the device, canonical affine).  Checker code used as a
+    reported baseline only -- never on the product path.  Three configurations:
+      all-core (chunk x window) grid (value): the FULL input is cut into chunks so that chunks x windows ~ threads, every (chunk, window)
+          pair is one task of ark's window routine, partial sums are added -- the strongest CPU arrangement of the same algorithm
+          (not an arkworks configuration); its result must equal the GPU's full-size result bit for bit;
+      window-parallel: what arkworks' `parallel` feature does (one thread per window), on a 2^22 sample with the window width ark's rule
+          gives the full input;
+      single thread: the reference's actual configuration (no `parallel` feature), on a 2^18 sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     from oracle_lib import po
 
     curve = po.BLS12_381
-    n = 1 << log_n_sample
-    k = random_scalars_lt_r(n, 901)
-    bases = ol.oracle_g1_mul_gen(curve, k)
-    s = random_scalars_lt_r(n, 902)
+    n = s_host.shape[0]
     avail = os.cpu_count() or 1
-    c = po.ark_window_bits(n)
-    windows = (255 + c - 1) // c
-    threads = max(1, min(threads_req or avail, windows))
+    threads = max(1, min(threads_req or avail, avail))
     t0 = time.perf_counter()
-    r1 = ol.oracle_msm_g1(curve, bases, s, algo=0, threads=1)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rN = ol.oracle_msm_g1(curve, bases, s, algo=0, threads=threads)
-    tN = time.perf_counter() - t0
-    assert (r1[0] == rN[0]).all()
+    bases = be.bases_download(h)  # canonical affine x||y, the very points the GPU used
+    t_dl = time.perf_counter() - t0
+    xy, inf, sec_all = ol.oracle_msm_g1_timed(curve, bases, s_host, algo=2, threads=threads)
+    parity = bool(inf == 0 and (xy == np.asarray(gpu_xy)).all())
+    if not parity:
+        raise SystemExit("full-size parity check failed: the CPU oracle's MSM of the complete input differs from the GPU result")
+    c_full = po.ark_window_bits(n)
+    m = min(n, 1 << 22)
+    windows = (255 + c_full - 1) // c_full
+    wt = max(1, min(threads, windows))
+    _, _, sec_win = ol.oracle_msm_g1_timed(curve, bases[:m], s_host[:m], algo=0, threads=wt, c_override=c_full)
+    m1 = min(n, 1 << 18)
+    _, _, sec_one = ol.oracle_msm_g1_timed(curve, bases[:m1], s_host[:m1], algo=0, threads=1)
+    del bases
     return {
-        "value": n / tN,
+        "value": n / sec_all,
         "unit": "points/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"2^{log_n_sample} BLS12-381 G1 points, ark window rule c={c} ({windows} windows), window-parallel over {threads} threads "
-                  f"(what arkworks' `parallel` feature does); arkworks-algorithm restatement, not the arkworks binary",
-        "single_thread_value": n / t1,
-        "single_thread_note": "1 thread = the reference's actual configuration (no `parallel` feature, plugins/arkworks/Cargo.toml)",
+        "sample": f"the complete 2^{full_log_n} BLS12-381 G1 input of the GPU run (same bases, same scalars) as a (chunk x window) task grid over {threads} "
+                  f"threads (ark's window routine per task, ark window rule for the chunk length, partials added); arkworks-algorithm "
+                  f"restatement in C, not the arkworks binary; {sec_all:.2f} s of wall time",
+        "parity_full_size": parity,
+        "parity_note": "the CPU result over the complete input equals the GPU result bit for bit (canonical affine coordinates)",
+        "window_parallel": {"value": m / sec_win, "cores": wt, "sample": f"2^{m.bit_length() - 1} prefix with the full input's window width c={c_full} "
+                            f"({windows} windows, one thread each: what arkworks' `parallel` feature does; the sample over-weights the bucket "
+                            f"reduction by ~{100.0 * 2 * (1 << c_full) / m:.0f} % relative to the full input)"},
+        "single_thread": {"value": m1 / sec_one, "cores": 1, "sample": f"2^{m1.bit_length() - 1} prefix, ark window rule for that size; 1 thread = the reference's "
+                          "actual configuration (no `parallel` feature, plugins/arkworks/Cargo.toml)"},
         "host_cpus": avail,
-    }, (curve, bases, s, r1)
+        "bases_download_s": t_dl,
+    }
+
+
+def cpu_baseline_ntt(x_mont: np.ndarray, threads_req: int):
+    """CPU oracle NTT (in-order radix-2 with a tabulated root table, as ark-poly 0.3.0) on the GPU run's input: all cores on the full
+    vector (value), one thread (the reference's configuration) on a 2^22 prefix."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from oracle_lib import po
+
+    curve = po.BLS12_381
+    n = x_mont.shape[0]
+    avail = os.cpu_count() or 1
+    threads = max(1, min(threads_req or avail, avail, 64))
+    X, sec_f = ol.oracle_ntt_timed(curve, x_mont, inverse=False, threads=threads)
+    back, sec_i = ol.oracle_ntt_timed(curve, X, inverse=True, threads=threads)
+    if not (back == x_mont).all():
+        raise SystemExit("CPU oracle NTT round trip failed")
+    m = min(n, 1 << 22)
+    _, sec_1 = ol.oracle_ntt_timed(curve, np.ascontiguousarray(x_mont[:m]), inverse=False, threads=1)
+    return {"value": 2.0 * n / (sec_f + sec_i), "unit": "elements/s (forward + inverse)", "cores": threads, "kind": "port",
+            "sample": f"the complete 2^{n.bit_length() - 1} vector of the GPU run, forward then inverse, butterflies of every stage split over {threads} threads",
+            "forward_s": sec_f, "inverse_s": sec_i,
+            "single_thread": {"value": m / sec_1, "unit": "elements/s (forward)", "cores": 1, "sample": f"2^{m.bit_length() - 1} prefix, forward"}}, X
+
+
+def cpu_baseline_groth16(be, keys, circ, gpu_proof, r, s, threads_req: int):
+    """The CPU oracle's Groth16 prover (witness map + 4 G1 MSMs + 1 G2 MSM, window-parallel MSMs = arkworks `parallel`) on the SAME proving
+    key (downloaded from the device), R1CS, witness and blinding scalars: must produce the GPU's proof bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import groth16_util as gu
+    from oracle_lib import po
+    from openzl_amd import ZL_G2  # noqa: F401
+
+    curve = po.BLS12_381
+    avail = os.cpu_count() or 1
+    threads = max(1, min(threads_req or avail, avail, 32))
+    arrays = circ.arrays()
+    pk = keys.pk_dict()
+    for name in ("a_query", "b_g1_query", "h_query", "l_query", "b_g2_query"):
+        pk[name] = be.bases_download(pk[name])
+    t0 = time.perf_counter()
+    cpu_proof, _ = gu.oracle_prove(curve, arrays, arrays["assignment"], pk, np.ascontiguousarray(r), np.ascontiguousarray(s), threads=threads)
+    sec = time.perf_counter() - t0
+    same = all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(cpu_proof, gpu_proof))
+    if not same:
+        raise SystemExit("full-size parity check failed: the CPU oracle's Groth16 proof differs from the GPU proof")
+    n_c = arrays["n_constraints"]
+    return {"value": n_c / sec, "unit": "constraints/s", "cores": threads, "kind": "port", "prove_s": sec, "parity_full_size": True,
+            "sample": f"the complete config-5 circuit ({n_c} constraints), same proving key / witness / (r, s) as the GPU proof; window-parallel MSMs over "
+                      f"{threads} threads (arkworks `parallel`), single-threaded NTTs; arkworks-algorithm restatement in C, not the arkworks binary"}
 
 
 def skewed(s):
@@ -170,14 +245,13 @@ def distributed_ntt_leg(be, dist, torch, dev, rank, world, log_m):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=24, help="log2 points per GPU (BASELINE metric: 24)")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=24, help="log2 points per GPU (BASELINE metric: 24; config 4 at 8 GPUs: 23)")
     ap.add_argument("--window", type=int, default=0, help="force the Pippenger window width (0 = auto)")
-    ap.add_argument("--precompute", type=int, default=22,
-                    help="window width of the precomputed table of 2^(c w) P_i (zl_bases_precompute; W x the base memory, built once "
-                         "at upload, untimed like the upload itself); -1 = no table (plain 16-bit windows)")
-    ap.add_argument("--cpu-log-n", type=int, default=18)
+    ap.add_argument("--fixed-key", type=int, default=22,
+                    help="window width of the precomputed-table mode reported BESIDE the headline as msm_fixed_key (zl_bases_precompute: "
+                         "2^(c w) P_i, W x the base memory, built once per key); -1 = skip that leg")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
@@ -191,6 +265,7 @@ def main():
     import torch
     import torch.distributed as dist
     from openzl_amd import Backend, ZL_BLS12_381
+    from openzl_amd.selfcheck import dot_mod_r, expected_point
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -220,56 +295,75 @@ def main():
     n = 1 << args.log_n
 
     # ---- synthetic inputs, generated per rank, resident in HBM before the timed region ---------------------------
-    k = random_scalars_lt_r(n, 1000 + rank)          # discrete logs of the bases: P_i = k_i * G (device generator)
+    # bases P_i = k_i * G with 63-bit k_i (device generator): known discrete logs make every full-size result checkable exactly
+    rng = np.random.Generator(np.random.PCG64(1000 + rank))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    t0 = time.perf_counter()
     h = be.bases_generate(ZL_BLS12_381, k)
-    pre_c = args.precompute if args.precompute >= 0 and not args.window else -1
-    if pre_c >= 0 and args.log_n < 24:
-        pre_c = 0  # let the library pick c for small inputs
-    if pre_c >= 0:
-        be.bases_precompute(h, pre_c)
-    s_host = random_scalars_lt_r(n, 2000 + rank)
+    t_generate = time.perf_counter() - t0
+    del k
+    # two different scalar vectors: consecutive steps of the pipelined batch alternate between them, so a cross-job buffer race in the
+    # three-stream pipeline cannot hide behind identical inputs
+    vecs = [random_scalars_lt_r(n, 2000 + rank), random_scalars_lt_r(n, 4000 + rank)]
     if args.scalars == "skewed":
-        s_host = skewed(s_host)
-    d_scalars = torch.from_numpy(s_host.view(np.int64)).to(dev)
+        vecs = [skewed(v) for v in vecs]
+    d_vecs = [torch.from_numpy(v.view(np.int64)).to(dev) for v in vecs]
     torch.cuda.synchronize()
+    # exact expected answers at FULL size: (sum s_i k_i mod r) * G -- one O(n) dot product per vector, one point from the device generator
+    dots = [dot_mod_r(v, k64, R_BLS) for v in vecs]
+    exp_xy = [expected_point(be, ZL_BLS12_381, d) for d in dots]   # this rank's shard
+    exp_all = exp_xy                                                # all ranks together (N > 1: sum of the shard dot products mod r)
+    if world > 1:
+        is_nccl0 = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
+        mine = torch.tensor([(d >> (32 * j)) & 0xFFFFFFFF for d in dots for j in range(8)], dtype=torch.int64, device=dev if is_nccl0 else None)
+        allv = torch.empty(world * 16, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().numpy().reshape(world, 2, 8)
+        tot = [sum(sum(int(allv[g, j, w]) << (32 * w) for w in range(8)) for g in range(world)) % R_BLS for j in (0, 1)]
+        exp_all = [expected_point(be, ZL_BLS12_381, d) for d in tot]
 
-    # ---- correctness gate before timing: known-discrete-log check on a 2^14 prefix (full sizes: tests/) -----------
-    m = min(n, 1 << 14)
-    got, inf = be.msm_dev(h, d_scalars.data_ptr(), m)
-    dot = sum(limbs_to_int(a) * limbs_to_int(b) for a, b in zip(k[:m], s_host[:m])) % R_BLS
-    kd = np.array([[(dot >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64)
-    hd = be.bases_generate(ZL_BLS12_381, kd)
-    exp = be.bases_download(hd)[0]
-    be.bases_free(hd)
-    if inf or not (got == exp).all():
-        raise SystemExit("MSM self-check failed: result != (sum s_i k_i) G")
+    def check(xy, inf, j, what):
+        if inf or not (np.asarray(xy) == exp_xy[j]).all():
+            raise SystemExit(f"MSM self-check failed ({what}): result != (sum s_i k_i) G at full size")
 
-    from openzl_amd.sharded import sharded_msm, sharded_msm_batch
+    from openzl_amd.sharded import fold_partials, sharded_msm, sharded_msm_batch
 
     gather_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
 
-    def step():
+    def step(j=0):
         # local Pippenger -> 1 partial sum; N > 1: all_gather over RCCL + fold on every rank (openzl_amd/sharded.py)
-        return sharded_msm(lambda: be.msm_partial_dev(h, d_scalars.data_ptr(), n), ZL_BLS12_381, device=gather_dev)
+        return sharded_msm(lambda: be.msm_partial_dev(h, d_vecs[j].data_ptr(), n), ZL_BLS12_381, device=gather_dev)
 
-    def steps_pipelined(k):
-        # the K steps as ONE pipelined batch (zl_msm_batch_partial_dev: sort of step i+2 | accumulation of step i+1 | tail of step i on
-        # three streams), every step a complete MSM with its own result; N > 1: one all_gather of the K partials per rank, K folds
-        parts = be.msm_batch_partial_dev(h, [d_scalars.data_ptr()] * k, n)
-        return sharded_msm_batch(parts, ZL_BLS12_381, device=gather_dev)
+    def local_batch(cnt):
+        # cnt MSMs as ONE pipelined batch (zl_msm_batch_partial_dev: sort of step i+2 | accumulation of step i+1 | tail of step i on three streams)
+        return be.msm_batch_partial_dev(h, [d_vecs[i % 2].data_ptr() for i in range(cnt)], n)
+
+    def steps_pipelined(cnt):
+        # every step a complete MSM with its own result; N > 1: one all_gather of the K partials per rank, K folds
+        return sharded_msm_batch(local_batch(cnt), ZL_BLS12_381, device=gather_dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ref_xy, ref_inf = step()  # untimed: the full-size result through the plain single-call path, every timed step must reproduce it
+    # ---- correctness gate before timing: the exact configuration that is timed, at full size, both scalar vectors ----------------------
+    for j in (0, 1):
+        xy_j, inf_j = fold_partials(ZL_BLS12_381, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
+        check(xy_j, inf_j, j, "single call")
+    if world > 1:  # the folded all-rank result must be (sum over ALL shards of s_i k_i) G
+        for j in (0, 1):
+            xy_j, inf_j = step(j)
+            if inf_j or not (np.asarray(xy_j) == exp_all[j]).all():
+                raise SystemExit("MSM self-check failed (all ranks, single call): result != (sum s_i k_i) G")
     pipelined = not args.no_pipeline and args.steps > 1
     if pipelined:
         # setup, untimed like the base upload: one 3-deep batch creates the side streams and grows all three buffer sets
-        for xy_k, inf_k in steps_pipelined(3):
-            if inf_k != ref_inf or not (np.asarray(xy_k) == np.asarray(ref_xy)).all():
-                raise SystemExit("MSM self-check failed: the pipelined path disagrees with the single-call result")
+        for i, part in enumerate(local_batch(3)):
+            xy_i, inf_i = fold_partials(ZL_BLS12_381, part.reshape(1, -1))
+            check(xy_i, inf_i, i % 2, "pipelined batch")
         if args.warmup:
             steps_pipelined(args.warmup)
     else:
@@ -285,26 +379,43 @@ def main():
         tot_ms.append(tm.total_ms)      # device time per step, pipelined
     else:
         results = []
-        for _ in range(args.steps):
-            results.append(step())
+        for i in range(args.steps):
+            results.append(step(i % 2))
             tm = be.last_timing()
             dom_ms.append(tm.dominant_ms)
             tot_ms.append(tm.total_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     tm = be.last_timing()
-    for xy_k, inf_k in results:
-        if inf_k != ref_inf or not (np.asarray(xy_k) == np.asarray(ref_xy)).all():
-            raise SystemExit("MSM self-check failed: a timed step disagrees with the single-call result")
+    for i, (xy_i, inf_i) in enumerate(results):  # every timed step is checked exactly (N > 1: against the sum over all shards)
+        if inf_i or not (np.asarray(xy_i) == exp_all[i % 2]).all():
+            raise SystemExit("MSM self-check failed (timed step): result != (sum s_i k_i) G at full size")
     # latency of one un-pipelined MSM call, for the record
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    be.msm_partial_dev(h, d_scalars.data_ptr(), n)
+    be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
     single_ms = (time.perf_counter() - t1) * 1e3
+    single_dev = be.last_timing()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    s_host = vecs[0]
+    d_scalars = d_vecs[0]
+
+    # ---- PCIe-inclusive rate (SURVEY.md §8d config 2's timed region: scalars from host memory + kernels + result; never `value`) ---------
+    pcie_info = None
+    if rank == 0 and world == 1:
+        be.msm(h, s_host)  # warm-up: staging buffer
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            xy_p, inf_p = be.msm(h, s_host)
+            ts.append(time.perf_counter() - t1)
+        check(xy_p, inf_p, 0, "host scalars")
+        pcie_info = {"ms_per_msm": float(np.min(ts)) * 1e3, "points_per_s": n / float(np.min(ts)),
+                     "note": "zl_msm: scalars copied from pageable host memory (32 B/point over PCIe) + all kernels + result D2H, bases resident"}
 
     skew_info = None
     if rank == 0 and world == 1 and not args.no_skew:
@@ -319,12 +430,55 @@ def main():
             be.msm_partial_dev(h, d2.data_ptr(), n)
             if it:
                 ts.append(time.perf_counter() - t1)
-        skew_info = {"scalars": "50% zeros, 25% ones, 25% uniform < r, shuffled", "ms_per_step": float(np.mean(ts)) * 1e3,
+        xy_s, inf_s = fold_partials(ZL_BLS12_381, be.msm_partial_dev(h, d2.data_ptr(), n).reshape(1, -1))
+        if inf_s or not (np.asarray(xy_s) == expected_point(be, ZL_BLS12_381, dot_mod_r(s2, k64, R_BLS))).all():
+            raise SystemExit("MSM self-check failed (skewed scalars): result != (sum s_i k_i) G at full size")
+        skew_info = {"scalars": "50% zeros, 25% ones, 25% uniform < r, shuffled", "ms_per_step": float(np.mean(ts)) * 1e3, "checked_exactly": True,
                      "points_per_s": n / float(np.mean(ts)),
                      "note": "zero digits are dropped by the recoder; scalars equal to 1 bypass the sort (compact list + direct sum, as "
-                             "arkworks special-cases them); other repeated values form giant buckets cut into fixed 64-entry chunks and merged "
+                             "arkworks special-cases them); other repeated values form giant buckets cut into fixed-length chunks and merged "
                              "in two stages; exactness of these paths: tests/test_gpu_msm.py (skewed cases), tests/test_gpu_msm_fuzz.py"}
         del d2
+
+    # ---- fixed-key mode, reported beside the headline: table of 2^(c w) P_i built once per key (a Groth16 proving key is static) -------
+    fixed_info = None
+    if args.fixed_key >= 0 and rank == 0 and world == 1 and not args.window:
+        c_fk = args.fixed_key if args.log_n >= 24 else 0  # let the library pick c for small inputs
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        be.bases_precompute(h, c_fk)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t1) * 1e3
+        for j in (0, 1):
+            xy_j, inf_j = fold_partials(ZL_BLS12_381, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
+            check(xy_j, inf_j, j, "fixed-key single call")
+        tmf1 = be.last_timing()
+        local_batch(3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        parts = local_batch(args.steps)
+        torch.cuda.synchronize()
+        fk_ms = (time.perf_counter() - t1) * 1e3 / args.steps
+        tmf = be.last_timing()
+        for i, part in enumerate(parts):
+            xy_i, inf_i = fold_partials(ZL_BLS12_381, part.reshape(1, -1))
+            check(xy_i, inf_i, i % 2, "fixed-key pipelined step")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
+        fk_single = (time.perf_counter() - t1) * 1e3
+        plain_ms = elapsed / args.steps * 1e3
+        cw = int(tmf.window_bits)
+        W = (256 + cw - 1) // cw
+        fixed_info = {
+            "points_per_s": n / (fk_ms * 1e-3), "ms_per_msm": fk_ms, "single_call_latency_ms": fk_single, "window_bits": cw, "windows": W,
+            "kernel_ms": float(tmf.dominant_ms),
+            "table_build_ms": build_ms, "table_bytes": float(W) * n * 128.0,
+            "break_even_msms": (build_ms / (plain_ms - fk_ms)) if plain_ms > fk_ms else None,
+            "note": "zl_bases_precompute: 2^(c w) P_i for every window beside the bases, so all windows share ONE bucket set and c grows to 22 "
+                    "(12 instead of 14 additions per point); the build is per key and pays back only after break_even_msms MSMs on the same "
+                    "bases (a Groth16 proving key).  Same exact full-size checks as the headline.  NOT `value`: multi_scalar_mul(bases, scalars) has no per-key state.",
+        }
 
     ntt_info = None
     if not args.no_ntt:
@@ -348,6 +502,23 @@ def main():
         back = dx.cpu().numpy().view(np.uint64)
         if not (back == x).all():
             raise SystemExit("NTT self-check failed: iNTT(NTT(x)) != x")
+        ntt_cpu = None
+        if not args.no_cpu and rank == 0 and world == 1:
+            # CPU oracle on the same vector; its forward transform must equal the GPU's bit for bit (full size)
+            ntt_cpu, X_cpu = cpu_baseline_ntt(x, args.cpu_threads)
+            be.ntt_dev(ZL_BLS12_381, dx.data_ptr(), ln, inverse=False, mont=True)
+            X_gpu = dx.cpu().numpy().view(np.uint64)
+            if not (X_gpu == X_cpu).all():
+                raise SystemExit("full-size parity check failed: the CPU oracle's NTT differs from the GPU result")
+            ntt_cpu["parity_full_size"] = True
+            del X_cpu, X_gpu
+        ntt_traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_ntt.json")))
+            if ln == int(pmc["log_n"]):
+                ntt_traffic = pmc["traffic_bytes_per_transform"]
+        except Exception:
+            ntt_traffic = None
         f_ms, i_ms = float(np.mean(fwd)), float(np.mean(inv))
         if world > 1:
             cpu_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
@@ -362,8 +533,10 @@ def main():
             "forward_elems_per_s": tot / (f_ms * 1e-3), "inverse_elems_per_s": tot / (i_ms * 1e-3),
             "fwd_plus_inv_elems_per_s": tot / ((f_ms + i_ms) * 1e-3),
             "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform; kernel = k_ntt_pass x3 launches"},
+                         "frac": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
+                         "traffic_unit": "bytes per transform, all passes (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic_ntt.json; null for other sizes)",
+                         "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform, all butterfly passes of one transform together"},
+            "cpu_baseline": ntt_cpu,
         }
         del dx
 
@@ -380,7 +553,7 @@ def main():
         t0 = time.perf_counter()
         keys = Groth16Keys(be, circ, seed=0x5EED0006)
         t_setup = time.perf_counter() - t0
-        p0, _, _ = keys.prove(seed=7)  # warm-up (twiddle tables, scratch growth)
+        p0, r_g16, s_g16 = keys.prove(seed=7)  # warm-up (twiddle tables, scratch growth)
         times, devms = [], []
         for _ in range(3):
             torch.cuda.synchronize()
@@ -409,6 +582,8 @@ def main():
             "note": "prove = Groth16<E>::prove: assignment H2D, spmv, 7 NTTs, 4 G1 MSMs + 1 G2 MSM on the device, host assembly; "
                     "the proof is verified here with Groth16::verify (host pairing); bit-exact parity vs the oracle in tests/test_groth16.py, tests/test_host_mirror.py",
         }
+        if not args.no_cpu:
+            g16_info["cpu_baseline"] = cpu_baseline_groth16(be, keys, circ, p1, r_g16, s_g16, args.cpu_threads)
         keys.close()
         circ.close()
         # SURVEY.md §8d config 5 also names the small circuits: k = 1 (N = 2^8) and k = 2^6 (N = 2^14); latency-bound, reported beside
@@ -436,22 +611,23 @@ def main():
 
     cpu = None
     if not args.no_cpu and rank == 0 and world == 1:
-        cpu, _ = cpu_baseline(args.cpu_log_n, args.cpu_threads)
+        cpu = cpu_baseline(be, h, k64, s_host, exp_xy[0], args.cpu_threads, args.log_n)
 
     if rank == 0:
         pts = float(n) * world * args.steps
         value = pts / elapsed
         dom = float(np.mean(dom_ms))
         achieved = 128.0 * n / (dom * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic_final.json: rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration
+        # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration, null otherwise
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")))
-            if args.log_n == 24 and int(tm.window_bits) == int(pmc["window_bits"]) and pre_c >= 0:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if args.log_n == int(pmc["log_n"]) and int(tm.window_bits) == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
                 traffic = pmc["k_msm_accumulate_traffic_bytes"]
         except Exception:
             traffic = None
+        cw = int(tm.window_bits)
         line = {
             "metric": "MSM points/sec (BLS12-381 G1)",
             "value": value,
@@ -466,17 +642,19 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"bls12_381_g1_msm_2^{args.log_n}_per_gpu", "points_per_gpu": n, "curve": "BLS12-381 G1",
-                       "scalars": "uniform < r (255 bit)" if args.scalars == "uniform" else "50% zeros, 25% ones, 25% uniform", "bases": "k_i*G from a device generator, resident in HBM",
-                       "window_bits": int(tm.window_bits),
-                       "precomputed_table": (f"2^(c w) P_i for all windows, c={int(tm.window_bits)} (one merged bucket set; built at upload)"
-                                             if pre_c >= 0 else "none"),
+                       "scalars": "uniform < r (255 bit)" if args.scalars == "uniform" else "50% zeros, 25% ones, 25% uniform",
+                       "bases": "k_i*G from a device generator, resident in HBM; NO per-key precomputation (what multi_scalar_mul(bases, scalars) is)",
+                       "window_bits": cw, "windows": (256 + cw - 1) // cw,
+                       "precomputed_table": "none (the fixed-key table mode is reported separately as msm_fixed_key)",
                        "parallelism": f"shard{world}" if world > 1 else "single",
-                       "steps_issued_as": "one pipelined batch (zl_msm_batch_partial_dev): sort | accumulate | tail of consecutive steps overlap on three streams"
-                                          if pipelined else "separate calls",
-                       "single_call_latency_ms": single_ms,
-                       "result_check": "known-discrete-log prefix check passed; bit-exact parity in tests/"},
+                       "steps_issued_as": "one pipelined batch (zl_msm_batch_partial_dev): sort | accumulate | tail of consecutive steps overlap on three streams; "
+                                          "consecutive steps alternate between two scalar vectors" if pipelined else "separate calls",
+                       "single_call_latency_ms": single_ms, "single_call_device_ms": float(single_dev.total_ms),
+                       "bases_generate_s": t_generate,
+                       "result_check": "every timed step equals (sum s_i k_i) G exactly at full size (known discrete logs); the CPU oracle's MSM of the "
+                                       "complete input equals it too (cpu_baseline.parity_full_size)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic_final.json)",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json; null for any other configuration)",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
                          "int_alu": {"unit": "G Fq-mul/s", "achieved": float(tm.entries) * 9.5 / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
                                      "frac": float(tm.entries) * 9.5 / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
@@ -487,6 +665,8 @@ def main():
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie_info,
+            "msm_fixed_key": fixed_info,
             "msm_skewed_scalars": skew_info,
             "ntt": ntt_info,
             "groth16": g16_info,

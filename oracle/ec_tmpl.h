@@ -195,8 +195,14 @@ static void E(msm_window)(E(jac) *res, const E(aff) *bases, const uint64_t *scal
 /* ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul.  threads <= 1: the reference's configuration (no
  * `parallel` feature, plugins/arkworks/Cargo.toml:25-110).  threads > 1: window-parallel, which is what
  * the arkworks `parallel` feature does (rayon over windows). */
+static void E(msm_ark_c)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads, int c_override);
 static void E(msm_ark)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads) {
-    int c = E(ark_c)(n);
+    E(msm_ark_c)(out, bases, scalars, n, threads, 0);
+}
+/* c_override > 0: the window width ark's rule would pick for a LARGER input (timing a bounded sample of a big workload with the big
+ * workload's window structure); results do not depend on c. */
+static void E(msm_ark_c)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads, int c_override) {
+    int c = c_override > 0 ? c_override : E(ark_c)(n);
     int nwin = (SC_BITS + c - 1) / c;
     E(jac) *ws = (E(jac) *)malloc(sizeof(E(jac)) * (size_t)nwin);
     size_t nb = ((size_t)1 << c) - 1;
@@ -223,6 +229,56 @@ static void E(msm_ark)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars
         for (int k = 0; k < c; k++) E(jac_double)(&total);
     }
     E(jac_add)(&total, &ws[0]);
+    *out = total;
+    free(ws);
+}
+/* All-core MSM as a (chunk x window) grid (NOT what arkworks 0.3.0 does -- its `parallel` feature stops at one thread per window): the
+ * input is cut into contiguous chunks so that chunks x windows ~ threads, every (chunk, window) pair is one task running ark's window
+ * routine (window width by ark's rule for the chunk length; bucket arrays of a chunk-sized problem stay cache-sized), then a Horner per
+ * chunk and the chunk results are added.  The strongest CPU arrangement of the same algorithm that this restatement offers. */
+static void E(msm_chunked)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads) {
+    int nt = threads < 1 ? 1 : threads;
+    size_t chunks = 1;
+    int c = E(ark_c)(n), nwin = (SC_BITS + c - 1) / c;
+    for (chunks = 1; chunks < (size_t)nt && chunks < n; chunks++) {
+        c = E(ark_c)((n + chunks - 1) / chunks);
+        nwin = (SC_BITS + c - 1) / c;
+        if (chunks * (size_t)nwin >= (size_t)nt) break;
+    }
+    if (chunks < 1) chunks = 1;
+    size_t per = (n + chunks - 1) / chunks;
+    c = E(ark_c)(per ? per : 1);
+    nwin = (SC_BITS + c - 1) / c;
+    size_t tasks = chunks * (size_t)nwin, nb = ((size_t)1 << c) - 1;
+    E(jac) *ws = (E(jac) *)malloc(sizeof(E(jac)) * tasks);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+        E(jac) *buckets = (E(jac) *)malloc(sizeof(E(jac)) * nb);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (size_t t = 0; t < tasks; t++) {
+            size_t ch = t / (size_t)nwin, w = t % (size_t)nwin;
+            size_t lo = ch * per, hi = lo + per > n ? n : lo + per;
+            if (lo >= hi) { E(jac_set_zero)(&ws[t]); continue; }
+            E(msm_window)(&ws[t], bases + lo, scalars + 4 * lo, hi - lo, (int)w * c, c, buckets);
+        }
+        free(buckets);
+    }
+    E(jac) total;
+    E(jac_set_zero)(&total);
+    for (size_t ch = 0; ch < chunks; ch++) {
+        E(jac) acc;
+        E(jac_set_zero)(&acc);
+        for (int w = nwin - 1; w >= 1; w--) {
+            E(jac_add)(&acc, &ws[ch * (size_t)nwin + (size_t)w]);
+            for (int k = 0; k < c; k++) E(jac_double)(&acc);
+        }
+        E(jac_add)(&acc, &ws[ch * (size_t)nwin]);
+        E(jac_add)(&total, &acc);
+    }
     *out = total;
     free(ws);
 }

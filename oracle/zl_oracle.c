@@ -190,6 +190,23 @@ int zlo_field_from_mont(int fid, const uint64_t *in, uint64_t *out, size_t n) {
         free(b);                                                                                                  \
         return 0;                                                                                                 \
     }                                                                                                             \
+    /* timed variant for bench.py's cpu_baseline: parallel (untimed) load of the bases, *seconds = the MSM alone. */ \
+    static int EC##_msm_ex_api(const uint64_t *bases, int mont, const uint64_t *scalars, size_t n, int algo, int c_override, \
+                               int threads, uint64_t *out_xy, uint8_t *out_inf, double *seconds) {                 \
+        EC##_aff *b = (EC##_aff *)malloc(sizeof(EC##_aff) * (n ? n : 1));                                        \
+        if (!b) return -2;                                                                                        \
+        _Pragma("omp parallel for schedule(static)") for (size_t i = 0; i < n; i++)                               \
+            EC##_load_aff(&b[i], bases + (size_t)2 * NLQ * i, mont);                                              \
+        EC##_jac r;                                                                                               \
+        const double t0 = omp_get_wtime();                                                                        \
+        if (algo == 0) EC##_msm_ark_c(&r, b, scalars, n, threads, c_override);                                    \
+        else if (algo == 2) EC##_msm_chunked(&r, b, scalars, n, threads);                                         \
+        else EC##_msm_naive(&r, b, scalars, n);                                                                   \
+        if (seconds) *seconds = omp_get_wtime() - t0;                                                             \
+        EC##_store_aff(out_xy, out_inf, &r);                                                                      \
+        free(b);                                                                                                  \
+        return 0;                                                                                                 \
+    }                                                                                                             \
     static int EC##_mul_gen_api(const uint64_t *gen, const uint64_t *k, size_t n, uint64_t *out_xy) {             \
         EC##_aff g;                                                                                               \
         EC##_load_aff(&g, gen, 0);                                                                                \
@@ -229,6 +246,12 @@ int zlo_msm_g1(int curve, const uint64_t *bases, int bases_mont, const uint64_t 
                int threads, uint64_t *out_xy, uint8_t *out_inf) {
     if (curve == ZLO_BLS12_381) return blsg1_msm_api(bases, bases_mont, scalars, n, algo, threads, out_xy, out_inf);
     if (curve == ZLO_BN254) return bng1_msm_api(bases, bases_mont, scalars, n, algo, threads, out_xy, out_inf);
+    return -1;
+}
+int zlo_msm_g1_ex(int curve, const uint64_t *bases, int bases_mont, const uint64_t *scalars, size_t n, int algo, int c_override,
+                  int threads, uint64_t *out_xy, uint8_t *out_inf, double *seconds) {
+    if (curve == ZLO_BLS12_381) return blsg1_msm_ex_api(bases, bases_mont, scalars, n, algo, c_override, threads, out_xy, out_inf, seconds);
+    if (curve == ZLO_BN254) return bng1_msm_ex_api(bases, bases_mont, scalars, n, algo, c_override, threads, out_xy, out_inf, seconds);
     return -1;
 }
 int zlo_g1_mul_gen(int curve, const uint64_t *k, size_t n, uint64_t *out_xy) {
@@ -337,6 +360,25 @@ int zlo_ntt(int curve, uint64_t *data, unsigned log_n, int inverse, int coset, i
         return 0;
     }
     return -1;
+}
+
+/* timed variant for bench.py's cpu_baseline (Montgomery limbs in / out): threads <= 1 = the in-order single-threaded transform
+ * (the reference's configuration), threads > 1 = the multi-threaded arrangement of the same transform; *seconds = the transform alone */
+int zlo_ntt_ex(int curve, uint64_t *data, unsigned log_n, int inverse, int coset, int threads, double *seconds) {
+    const double t0 = omp_get_wtime();
+    if (curve == ZLO_BLS12_381) {
+        if (log_n > blsntt_TWO_ADICITY) return -1;
+        if (threads > 1) blsntt_transform_mt((blsr_t *)data, log_n, inverse, coset, threads);
+        else blsntt_transform((blsr_t *)data, log_n, inverse, coset);
+    } else if (curve == ZLO_BN254) {
+        if (log_n > bnntt_TWO_ADICITY) return -1;
+        if (threads > 1) bnntt_transform_mt((bnr_t *)data, log_n, inverse, coset, threads);
+        else bnntt_transform((bnr_t *)data, log_n, inverse, coset);
+    } else {
+        return -1;
+    }
+    if (seconds) *seconds = omp_get_wtime() - t0;
+    return 0;
 }
 
 /* ---------------------------------------------------------------- Poseidon (pins Fr mul/add vs reference KAT) */

@@ -41,6 +41,12 @@ int zlo_field_from_mont(int fid, const uint64_t *in, uint64_t *out, size_t n);
  * out_xy: canonical affine x||y; *out_inf = 1 when the sum is infinity (out_xy zeroed). */
 int zlo_msm_g1(int curve, const uint64_t *bases, int bases_mont, const uint64_t *scalars, size_t n, int algo,
                int threads, uint64_t *out_xy, uint8_t *out_inf);
+/* Same with timing for bench.py's cpu_baseline: the bases are loaded in parallel (untimed), *seconds = the MSM alone.
+ * algo 0: ark Pippenger, window-parallel over `threads` (c_override > 0 forces the window width, e.g. the width ark's rule gives the
+ * full-size workload when a bounded sample is timed); algo 2: point-chunked over `threads` (every thread runs the single-threaded
+ * ark algorithm on its chunk; not an arkworks configuration -- the strongest CPU arrangement of the same algorithm). */
+int zlo_msm_g1_ex(int curve, const uint64_t *bases, int bases_mont, const uint64_t *scalars, size_t n, int algo, int c_override,
+                  int threads, uint64_t *out_xy, uint8_t *out_inf, double *seconds);
 /* G2 MSM: bases n x (x.c0||x.c1||y.c0||y.c1). */
 int zlo_msm_g2(int curve, const uint64_t *bases, int bases_mont, const uint64_t *scalars, size_t n, int algo,
                int threads, uint64_t *out_xy, uint8_t *out_inf);
@@ -53,6 +59,9 @@ int zlo_g1_mul(int curve, const uint64_t *p_xy, const uint64_t *k, uint64_t *out
 /* NTT over the scalar field of `curve`, in place, natural order in/out; data n=2^log_n x 4 u64;
  * mont: 1 = Montgomery limbs in/out, 0 = canonical in/out. */
 int zlo_ntt(int curve, uint64_t *data, unsigned log_n, int inverse, int coset, int mont);
+
+/* timed variant (Montgomery limbs): threads <= 1 single-threaded in-order transform, > 1 the same transform split over threads */
+int zlo_ntt_ex(int curve, uint64_t *data, unsigned log_n, int inverse, int coset, int threads, double *seconds);
 
 /* Poseidon permutation width 3 (tutorial schedule) over BLS12-381 Fr from caller-supplied constants:
  * keys (3*(rf+rp) canonical), mds (9 canonical, row-major), state 3 canonical in/out. */

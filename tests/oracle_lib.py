@@ -41,10 +41,12 @@ def lib():
         L.zlo_field_from_mont.argtypes = [C.c_int, u64p, u64p, C.c_size_t]
         for f in (L.zlo_msm_g1, L.zlo_msm_g2):
             f.argtypes = [C.c_int, u64p, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int, u64p, u8p]
+        L.zlo_msm_g1_ex.argtypes = [C.c_int, u64p, C.c_int, u64p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p, u8p, C.POINTER(C.c_double)]
         for f in (L.zlo_g1_mul_gen, L.zlo_g2_mul_gen):
             f.argtypes = [C.c_int, u64p, C.c_size_t, u64p]
         L.zlo_g1_mul.argtypes = [C.c_int, u64p, u64p, u64p, u8p]
         L.zlo_ntt.argtypes = [C.c_int, u64p, C.c_uint, C.c_int, C.c_int, C.c_int]
+        L.zlo_ntt_ex.argtypes = [C.c_int, u64p, C.c_uint, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.zlo_poseidon3.argtypes = [u64p, u64p, C.c_int, C.c_int, u64p]
     return _LIB
 
@@ -122,6 +124,26 @@ def oracle_msm_g1(curve, bases: np.ndarray, scalars: np.ndarray, algo=0, threads
     rc = lib().zlo_msm_g1(curve.cid, p64(bases), int(mont), p64(scalars), n, algo, threads, p64(out), C.byref(inf))
     assert rc == 0
     return out, inf.value
+
+
+def oracle_msm_g1_timed(curve, bases: np.ndarray, scalars: np.ndarray, algo=0, threads=1, c_override=0, mont=False):
+    """-> (xy, inf, seconds of the MSM alone); algo 0 = ark window-parallel, 2 = point-chunked all-core"""
+    n = scalars.shape[0]
+    out = np.zeros(2 * nlq(curve), dtype=np.uint64)
+    inf = C.c_uint8(0)
+    sec = C.c_double(0.0)
+    rc = lib().zlo_msm_g1_ex(curve.cid, p64(bases), int(mont), p64(scalars), n, algo, c_override, threads, p64(out), C.byref(inf), C.byref(sec))
+    assert rc == 0
+    return out, inf.value, sec.value
+
+
+def oracle_ntt_timed(curve, data_mont: np.ndarray, inverse=False, coset=False, threads=1):
+    """Montgomery limbs in / out -> (result, seconds of the transform alone)"""
+    d = np.ascontiguousarray(data_mont.copy())
+    log_n = int(d.shape[0]).bit_length() - 1
+    sec = C.c_double(0.0)
+    assert lib().zlo_ntt_ex(curve.cid, p64(d), log_n, int(inverse), int(coset), threads, C.byref(sec)) == 0
+    return d, sec.value
 
 
 def oracle_g1_mul_gen(curve, k: np.ndarray) -> np.ndarray:

@@ -129,3 +129,27 @@ def test_c_msm_known_discrete_log_2_12():
     xy, inf = ol.oracle_msm_g1(curve, B, S, 0, 8)
     dot = sum(a * b for a, b in zip(ol.limbs_to_ints(S), ol.limbs_to_ints(K))) % curve.fr.p
     assert ol.limbs_to_point(curve, xy, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
+
+
+def test_oracle_timed_variants_agree():
+    """bench.py's cpu_baseline legs: forced window width, point-chunked all-core MSM and the multi-threaded NTT arrangement must give the
+    same answers as the plain restatements."""
+    c = po.BLS12_381
+    n = 3000
+    k = ol.random_scalars(c, n, 31)
+    S = ol.random_scalars(c, n, 32)
+    S[0] = 0
+    S[1] = ol.ints_to_limbs([1], 4)[0]
+    B = ol.oracle_g1_mul_gen(c, k)
+    ref, rinf = ol.oracle_msm_g1(c, B, S, algo=0, threads=1)
+    for algo, th, co in ((0, 1, 0), (0, 4, 0), (0, 4, 18), (2, 4, 0), (2, 7, 0), (2, 5000, 0)):
+        xy, inf, sec = ol.oracle_msm_g1_timed(c, B, S, algo=algo, threads=th, c_override=co)
+        assert inf == rinf and (xy == ref).all() and sec > 0
+    for curve in (po.BLS12_381, po.BN254):
+        x = ol.random_scalars(curve, 1 << 10, 33)
+        for inv in (False, True):
+            for cos in (False, True):
+                want = ol.oracle_ntt(curve, x, inverse=inv, coset=cos, mont=True)
+                for th in (1, 3):
+                    got, _ = ol.oracle_ntt_timed(curve, x, inverse=inv, coset=cos, threads=th)
+                    assert (got == want).all()
