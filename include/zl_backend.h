@@ -15,7 +15,8 @@
  *   - return 0 (ZL_OK) on success, a negative ZL_E* code otherwise; nothing throws or aborts across the ABI;
  *   - the caller owns every host buffer; device-resident base tables are owned by the ctx and named by handle
  *     (a proving key is static per circuit: upload once, prove many times);
- *   - a ctx is bound to one GPU and one HIP stream and is used from one thread at a time; ctxs are independent;
+ *   - a ctx is bound to one GPU and one HIP stream and is used from one thread at a time; ctxs are independent; a zl_mctx bundles one
+ *     ctx per device for the sharded entry points;
  *   - field elements are little-endian arrays of u64 limbs, 4 per Fr / BN254 Fq element, 6 per BLS12-381 Fq
  *     element.  ZL_MONT = limbs are arkworks' in-memory Montgomery form (value*2^(64*limbs) mod p), i.e. what
  *     `Fp256/Fp384.0.0` holds; ZL_CANON(0) = canonical integers (what `into_repr()` yields);
@@ -121,6 +122,30 @@ int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsi
  * Montgomery between the legs (ZL_MONT_IN / ZL_MONT_OUT pick the outer representation).  1 <= log_g <= 4, 2*log_g <= log_n.
  * openzl_amd/sharded.py drives the three steps over torch.distributed (RCCL all_to_all_single). */
 int zl_ntt_cross_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags);
+
+/* ---- multi-GPU in one process: G devices, one zl_ctx each, RCCL (ncclCommInitAll) between them ------------------
+ * Upload / generate / precompute every rank's shard of the bases on ITS ctx (zl_mctx_ctx(m, rank)) with the single-device calls above.
+ * device_ids may repeat (several "virtual ranks" on one GPU, for testing on a 1-GPU box): RCCL refuses duplicate devices, so the
+ * exchanges then run as device-to-device copies with the same data movement pattern; zl_mctx_uses_rccl tells which.  1 <= n_devices <= 16.
+ * Callers that run one process per GPU instead use zl_msm_partial_dev + their own all-gather + zl_partials_sum (openzl_amd/sharded.py). */
+typedef struct zl_mctx zl_mctx;
+int zl_ctx_create_multi(zl_mctx** out, const int* device_ids, int n_devices);
+void zl_mctx_destroy(zl_mctx* m);
+int zl_mctx_size(const zl_mctx* m);
+zl_ctx* zl_mctx_ctx(zl_mctx* m, int rank);
+int zl_mctx_uses_rccl(const zl_mctx* m);
+int zl_mctx_last_rccl_error(const zl_mctx* m);
+/* Sharded MSM (config 4: 2^26 as 8 x 2^23): rank g holds bases handle bases[g] on its ctx and n[g] canonical scalars in ITS device memory
+ * (d_scalars[g]); first may be NULL.  Every device runs the complete local Pippenger concurrently, the G un-normalised partial sums
+ * (ZL_PARTIAL_WORDS u64 each) are all-gathered (ncclAllGather as ncclUint64; EC addition is no RCCL reduction op, so gather-then-add
+ * IS the reduce) and folded: out_xy = canonical affine sum over all shards. */
+int zl_msm_sharded(zl_mctx* m, const uint64_t* bases, const size_t* first, const void* const* d_scalars, const size_t* n, uint64_t* out_xy,
+                   uint8_t* out_inf);
+/* ONE 2^log_n transform over G = 2^log_g ranks (layouts and legs: zl_ntt_cross_dev below): d_data[g] = rank g's M = 2^(log_n - log_g)
+ * elements in its device memory, in place.  forward: block-column coefficients in, cyclic evaluations out; ZL_INVERSE: the reverse.
+ * One all-to-all (grouped ncclSend / ncclRecv of G chunks of M/G elements per rank) between the two local legs.  flags: ZL_MONT,
+ * ZL_COSET, ZL_INVERSE. */
+int zl_ntt_sharded(zl_mctx* m, zl_curve_t curve, void* const* d_data, unsigned log_n, unsigned flags);
 
 /* ---- Groth16 prover (replaces ark_groth16::create_random_proof behind Groth16::<E>::prove, groth16.rs:445-457) - */
 /* R1CS in CSR form, as ark-relations' ConstraintMatrices hold it: variable order = instance block (index 0 is the

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
+    "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
     "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
 ]
 
@@ -120,6 +121,17 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_proof_bytes.restype = C.c_size_t
     L.zl_groth16_proof_to_bytes.argtypes = [C.c_int, C.POINTER(G16ProofC), u8p]
     L.zl_groth16_proof_from_bytes.argtypes = [C.c_int, u8p, C.c_size_t, C.POINTER(G16ProofC)]
+    # multi-GPU in one process
+    L.zl_ctx_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    L.zl_mctx_destroy.argtypes = [vp]
+    L.zl_mctx_destroy.restype = None
+    L.zl_mctx_size.argtypes = [vp]
+    L.zl_mctx_ctx.argtypes = [vp, C.c_int]
+    L.zl_mctx_ctx.restype = vp
+    L.zl_mctx_uses_rccl.argtypes = [vp]
+    L.zl_mctx_last_rccl_error.argtypes = [vp]
+    L.zl_msm_sharded.argtypes = [vp, u64p, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t), u64p, u8p]
+    L.zl_ntt_sharded.argtypes = [vp, C.c_int, C.POINTER(vp), C.c_uint, C.c_uint]
     # test-only hooks (include/zl_backend_test.h)
     u32p = C.POINTER(C.c_uint32)
     L.zl_test_poseidon_permute_dev.argtypes = [vp, C.c_int, u64p]
@@ -139,11 +151,15 @@ class Backend:
     """One zl_ctx (one GPU, one stream).  Mirrors the two upstream entry points the arkworks plugin surfaces:
     VariableBaseMSM::multi_scalar_mul -> msm(); Radix2EvaluationDomain::{fft,ifft,coset_*} -> ntt()."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed_ctx=None):
         self.L = load_library()
+        self._bases = {}
+        self._owned = _borrowed_ctx is None
+        if _borrowed_ctx is not None:  # a rank of a MultiBackend: the zl_mctx owns the ctx
+            self._ctx = C.c_void_p(_borrowed_ctx)
+            return
         self._ctx = C.c_void_p()
         self._check(self.L.zl_ctx_create(C.byref(self._ctx), device), "zl_ctx_create")
-        self._bases = {}
 
     def _check(self, rc: int, what: str):
         if rc != 0:
@@ -151,7 +167,8 @@ class Backend:
 
     def close(self):
         if self._ctx:
-            self.L.zl_ctx_destroy(self._ctx)
+            if self._owned:
+                self.L.zl_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -315,6 +332,57 @@ class Backend:
         out = np.zeros((n, 4), dtype=np.uint64)
         self._check(self.L.zl_groth16_last_h(self._ctx, _p64(out), n), "zl_groth16_last_h")
         return out
+
+
+class MultiBackend:
+    """zl_mctx: G devices driven from one process (include/zl_backend.h, multi-GPU section).  ranks[g] is a Backend bound to rank g's
+    ctx (upload / generate that rank's shard of the bases there); device ids may repeat (virtual ranks on one GPU, test mode)."""
+
+    def __init__(self, device_ids):
+        self.L = load_library()
+        self._m = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self.L.zl_ctx_create_multi(C.byref(self._m), ids, len(device_ids))
+        if rc:
+            raise BackendError(rc, "zl_ctx_create_multi", self.L.zl_strerror(rc).decode())
+        self.size = self.L.zl_mctx_size(self._m)
+        self.ranks = [Backend(_borrowed_ctx=self.L.zl_mctx_ctx(self._m, g)) for g in range(self.size)]
+        self.uses_rccl = bool(self.L.zl_mctx_uses_rccl(self._m))
+
+    def msm_sharded(self, handles, d_scalars, counts, firsts=None) -> Tuple[np.ndarray, int]:
+        """handles[g]: bases handle on rank g; d_scalars[g]: device pointer (on rank g's device) to counts[g] x 4 u64 canonical scalars"""
+        G = self.size
+        curve, group, _ = self.ranks[0]._bases[handles[0]]
+        hs = np.array(handles, dtype=np.uint64)
+        ptrs = (C.c_void_p * G)(*[int(p) for p in d_scalars])
+        ns = (C.c_size_t * G)(*[int(c) for c in counts])
+        fs = (C.c_size_t * G)(*[int(f) for f in (firsts or [0] * G)])
+        out, inf = np.zeros(2 * group * FQ_LIMBS[curve], dtype=np.uint64), C.c_uint8(0)
+        rc = self.L.zl_msm_sharded(self._m, _p64(hs), fs, ptrs, ns, _p64(out), C.byref(inf))
+        if rc:
+            raise BackendError(rc, "zl_msm_sharded", self.L.zl_strerror(rc).decode())
+        return out, inf.value
+
+    def ntt_sharded(self, curve: int, d_data, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = False):
+        G = self.size
+        ptrs = (C.c_void_p * G)(*[int(p) for p in d_data])
+        flags = (ZL_INVERSE if inverse else 0) | (ZL_COSET if coset else 0) | (ZL_MONT if mont else 0)
+        rc = self.L.zl_ntt_sharded(self._m, curve, ptrs, log_n, flags)
+        if rc:
+            raise BackendError(rc, "zl_ntt_sharded", self.L.zl_strerror(rc).decode())
+
+    def close(self):
+        if self._m:
+            for r in self.ranks:
+                r.close()
+            self.L.zl_mctx_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------

@@ -35,7 +35,7 @@ def _digest(paths, extra="") -> str:
 
 
 def _units():
-    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", [])]
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", []), ("zl_multi", "zl_multi.hip", [])]
     for g in GROUPS:
         # Fq2 accumulators: 1 wave/SIMD register budget avoids scratch spills
         extra = ["-DZL_ACC_WAVES=1"] if g.endswith("G2") else []
@@ -75,7 +75,7 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(compile_one, todo))
     if todo or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]  # RCCL is dlopen'ed on first multi-GPU use
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -4,7 +4,7 @@
 // trusting the bound comments beside the formulas, the formulas themselves (they are templates over the coordinate field) are instantiated
 // here with an ABSTRACT field `zl::BF` that carries only "value <= b*q" and evaluated inside static_asserts: a contract violation calls a
 // non-constexpr function, which makes the static_assert's condition a non-constant expression -> the translation unit does not compile.
-// Covered: dbl_affine, dbl_inplace, add_mixed (both signs, and its doubling branch), add_full (and its doubling branch), neg_inplace,
+// Covered: dbl_affine, dbl_inplace, jac_dbl_inplace, add_mixed (both signs, and its doubling branch), add_full (and its doubling branch), neg_inplace,
 // to_affine -- over the base field (G1) and over Fq2 in both flavours (inlined four-product scans / called dual scans) (G2) -- with
 // every coordinate at the contract's maximum (8q), plus the closure property: results are <= 8q again, so any sequence of group
 // operations stays inside the contracts.  tests/test_field28_bounds.py drives the real arithmetic at the same bounds (host + device).
@@ -104,6 +104,11 @@ constexpr bool formulas_hold() {
         XYZZ<F> d = worst<F>();
         dbl_inplace(d);
         ok = ok && closed(d);
+    }
+    {   // Jacobian doubling chain (table construction)
+        Jac<F> j{Mk<F>::at(COORD_MAX), Mk<F>::at(COORD_MAX), Mk<F>::at(COORD_MAX)};
+        jac_dbl_inplace(j);
+        ok = ok && hi(j.x) <= COORD_MAX && hi(j.y) <= COORD_MAX && hi(j.z) <= COORD_MAX;
     }
     {   // negation, normalisation
         XYZZ<F> p = worst<F>();

@@ -58,6 +58,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     }
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
+    for (auto& t : ctx->fb_table) if (t) (void)hipFree(t);
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
     if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -18,6 +18,7 @@
 
 // ---- group configurations ---------------------------------------------------------------------------------
 struct BlsG1 {
+    static constexpr int ID = 0;
     using FqP = BLS12_381_Fq;
     using FrP = BLS12_381_Fr;
     using F = Fp28<BLS12_381_Fq28, BLS12_381_Fq>;  // 14 x 28-bit lazily reduced limbs (zl_field28.h): +30 % multiplier throughput
@@ -30,6 +31,7 @@ struct BlsG1 {
     ZL_HD static F coeff_b() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::b(i); return FieldIO<F>::load_mont32(w); }
 };
 struct BnG1 {
+    static constexpr int ID = 1;
     using FqP = BN254_Fq;
     using FrP = BN254_Fr;
     using F = Fp<FqP>;
@@ -41,8 +43,9 @@ struct BnG1 {
     ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
     ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
 };
-template <class C2, class FqP_, class FrP_, class F_, int SCB, int FQ64_>
+template <class C2, class FqP_, class FrP_, class F_, int SCB, int FQ64_, int ID_>
 struct G2Cfg {
+    static constexpr int ID = ID_;
     using FqP = FqP_;
     using FrP = FrP_;
     using F = F_;
@@ -59,8 +62,8 @@ struct G2Cfg {
     ZL_HD static F coeff_b() { return mk(C2::b0, C2::b1); }
 };
 // BLS12-381 G2 on the lazily reduced 28-bit field (Fq2 products as dual scans, zl_field28.h); BN254 G2 on 32-bit limbs
-using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2L<Fp28<BLS12_381_Fq28, BLS12_381_Fq>>, 255, 6>;
-using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2<BN254_Fq>, 254, 4>;
+using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2L<Fp28<BLS12_381_Fq28, BLS12_381_Fq>>, 255, 6, 2>;
+using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2<BN254_Fq>, 254, 4, 3>;
 
 // ---- context ----------------------------------------------------------------------------------------------
 struct zl_bases {
@@ -106,6 +109,7 @@ struct zl_ctx {
     size_t pinned_cap = 0;
     zl_ctx* aux2 = nullptr;  // second auxiliary context (Groth16: the witness map runs beside the witness-only MSMs)
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
+    void* fb_table[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base window tables of the generators (per group config, built on first use)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 8; reset when the next proof starts)
     size_t g16_h_n = 0;
 };

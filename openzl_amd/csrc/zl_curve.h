@@ -225,6 +225,34 @@ ZL_HD constexpr void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
     p.zz = mul(mul(p.zz, q.zz), pp);
     p.zzz = mul(mul(p.zzz, q.zzz), ppp);
 }
+// ---- Jacobian coordinates (x = X/Z^2, y = Y/Z^3) for long doubling chains: dbl-2009-l is 2M + 5S (5.85 multiplication-equivalents on the
+// 28-bit field) against 7.8 for the XYZZ doubling.  Used by the table construction (c doublings per level).  Z == 0 encodes infinity.
+template <class F>
+struct Jac {
+    F x, y, z;
+    ZL_HD constexpr bool is_inf() const { return z.raw_zero(); }
+    ZL_HD static constexpr Jac inf() { return Jac{F::one(), F::one(), F::zero()}; }
+    ZL_HD static constexpr Jac from_affine(const Affine<F>& a) {
+        if (a.is_inf()) return inf();
+        return Jac{a.x, a.y, F::one()};
+    }
+};
+// p = 2p (dbl-2009-l, a = 0).  Coordinates < 8q in, < 8q out (bounds in units of q beside every line; proved in zl_bounds.h)
+template <class F>
+ZL_HD constexpr void jac_dbl_inplace(Jac<F>& p) {
+    if (p.is_inf()) return;
+    const F a = sqr(p.x), b = sqr(p.y);                       // 64 -> < 2
+    const F c = sqr(b);                                       // < 2
+    const F t = add(p.x, b);                                  // < 10
+    const F d = dbl(subk<1>(subk<1>(sqr(t), a), c));          // (2 + 2) + 2 = 6 -> < 12
+    const F e = add(dbl(a), a);                               // < 6
+    const F x3 = wred(subk<5>(sqr(e), dbl(d)));               // 2 + 32 = 34 -> weakly reduced < 4
+    const F c8 = dbl(dbl(dbl(c)));                            // < 16
+    const F z3 = mul(dbl(p.y), p.z);                          // 16 * 8 -> < 2
+    p.y = muladd(e, subk<2>(d, x3), negk<4>(c8), F::one());   // e (d - x3) - 8c: 6 * 16 + 16 * 1 -> < 2 (Fq2 operands must stay <= 16)
+    p.x = x3;
+    p.z = z3;
+}
 // p = -p
 template <class F>
 ZL_HD constexpr void neg_inplace(XYZZ<F>& p) {
@@ -274,4 +302,5 @@ ZL_HD XYZZ<F> mul_scalar2(const XYZZ<F>& p, const uint32_t* k1, const XYZZ<F>& q
     return acc;
 }
 }  // namespace zl
+template <class F> using Jac = zl::Jac<F>;  // global spelling, like Affine / XYZZ
 #include "zl_bounds.h"  // compile-time proof of the lazy-reduction contracts of the formulas above

@@ -2,7 +2,9 @@
 // "host mirror" section).  Host code only; compiled by hipcc because it shares zl_field.h with the kernels.
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
+#include <thread>
 #include "zl_host.h"
 #include "zl_serialize.h"
 
@@ -14,6 +16,28 @@ static void to_canon_words(uint64_t* out, const Fp<FrP>& mont) {
     memcpy(out, c.l, 32);
 }
 
+// fn(lo, hi, chunk) over [0, n) on up to 64 host threads (the setup path is O(constraints) field work: Lagrange coefficients, the
+// transposed sparse products, exponent vectors; single-threaded it cost 3 s of a 4 s compile at 10^6 constraints)
+template <class Fn>
+static void parallel_chunks(size_t n, size_t min_chunk, Fn fn) {
+    size_t nt = std::min<size_t>(std::max<unsigned>(1u, std::thread::hardware_concurrency()), 64);
+    nt = std::min(nt, std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
+    if (nt <= 1) { fn((size_t)0, n, (size_t)0); return; }
+    const size_t per = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) {
+        const size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { fn(lo, hi, t); });
+    }
+    for (auto& x : th) x.join();
+}
+template <class FrP>
+static Fp<FrP> pow_u64(const Fp<FrP>& a, uint64_t e) {
+    const uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+    return zl::pow_words(a, w, 64);
+}
+
 template <class FrP>
 void R1csExport<FrP>::build(const R1CS<FrP>& cs) {
     const size_t nc = cs.constraint_count();
@@ -22,20 +46,25 @@ void R1csExport<FrP>::build(const R1CS<FrP>& cs) {
         ptr[m].assign(1, 0);
         col[m].clear();
         val[m].clear();
+        ptr[m].resize(rows.size() + 1);
         size_t nnz = 0;
-        for (auto& lc : rows) nnz += lc.terms.size();
-        col[m].reserve(nnz);
-        val[m].reserve(nnz * 4);
-        for (auto& lc : rows) {
-            // variable order: instance block then witness block; keys sort the same way (witness bit is the top bit)
-            for (auto& t : lc.terms) {
-                col[m].push_back(cs.var_index(t.first));
-                uint64_t w[4];
-                to_canon_words<FrP>(w, t.second);
-                val[m].insert(val[m].end(), w, w + 4);
+        for (size_t r = 0; r < rows.size(); r++) { nnz += rows[r].terms.size(); ptr[m][r + 1] = (uint32_t)nnz; }
+        col[m].resize(nnz);
+        val[m].resize(nnz * 4);
+        uint32_t* colp = col[m].data();
+        uint64_t* valp = val[m].data();
+        const uint32_t* pp = ptr[m].data();
+        parallel_chunks(rows.size(), 4096, [&, colp, valp, pp](size_t lo, size_t hi, size_t) {
+            for (size_t r = lo; r < hi; r++) {
+                size_t k = pp[r];
+                // variable order: instance block then witness block; keys sort the same way (witness bit is the top bit)
+                for (auto& t : rows[r].terms) {
+                    colp[k] = cs.var_index(t.first);
+                    to_canon_words<FrP>(valp + 4 * k, t.second);
+                    k++;
+                }
             }
-            ptr[m].push_back((uint32_t)col[m].size());
-        }
+        });
         view.row_ptr[m] = ptr[m].data();
         view.col[m] = col[m].data();
         view.val[m] = val[m].data();
@@ -44,7 +73,10 @@ void R1csExport<FrP>::build(const R1CS<FrP>& cs) {
     const auto& wit = cs.witness_assignment();
     assignment.resize((inst.size() + wit.size()) * 4);
     for (size_t i = 0; i < inst.size(); i++) to_canon_words<FrP>(&assignment[4 * i], inst[i]);
-    for (size_t i = 0; i < wit.size(); i++) to_canon_words<FrP>(&assignment[4 * (inst.size() + i)], wit[i]);
+    uint64_t* asg = assignment.data() + 4 * inst.size();
+    parallel_chunks(wit.size(), 8192, [&, asg](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) to_canon_words<FrP>(asg + 4 * i, wit[i]);
+    });
     view.n_constraints = (uint32_t)nc;
     view.n_instance = (uint32_t)inst.size();
     view.n_witness = (uint32_t)wit.size();
@@ -91,44 +123,77 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     // Lagrange coefficients L_j = Z(tau)/N * w^j / (tau - w^j), batch inversion
     std::vector<F> L(N), den(N), pref(N);
     {
-        F wj = F::one();
-        for (size_t j = 0; j < N; j++) { den[j] = zl::sub(tau, wj); L[j] = wj; wj = zl::mul(wj, w); }
-        F acc = F::one();
-        for (size_t j = 0; j < N; j++) { pref[j] = acc; acc = zl::mul(acc, den[j]); }
-        F inv = zl::inv(acc);
         const F scale = zl::mul(zt, zl::inv(zl::from_u64<FrP>((uint64_t)N)));
-        for (size_t j = N; j-- > 0;) {
-            const F dinv = zl::mul(inv, pref[j]);
-            inv = zl::mul(inv, den[j]);
-            L[j] = zl::mul(zl::mul(L[j], dinv), scale);
-        }
+        parallel_chunks(N, 4096, [&](size_t lo, size_t hi, size_t) {  // every chunk shares one inversion among its denominators
+            F wj = pow_u64<FrP>(w, (uint64_t)lo);
+            F acc = F::one();
+            for (size_t j = lo; j < hi; j++) {
+                den[j] = zl::sub(tau, wj);
+                L[j] = wj;
+                wj = zl::mul(wj, w);
+                pref[j] = acc;
+                acc = zl::mul(acc, den[j]);
+            }
+            F inv = zl::inv(acc);
+            for (size_t j = hi; j-- > lo;) {
+                const F dinv = zl::mul(inv, pref[j]);
+                inv = zl::mul(inv, den[j]);
+                L[j] = zl::mul(zl::mul(L[j], dinv), scale);
+            }
+        });
     }
     std::vector<F> u(nv, F::zero()), v(nv, F::zero()), ww(nv, F::zero());
     for (size_t j = 0; j < ni; j++) u[j] = L[nc + j];
-    for (int m = 0; m < 3; m++) {
-        std::vector<F>& dst = m == 0 ? u : m == 1 ? v : ww;
-        const auto& rows = cs.rows(m);
-        for (size_t row = 0; row < rows.size(); row++)
-            for (auto& t : rows[row].terms) {
-                const uint32_t i = cs.var_index(t.first);
-                dst[i] = zl::add(dst[i], zl::mul(t.second, L[row]));
+    {
+        // u = A^T L, v = B^T L, w = C^T L: scatter-adds over the variables.  Row chunks accumulate into private vectors (<= 8 per matrix),
+        // which are then summed per variable range; the three matrices run side by side.
+        auto transposed = [&](int m, std::vector<F>& dst) {
+            const auto& rows = cs.rows(m);
+            const size_t parts = std::min<size_t>(8, std::max<size_t>(1, rows.size() / 65536));
+            std::vector<std::vector<F>> priv(parts > 1 ? parts - 1 : 0, std::vector<F>(nv, F::zero()));
+            const size_t per = (rows.size() + parts - 1) / parts;
+            std::vector<std::thread> th;
+            for (size_t p = 0; p < parts; p++) {
+                th.emplace_back([&, p]() {
+                    std::vector<F>& acc = p == 0 ? dst : priv[p - 1];
+                    const size_t lo = p * per, hi = std::min(rows.size(), lo + per);
+                    for (size_t row = lo; row < hi; row++)
+                        for (auto& t : rows[row].terms) {
+                            const uint32_t i = cs.var_index(t.first);
+                            acc[i] = zl::add(acc[i], zl::mul(t.second, L[row]));
+                        }
+                });
             }
+            for (auto& x : th) x.join();
+            if (parts > 1)
+                parallel_chunks(nv, 8192, [&](size_t lo, size_t hi, size_t) {
+                    for (auto& pv : priv)
+                        for (size_t i = lo; i < hi; i++) dst[i] = zl::add(dst[i], pv[i]);
+                });
+        };
+        std::thread tb([&]() { transposed(1, v); }), tc([&]() { transposed(2, ww); });
+        transposed(0, u);
+        tb.join();
+        tc.join();
     }
     const F dinv = zl::inv(delta), ginv = zl::inv(gamma);
     // exponent vectors (canonical) for the device generator
     std::vector<uint64_t> ea(nv * 4), eb(nv * 4), eh((N - 1) * 4), el(std::max<size_t>(nw, 1) * 4), single(5 * 4);
     VerifyingContext vk;
-    for (size_t i = 0; i < nv; i++) {
-        to_canon_words<FrP>(&ea[4 * i], u[i]);
-        to_canon_words<FrP>(&eb[4 * i], v[i]);
-        const F comb = zl::add(zl::add(zl::mul(beta, u[i]), zl::mul(alpha, v[i])), ww[i]);
-        if (i < ni) vk.gamma_abc_exponents.push_back(zl::mul(comb, ginv));
-        else to_canon_words<FrP>(&el[4 * (i - ni)], zl::mul(comb, dinv));
-    }
-    {
-        F tp = zl::mul(zt, dinv);
-        for (size_t j = 0; j + 1 < N; j++) { to_canon_words<FrP>(&eh[4 * j], tp); tp = zl::mul(tp, tau); }
-    }
+    vk.gamma_abc_exponents.resize(ni);
+    parallel_chunks(nv, 8192, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) {
+            to_canon_words<FrP>(&ea[4 * i], u[i]);
+            to_canon_words<FrP>(&eb[4 * i], v[i]);
+            const F comb = zl::add(zl::add(zl::mul(beta, u[i]), zl::mul(alpha, v[i])), ww[i]);
+            if (i < ni) vk.gamma_abc_exponents[i] = zl::mul(comb, ginv);
+            else to_canon_words<FrP>(&el[4 * (i - ni)], zl::mul(comb, dinv));
+        }
+    });
+    parallel_chunks(N - 1, 8192, [&](size_t lo, size_t hi, size_t) {
+        F tp = zl::mul(zl::mul(zt, dinv), pow_u64<FrP>(tau, (uint64_t)lo));
+        for (size_t j = lo; j < hi; j++) { to_canon_words<FrP>(&eh[4 * j], tp); tp = zl::mul(tp, tau); }
+    });
     ProvingContext pc;
     pc.ctx = ctx;
     pc.trapdoor = td;

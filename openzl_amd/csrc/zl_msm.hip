@@ -1033,39 +1033,122 @@ __global__ void __launch_bounds__(128) k_bases_export(const Affine<typename G::F
     FieldIO<F>::store_canon(dst, p.x);
     FieldIO<F>::store_canon(dst + WORDS, p.y);
 }
-// bases[i] = k[i] * G by double-and-add, then one inversion per point (input generator, untimed)
+// ---- fixed-base windowed generation + batch normalisation (the setup path: ark_ec::msm::FixedBaseMSM::{get_window_table,
+// multi_scalar_mul} + ProjectiveCurve::batch_normalization_into_affine behind Groth16::compile,
+// /root/reference/plugins/arkworks/src/groth16.rs:427-443) -------------------------------------------------------
+// T[w][d] = d * 2^(ZL_FB_BITS w) * G (affine), shared by every point: k * G is then ceil(256 / ZL_FB_BITS) mixed additions of table
+// entries instead of 256 doublings + ~128 additions, and the affine conversion shares ONE field inversion among the ~32-64 points a
+// lane normalises (Montgomery's trick) instead of one 570-multiplication Fermat inversion per point.
+#ifndef ZL_FB_BITS
+#define ZL_FB_BITS 8
+#endif
+#define ZL_FB_WINDOWS ((256 + ZL_FB_BITS - 1) / ZL_FB_BITS)
+// Out-of-line group operations for the cold table-construction kernels: with Fq2 coordinates a fully inlined doubling + addition loop
+// needs the whole 512-register budget plus spills, and hipcc (ROCm 7.2) was observed to drop one limb of a spilled coordinate in that
+// shape (k_fb_table<BlsG2>: zz.c0.l[11] written as 0).  One call per operation keeps the kernels small; they are not on any timed path.
+template <class F> __device__ __noinline__ void zl_add_full_ool(XYZZ<F>* p, const XYZZ<F>* q) { zl::add_full(*p, *q); }
+template <class F> __device__ __noinline__ void zl_dbl_ool(XYZZ<F>* p) { zl::dbl_inplace(*p); }
+// lane w: base_w = 2^(ZL_FB_BITS w) * G  (one-time, latency only)
 template <class G>
-__global__ void __launch_bounds__(64) k_bases_generate(const uint32_t* __restrict__ k, uint32_t n, Affine<typename G::F>* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_fb_bases(XYZZ<typename G::F>* __restrict__ out) {
     using F = typename G::F;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t* s = k + (size_t)i * 8;
-    const F gx = G::gen_x(), gy = G::gen_y();
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int bit = 255; bit >= 0; bit--) {
-        zl::dbl_inplace(acc);
-        if ((s[bit >> 5] >> (bit & 31)) & 1) zl::add_mixed(acc, gx, gy, false);
-    }
-    out[i] = zl::to_affine(acc);
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ZL_FB_WINDOWS) return;
+    XYZZ<F> p = XYZZ<F>::from_affine(Affine<F>{G::gen_x(), G::gen_y()});
+    for (uint32_t k = 0; k < w * ZL_FB_BITS; k++) zl_dbl_ool(&p);
+    out[w] = p;
 }
-
-// table[w][i] = 2^(c w) * P_i (affine), w < W: c doublings per level, one inversion per level (upload-time, untimed)
+// lane (w, d): d * base_w by double-and-add -> XYZZ (normalised afterwards by k_batch_affine)
 template <class G>
-__global__ void __launch_bounds__(64) k_bases_precompute(const Affine<typename G::F>* __restrict__ in, uint32_t n, int c, int W,
-                                                          Affine<typename G::F>* __restrict__ table) {
+__global__ void __launch_bounds__(64) k_fb_table(const XYZZ<typename G::F>* __restrict__ bases_w, XYZZ<typename G::F>* __restrict__ out) {
+    using F = typename G::F;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)ZL_FB_WINDOWS << ZL_FB_BITS) return;
+    const uint32_t w = t >> ZL_FB_BITS, d = t & ((1u << ZL_FB_BITS) - 1u);
+    const XYZZ<F> base = bases_w[w];
+    XYZZ<F> acc = XYZZ<F>::inf();
+#pragma nounroll
+    for (int i = ZL_FB_BITS - 1; i >= 0; i--) {
+        zl_dbl_ool(&acc);
+        if ((d >> i) & 1) zl_add_full_ool(&acc, &base);
+    }
+    out[t] = acc;
+}
+// out[i] = k[i] * G as XYZZ: one mixed addition per non-zero window digit
+template <class G>
+__global__ void __launch_bounds__(64) k_bases_generate_fb(const uint32_t* __restrict__ k, uint32_t n, const Affine<typename G::F>* __restrict__ table,
+                                                           XYZZ<typename G::F>* __restrict__ out) {
     using F = typename G::F;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<F> p = in[i];
-    table[i] = p;
-    for (int w = 1; w < W; w++) {
-        if (!p.is_inf()) {
-            XYZZ<F> q = zl::dbl_affine(p.x, p.y);
-            for (int k = 1; k < c; k++) zl::dbl_inplace(q);
-            p = zl::to_affine(q);
-        }
-        table[(size_t)w * n + i] = p;
+    const uint4* sp = reinterpret_cast<const uint4*>(k + (size_t)i * 8);
+    const uint4 lo = sp[0], hi = sp[1];
+    const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < ZL_FB_WINDOWS; w++) {
+        const uint32_t d = zl_get_bits(s, w * ZL_FB_BITS, ZL_FB_BITS);
+        if (d == 0) continue;
+        const Affine<F> P = table[((size_t)w << ZL_FB_BITS) + d];
+        zl::add_mixed(acc, P.x, P.y, false);
     }
+    out[i] = acc;
+}
+// batch_normalization_into_affine: lane t normalises elements t, t + lanes, t + 2 lanes, ... (coalesced) with ONE inversion: forward
+// sweep stores the running product of the denominators, one Fermat inversion, backward sweep peels the inverses off.
+// FORM 0: XYZZ (denominator zzz; x / zz, y / zzz), FORM 1: Jacobian (denominator z; x / z^2, y / z^3).  Infinity in -> infinity out.
+template <class G, int FORM>
+__global__ void __launch_bounds__(64) k_batch_affine(const void* __restrict__ in_, uint32_t n, uint32_t lanes, typename G::F* __restrict__ prefix,
+                                                      Affine<typename G::F>* __restrict__ out) {
+    using F = typename G::F;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    const XYZZ<F>* in_x = reinterpret_cast<const XYZZ<F>*>(in_);
+    const Jac<F>* in_j = reinterpret_cast<const Jac<F>*>(in_);
+    F acc = F::one();
+    uint32_t last = t;
+    for (uint32_t i = t; i < n; i += lanes) {
+        F d;
+        if (FORM == 0) d = in_x[i].zzz; else d = in_j[i].z;
+        prefix[i] = acc;
+        if (!d.raw_zero()) acc = zl::mul(acc, d);
+        last = i;
+    }
+    F u = zl::inv(acc);
+    for (uint32_t i = last;; i -= lanes) {
+        if (FORM == 0) {
+            const XYZZ<F> p = in_x[i];
+            if (p.is_inf()) {
+                out[i] = Affine<F>::inf();
+            } else {
+                const F izzz = zl::mul(u, prefix[i]);
+                u = zl::mul(u, p.zzz);
+                const F tt = zl::mul(p.zz, izzz);  // 1 / z
+                const F izz = zl::mul(tt, tt);     // 1 / zz
+                out[i] = Affine<F>{zl::canon(zl::mul(p.x, izz)), zl::canon(zl::mul(p.y, izzz))};
+            }
+        } else {
+            const Jac<F> p = in_j[i];
+            if (p.is_inf()) {
+                out[i] = Affine<F>::inf();
+            } else {
+                const F iz = zl::mul(u, prefix[i]);
+                u = zl::mul(u, p.z);
+                const F iz2 = zl::sqr(iz);
+                out[i] = Affine<F>{zl::canon(zl::mul(p.x, iz2)), zl::canon(zl::mul(p.y, zl::mul(iz2, iz)))};
+            }
+        }
+        if (i < lanes) break;
+    }
+}
+// one level of the window table: out[i] = 2^c * in[i] in Jacobian coordinates (c doublings at 2M + 5S), normalised by k_batch_affine
+template <class G>
+__global__ void __launch_bounds__(64) k_bases_level_dbl(const Affine<typename G::F>* __restrict__ in, uint32_t n, int c, Jac<typename G::F>* __restrict__ out) {
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jac<F> q = Jac<F>::from_affine(in[i]);
+    for (int k = 0; k < c; k++) zl::jac_dbl_inplace(q);
+    out[i] = q;
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -1605,7 +1688,49 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     return ZL_OK;
 }
 
-// table[w][i] = 2^(c w) P_i for every base of the handle (one-time, at upload)
+// in (XYZZ / Jacobian, n elements) -> out (affine), sharing one inversion among the elements of a lane; prefix scratch in slot `slot`
+template <class G, int FORM>
+static int batch_affine_t(zl_ctx* ctx, const void* d_in, size_t n, Affine<typename G::F>* d_out, int slot, hipStream_t st) {
+    using F = typename G::F;
+    if (!n) return ZL_OK;
+    void* d_prefix;
+    int rc;
+    if ((rc = zl_scratch_get(ctx, slot, n * sizeof(F), &d_prefix))) return rc;
+    // ~2^18 lanes (>= 1 wave per SIMD) once there is enough work; up to 64 elements share an inversion
+    uint32_t per = (uint32_t)std::min<size_t>(64, std::max<size_t>(1, n >> 18));
+    per = (uint32_t)std::max(1, zl_tune("ZL_TUNE_BATCH_INV", (int)per));
+    const uint32_t lanes = (uint32_t)((n + per - 1) / per);
+    hipLaunchKernelGGL((k_batch_affine<G, FORM>), dim3((lanes + 63) / 64), dim3(64), 0, st, d_in, (uint32_t)n, lanes, (F*)d_prefix, d_out);
+    ZL_HIP(ctx, hipGetLastError());
+    return ZL_OK;
+}
+// the shared fixed-base table of the group's generator (built once per ctx, ~1 MB for 8-bit windows)
+template <class G>
+static int fb_table_get(zl_ctx* ctx, const Affine<typename G::F>** out) {
+    using F = typename G::F;
+    void*& slot = ctx->fb_table[G::ID];
+    if (!slot) {
+        const size_t entries = (size_t)ZL_FB_WINDOWS << ZL_FB_BITS;
+        void *d_tab = nullptr, *d_tmp = nullptr;
+        ZL_HIP(ctx, hipMalloc(&d_tab, entries * sizeof(Affine<F>)));
+        int rc = zl_scratch_get(ctx, 5, (entries + ZL_FB_WINDOWS) * sizeof(XYZZ<F>), &d_tmp);
+        if (rc) { (void)hipFree(d_tab); return rc; }
+        XYZZ<F>* d_bw = (XYZZ<F>*)d_tmp;
+        XYZZ<F>* d_x = d_bw + ZL_FB_WINDOWS;
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL((k_fb_bases<G>), dim3((ZL_FB_WINDOWS + 63) / 64), dim3(64), 0, st, d_bw);
+        hipLaunchKernelGGL((k_fb_table<G>), dim3((uint32_t)((entries + 63) / 64)), dim3(64), 0, st, d_bw, d_x);
+        rc = batch_affine_t<G, 0>(ctx, d_x, entries, (Affine<F>*)d_tab, 6, st);
+        hipError_t e = rc ? hipSuccess : hipStreamSynchronize(st);
+        if (rc || e != hipSuccess) { (void)hipFree(d_tab); if (!rc) { ctx->last_hip = (int)e; rc = ZL_EHIP; } return rc; }
+        slot = d_tab;
+    }
+    *out = reinterpret_cast<const Affine<F>*>(slot);
+    return ZL_OK;
+}
+
+// table[w][i] = 2^(c w) P_i for every base of the handle (one-time, at upload): level by level, c Jacobian doublings per point and one
+// shared inversion per ~64 points
 template <class G>
 static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
     using F = typename G::F;
@@ -1617,11 +1742,24 @@ static int bases_precompute_t(zl_ctx* ctx, zl_bases& bs, int c) {
     void* t = nullptr;
     ZL_HIP(ctx, hipMalloc(&t, std::max<size_t>(bs.n, 1) * W * sizeof(Affine<F>)));
     if (bs.n) {
-        hipLaunchKernelGGL((k_bases_precompute<G>), dim3((uint32_t)((bs.n + 63) / 64)), dim3(64), 0, ctx->stream, reinterpret_cast<const Affine<F>*>(bs.d_pts),
-                           (uint32_t)bs.n, c, W, reinterpret_cast<Affine<F>*>(t));
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(t); return ZL_EHIP; }
+        hipStream_t st = ctx->stream;
+        Affine<F>* tab = reinterpret_cast<Affine<F>*>(t);
+        void* d_jac = nullptr;
+        int rc = zl_scratch_get(ctx, 5, bs.n * sizeof(Jac<F>), &d_jac);
+        hipError_t e = rc ? hipSuccess : hipMemcpyAsync(tab, bs.d_pts, bs.n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, st);
+        for (int w = 1; w < W && !rc && e == hipSuccess; w++) {
+            hipLaunchKernelGGL((k_bases_level_dbl<G>), dim3((uint32_t)((bs.n + 63) / 64)), dim3(64), 0, st, tab + (size_t)(w - 1) * bs.n, (uint32_t)bs.n, c,
+                               (Jac<F>*)d_jac);
+            e = hipGetLastError();
+            if (e == hipSuccess) rc = batch_affine_t<G, 1>(ctx, d_jac, bs.n, tab + (size_t)w * bs.n, 6, st);
+        }
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(st);
+        if (rc || e != hipSuccess) {
+            if (!rc) { ctx->last_hip = (int)e; rc = ZL_EHIP; }
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(t);
+            return rc;
+        }
     }
     bs.d_table = t;
     bs.precomp_c = c;
@@ -1758,15 +1896,20 @@ static int bases_generate_t(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* 
     if (n) {
         void* d_k;
         int rc;
-        if ((rc = zl_scratch_get(ctx, 5, n * 32, &d_k))) { (void)hipFree(d_pts); return rc; }
+        const Affine<F>* d_tab = nullptr;
+        if ((rc = fb_table_get<G>(ctx, &d_tab))) { (void)hipFree(d_pts); return rc; }  // uses slots 5 / 6 itself: before d_k is bound
+        void* d_x;
+        if ((rc = zl_scratch_get(ctx, 5, n * 32 + 256 + n * sizeof(XYZZ<F>), &d_k))) { (void)hipFree(d_pts); return rc; }
+        d_x = reinterpret_cast<unsigned char*>(d_k) + ((n * 32 + 255) / 256) * 256;
         hipStream_t st = ctx->stream;
         hipError_t e = hipMemcpyAsync(d_k, k, n * 32, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_bases_generate<G>), dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_k, (uint32_t)n, (Affine<F>*)d_pts);
+            hipLaunchKernelGGL((k_bases_generate_fb<G>), dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, (const uint32_t*)d_k, (uint32_t)n, d_tab, (XYZZ<F>*)d_x);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(d_pts); return ZL_EHIP; }
+        if (e == hipSuccess) rc = batch_affine_t<G, 0>(ctx, d_x, n, (Affine<F>*)d_pts, 6, st);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+        if (rc || e != hipSuccess) { if (!rc) { ctx->last_hip = (int)e; rc = ZL_EHIP; } (void)hipStreamSynchronize(st); (void)hipFree(d_pts); return rc; }
     }
     out->d_pts = d_pts;
     out->n = n;

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     L = load_library()
     hdr = open(os.path.join(ROOT, "include", "zl_backend.h")).read()
-    declared = set(re.findall(r"^\s*(?:const char\*|int|void|size_t)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:const char\*|zl_ctx\*|int|void|size_t)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared, "header parse failed"
     assert declared == set(ABI_SYMBOLS)
     for sym in declared:
@@ -29,7 +29,7 @@ def test_library_exports_every_declared_test_hook():
     """include/zl_backend_test.h: test-only hooks (device field KAT, raw-limb field / point access); host paths run without a GPU"""
     L = load_library()
     hdr = open(os.path.join(ROOT, "include", "zl_backend_test.h")).read()
-    declared = set(re.findall(r"^\s*(?:const char\*|int|void|size_t)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:const char\*|zl_ctx\*|int|void|size_t)\s+(zl_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(TEST_ABI_SYMBOLS)
     for sym in declared:
         assert getattr(L, sym) is not None
