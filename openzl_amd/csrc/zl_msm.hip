@@ -884,86 +884,60 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------ bucket reduction
-// sum_{k=1..H} k * B_k per bucket set, hierarchically and without any scalar multiple.  A block of L consecutive buckets is summarised by
-// the pair (A, R): A = sum_j j * B_{k0+j} (weights local to the block), R = sum_j B_{k0+j}.  G consecutive blocks of equal length L
-// combine to  A = sum_i A_i + L * sum_i i * R_i,  R = sum_i R_i  (i = 0..G-1): one running-sum pass over the R_i (2 additions per
-// element), one addition per A_i, and log2(L) doublings + 1 addition per lane for the factor L.  Level 0 (L = 1) reads the buckets
-// themselves (A_i = R_i = B_i: the classic running sum, 2 additions per bucket).  Every level is one launch with one lane per output
-// block, so the lane count falls by G per level and no lane ever runs a double-and-add ladder for its offset (the former k0 * run
-// term cost more than the segment's own additions).  The root block's A is the window sum.
-// in_a == nullptr: level 0 (elements are single buckets).  Elements of set s live at [s * in_stride, s * in_stride + count).
-// Above level 0 a block is shared by a lane pair: the even lane sums the A_i, the odd lane runs the weighted chain over the R_i and
-// hands its result over by shuffles, so the dependent chain per level is 2 * group additions instead of 3 * group.
-// flat_set / flat_log: blocks of set flat_set whose inputs are at least 2^flat_log buckets long carry no offset weight (the spread
-// top window, k_msm_recode_wide): A = sum A_i there.
+// sum_{k=1..H} k * B_k per bucket set without any scalar multiple and with a dependent chain of only ~log2(H) additions:
+//   level 0   one lane per block of g0 consecutive buckets (bucket index i <-> weight i + 1): running sums in registers give
+//             T = sum B_i and A = sum (i - i0 + 1) B_i   (2 additions per bucket, the classic trick inside the block)
+//   tree      the remaining weight of block j is g0 * j.  sum_j j T_j = sum_b 2^b S_b with S_b = sum of the T_j whose index has bit b
+//             set.  A binary tree over the block index carries, per node, the channels (T, A, S_0 .. S_(level-1)): combining children
+//             (L, R) adds channel-wise, and the new top channel is S_(level-1) = T_R.  Every (node, channel) pair is ONE independent
+//             addition (one lane), so a tree level is one launch of depth 1 and the whole reduction is log2(H / g0) dependent
+//             additions -- no lane runs a double-and-add ladder for its offset and nothing is multiplied by a power of two on the
+//             device.  Total work stays ~2 additions per bucket + ~3 per block.
+//   host      the root's channels of every set, folded into the window Horner it runs anyway: position c w + log2 g0 + b receives
+//             S_(w,b), position c w receives A_w (one extra addition per bit position, no extra doublings).
+// flat_set: the spread top window (k_msm_recode_wide): its buckets are weighted by their low spread_t bits only; level 0 is weightless
+// for it when spread_t == 0, and the host skips its S_b from bit spread_t on.
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ in_r, uint32_t in_stride, uint32_t count, uint32_t group,
-                                                           uint32_t blocks_per_set, uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
-                                                           XYZZ<typename G::F>* __restrict__ out_a, XYZZ<typename G::F>* __restrict__ out_r) {
+__global__ void __launch_bounds__(64) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
+                                                           uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
+                                                           XYZZ<typename G::F>* __restrict__ out /* [set][block][2]: T, A */) {
     ZL_SIDE_PRIO();
     using X = XYZZ<typename G::F>;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_blocks) return;
     const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
-    const uint32_t i0 = blk * group, i1 = min(count, i0 + group);
-    const size_t base = (size_t)set * in_stride;
+    const uint32_t i0 = blk * group, i1 = min(H, i0 + group);
+    const size_t base = (size_t)set * H;
     const bool flat = set == flat_set && flat_log == 0;
-    // wsum = sum (i - i0 + 1) * B_i, run = sum B_i
     X run = X::inf(), wsum = X::inf();
     for (uint32_t i = i1; i > i0; i--) {
-        const X B = in_r[base + (i - 1)];
+        const X B = buckets[base + (i - 1)];
         zl::add_full(run, B);
         if (!flat) zl::add_full(wsum, run);
     }
-    out_a[t] = flat ? run : wsum;
-    out_r[t] = run;
+    out[(size_t)2 * t] = run;
+    out[(size_t)2 * t + 1] = flat ? run : wsum;
 }
+// one tree level: nodes of `level` (1-based) from the nodes of level - 1.  Node layout: [set][node][channel], ch_in = level + 1 channels
+// in (T, A, S_0 .. S_(level-2)), ch_out = level + 2 out.  One lane per (set, node, out channel).
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_reduce_level(const XYZZ<typename G::F>* __restrict__ in_a, const XYZZ<typename G::F>* __restrict__ in_r,
-                                                          uint32_t in_stride, uint32_t count, uint32_t group, uint32_t log_len, uint32_t blocks_per_set,
-                                                          uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
-                                                          XYZZ<typename G::F>* __restrict__ out_a, XYZZ<typename G::F>* __restrict__ out_r) {
+__global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F>* __restrict__ in, XYZZ<typename G::F>* __restrict__ out, uint32_t level,
+                                                         uint32_t nodes_out_per_set, uint32_t total_lanes) {
     ZL_SIDE_PRIO();
-    using F = typename G::F;
-    using X = XYZZ<F>;
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t t = lane >> 1, role = lane & 1u;
-    const bool live = t < total_blocks;
-    const uint32_t tt = live ? t : 0u;
-    const uint32_t set = tt / blocks_per_set, blk = tt % blocks_per_set;
-    const uint32_t i0 = blk * group, i1 = live ? min(count, i0 + group) : i0;
-    const size_t base = (size_t)set * in_stride;
-    const bool flat = set == flat_set && log_len >= flat_log;
-    X acc = X::inf(), run = X::inf();
-    if (role == 0) {
-        for (uint32_t i = i0; i < i1; i++) {  // sum A_i
-            const X A = in_a[base + i];
-            zl::add_full(acc, A);
-        }
-    } else {
-        // acc = sum (i - i0) * R_i (the first element has weight 0), run = sum R_i
-        for (uint32_t i = i1; i > i0; i--) {
-            const X R = in_r[base + (i - 1)];
-            zl::add_full(run, R);
-            if (i - 1 > i0 && !flat) zl::add_full(acc, run);
-        }
-        if (!flat) for (uint32_t k = 0; k < log_len; k++) zl::dbl_inplace(acc);  // * L (a power of two)
+    using X = XYZZ<typename G::F>;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_lanes) return;
+    const uint32_t ch_out = level + 2, ch_in = level + 1;
+    const uint32_t ch = t % ch_out, node = (t / ch_out) % nodes_out_per_set, set = t / (ch_out * nodes_out_per_set);
+    const size_t left = ((size_t)set * nodes_out_per_set * 2 + (size_t)2 * node) * ch_in, right = left + ch_in;
+    if (ch == ch_out - 1) {  // the new top channel: blocks of the right child have this bit set
+        out[t] = in[right];
+        return;
     }
-    // the odd lane's weighted sum travels to the even lane (all lanes of the wave take part in the shuffles)
-    X other;
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
-#pragma unroll
-        for (uint32_t k = 0; k < sizeof(X) / 4; k++) dst[k] = __shfl_xor(src[k], 1);
-    }
-    if (!live) return;
-    if (role == 0) {
-        zl::add_full(acc, other);
-        out_a[t] = acc;
-    } else {
-        out_r[t] = run;
-    }
+    X acc = in[left + ch];
+    const X o = in[right + ch];
+    zl::add_full(acc, o);
+    out[t] = acc;
 }
 // tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
 // set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
@@ -1203,9 +1177,8 @@ struct MsmJob {
     int spread_t = -1;  // >= 0: the top window's entries are spread over its bucket set, weights = low spread_t bits + 1
     bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
     uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, scan_blocks = 0, max_big = 0, max_giant = 0, Gn = 0;
-    struct RedLevel { uint32_t count, group, log_len, blocks; size_t out_off; };
-    std::vector<RedLevel> red;  // hierarchical bucket reduction: level 0 reads the buckets, the last level leaves one point per set
-    size_t red_elems = 0;       // (A, R) pairs of all levels
+    uint32_t red_g0 = 0, red_lg0 = 0, red_blocks = 0, red_levels = 0;  // bucket reduction: block length of level 0, blocks per set, tree levels
+    uint32_t roots_per_set = 0;                                         // channels of a set's root node: T, A, S_0 .. S_(levels-1)
     uint64_t maxE = 0;
     size_t n = 0, first = 0;
     const zl_bases* bsp = nullptr;
@@ -1248,37 +1221,23 @@ struct MsmJob {
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
-        // hierarchical bucket reduction (k_msm_reduce_level): groups of 8 (4 for small inputs: more lanes, shorter chains) per level
+        // bucket reduction (k_msm_reduce_level0 + k_msm_reduce_tree): blocks of 8 buckets (4 for small inputs: more lanes, shorter chains)
         {
             uint32_t g0 = NB >= (1u << 17) ? 8u : 4u;
             g0 = (uint32_t)std::max(2, zl_tune("ZL_TUNE_SEG", (int)g0));
-            const uint32_t gk = (uint32_t)std::max(2, zl_tune("ZL_TUNE_GRP", 4));
-            // plain wide windows: spread the narrow top window over its whole bucket set (k_msm_recode_wide); its low spread_t bits
-            // carry the weight, so a level boundary must fall on block length 2^spread_t
+            while (g0 & (g0 - 1)) g0 &= g0 - 1;
+            if (g0 > H) g0 = H;
+            red_g0 = g0;
+            red_lg0 = 31 - __builtin_clz(g0);
+            red_blocks = H / g0;  // both powers of two
+            red_levels = 31 - __builtin_clz(red_blocks);
+            roots_per_set = red_levels + 2;
+            // plain wide windows: spread the narrow top window over its whole bucket set (k_msm_recode_wide); the weight then lives in the
+            // low spread_t bits of the bucket index: all of level 0's bits must be on one side of that boundary
             spread_t = -1;
             if (wide && !pre) {
                 const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
-                if (top_bits - 1 < c - 1) spread_t = top_bits - 1;
-            }
-            red.clear();
-            red_elems = 0;
-            uint32_t count = H, log_len = 0;
-            for (;;) {
-                uint32_t g = red.empty() ? g0 : gk;
-                while (g & (g - 1)) g &= g - 1;  // power of two (block lengths stay powers of two)
-                if (spread_t > 0 && (int)log_len < spread_t) {
-                    while (g > 2 && log_len + 31 - __builtin_clz(g) > (uint32_t)spread_t) g >>= 1;
-                    if (log_len + 31 - __builtin_clz(g) > (uint32_t)spread_t) g = 1u << ((uint32_t)spread_t - log_len);
-                }
-                if (g > count) g = count;
-                const uint32_t blocks = (count + g - 1) / g;
-                red.push_back(RedLevel{count, g, log_len, blocks, red_elems});
-                red_elems += (size_t)SETS * blocks;
-                if (blocks == 1) break;
-                uint32_t lg = 0;
-                while ((1u << lg) < g) lg++;
-                log_len += lg;
-                count = blocks;
+                if (top_bits - 1 < c - 1 && (top_bits - 1 == 0 || top_bits - 1 >= (int)red_lg0)) spread_t = top_bits - 1;
             }
         }
         scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
@@ -1286,7 +1245,7 @@ struct MsmJob {
         max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         sc = reinterpret_cast<const uint32_t*>(d_scalars);
-        hw_own.assign(SETS + 1, X::inf());
+        hw_own.assign((size_t)SETS * roots_per_set + 1, X::inf());
         hw = hw_own.data();
         hE = &hE_own;
         return ZL_OK;
@@ -1319,11 +1278,14 @@ struct MsmJob {
         d_buckets = (X*)p;
         if ((rc = zl_scratch_get(ctx, o + 3, (size_t)2 * nchunks * sizeof(X), &p))) return rc;
         d_partials = (X*)p;
-        if ((rc = zl_scratch_get(ctx, 4, ((size_t)2 * red_elems + (size_t)SETS + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
-        d_segs = (X*)p;                    // A parts of all reduction levels
-        d_stage1 = d_segs + red_elems;     // R parts
-        d_sets = d_stage1 + red_elems;     // SETS window sums, then the sum of the scalar-1 bases
-        d_ones_parts = d_sets + SETS + 1;
+        // ping-pong node buffers of the reduction tree: leaves = 2 channels x blocks, level 1 = 3 channels x blocks / 2 (the largest)
+        const size_t leaf_elems = (size_t)2 * SETS * red_blocks, lvl1_elems = (size_t)3 * SETS * (red_blocks / 2 + 1);
+        const size_t root_elems = (size_t)SETS * roots_per_set;
+        if ((rc = zl_scratch_get(ctx, 4, (leaf_elems + lvl1_elems + root_elems + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
+        d_segs = (X*)p;                    // tree nodes, even levels (level 0 = leaves)
+        d_stage1 = d_segs + leaf_elems;    // tree nodes, odd levels
+        d_sets = d_stage1 + lvl1_elems;    // the root channels of every set, then the sum of the scalar-1 bases
+        d_ones_parts = d_sets + root_elems + 1;
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
         return ZL_OK;
     }
@@ -1477,38 +1439,42 @@ struct MsmJob {
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
                            pre ? d_bases + first : d_bases, d_ones_parts);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
-                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + SETS);
-        for (size_t l = 0; l < red.size(); l++) {
-            const RedLevel& L = red[l];
-            const uint32_t total = SETS * L.blocks;
-            const X* in_a = l == 0 ? (const X*)nullptr : d_segs + red[l - 1].out_off;
-            const X* in_r = l == 0 ? d_buckets : d_stage1 + red[l - 1].out_off;
-            X* out_a = l + 1 == red.size() ? d_sets : d_segs + L.out_off;  // root blocks: the window sums
+                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set);
+        {
             const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
-            if (l == 0)
-                hipLaunchKernelGGL((k_msm_reduce_level0<G>), dim3((total + 63) / 64), dim3(64), 0, st, in_r, H, L.count, L.group, L.blocks, total, fset, flog, out_a,
-                                   d_stage1 + L.out_off);
-            else
-                hipLaunchKernelGGL((k_msm_reduce_level<G>), dim3((2 * total + 63) / 64), dim3(64), 0, st, in_a, in_r, red[l - 1].blocks, L.count, L.group, L.log_len,
-                                   L.blocks, total, fset, flog, out_a, d_stage1 + L.out_off);
+            const uint32_t leaves = SETS * red_blocks;
+            X* cur = red_levels == 0 ? d_sets : d_segs;
+            hipLaunchKernelGGL((k_msm_reduce_level0<G>), dim3((leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
+            for (uint32_t lv = 1; lv <= red_levels; lv++) {
+                const uint32_t nodes = red_blocks >> lv, lanes = SETS * nodes * (lv + 2);
+                X* nxt = lv == red_levels ? d_sets : ((lv & 1) ? d_stage1 : d_segs);
+                hipLaunchKernelGGL((k_msm_reduce_tree<G>), dim3((lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
+                cur = nxt;
+            }
         }
         ZL_HIP(ctx, hipGetLastError());
-        ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * (SETS + 1), hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * ((size_t)SETS * roots_per_set + 1), hipMemcpyDeviceToHost, st));
         ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
         return ZL_OK;
     }
     X finish() const {
+        // One Horner over the bit positions of the scalar, high to low: the window sum of set w is A_w + g0 * sum_b 2^b S_(w,b), weighted by
+        // 2^(c w) (the table of a precomputed handle already carries that factor: one set, w = 0).  Position c w + lg g0 + b takes S_(w,b),
+        // position c w takes A_w; the doublings are the ones the window Horner needs anyway.
         X total = X::inf();
-        if (pre) {
-            total = hw[0];  // the table already carries the 2^(c w) factors
-        } else {
-            // Horner over windows, high to low: total = sum 2^(c*w) * window[w]
-            for (int w = W - 1; w >= 0; w--) {
-                if (w != W - 1) for (int k = 0; k < c; k++) zl::dbl_inplace(total);
-                zl::add_full(total, hw[w]);
+        const int top = (int)(SETS - 1) * c + (int)red_lg0 + (int)red_levels - 1;
+        for (int pos = std::max(top, 0); pos >= 0; pos--) {
+            if (pos != std::max(top, 0)) zl::dbl_inplace(total);
+            const int w = std::min<int>(pos / c, (int)SETS - 1), off = pos - w * c;
+            const X* root = hw + (size_t)w * roots_per_set;  // channels: T, A, S_0 ..
+            if (off == 0) zl::add_full(total, root[1]);
+            const int bsel = off - (int)red_lg0;
+            if (bsel >= 0 && bsel < (int)red_levels) {
+                const bool skipped = spread_t >= 0 && w == (int)SETS - 1 && off >= spread_t && !pre;  // spread top window: bits from spread_t on carry no weight
+                if (!skipped) zl::add_full(total, root[2 + bsel]);
             }
         }
-        zl::add_full(total, hw[SETS]);
+        zl::add_full(total, hw[(size_t)SETS * roots_per_set]);
         return total;
     }
 };
@@ -1590,7 +1556,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         jobs[i].sort_tmp_sizes(a5, a6);
         t5 = std::max(t5, a5);
         t6 = std::max(t6, a6);
-        max_sets = std::max(max_sets, jobs[i].SETS);
+        max_sets = std::max<uint32_t>(max_sets, jobs[i].SETS * jobs[i].roots_per_set);
     }
     // all buffers up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i: the first pass
     // grows every slot to its largest user, the second binds the final pointers.  Three sets: the tail of job i runs beside the
