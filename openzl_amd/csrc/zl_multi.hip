@@ -123,13 +123,15 @@ void zl_mctx_destroy(zl_mctx* m) {
     for (size_t g = 0; g < m->comms.size(); g++)
         if (m->comms[g]) (void)m->rccl.CommDestroy(m->comms[g]);
     for (int g = 0; g < m->n; g++) {
-        if (g < (int)m->dev.size()) (void)hipSetDevice(m->dev[g]);
-        if (m->ctx[g]) (void)hipStreamSynchronize(m->ctx[g]->stream);
+        if (!m->ctx[g]) continue;  // creation stopped before this rank (e.g. a bad device id): nothing of it exists
+        (void)hipSetDevice(m->dev[g]);
+        (void)hipStreamSynchronize(m->ctx[g]->stream);
         if (m->xbuf[g]) (void)hipFree(m->xbuf[g]);
         if (m->ev[g]) (void)hipEventDestroy(m->ev[g]);
-        if (m->ctx[g]) zl_ctx_destroy(m->ctx[g]);
+        zl_ctx_destroy(m->ctx[g]);
     }
     if (m->rccl.lib) dlclose(m->rccl.lib);
+    (void)hipGetLastError();  // a failed creation must not leave a stale error for the next launch check of another ctx
     delete m;
 }
 
