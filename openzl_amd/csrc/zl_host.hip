@@ -211,8 +211,11 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     // Memory: 13 x 128 B per G1 point, 16 x 256 B per G2 point (about 11 GB for this key).  Small keys stay on the plain path.
     if (!rc) {
         const size_t big = (size_t)1 << 19;
+        const char* e1 = getenv("ZL_TUNE_G1_TABLE_C");
+        const char* e2 = getenv("ZL_TUNE_G2_TABLE_C");
+        const int c1 = e1 ? atoi(e1) : 20, c2 = e2 ? atoi(e2) : 16;
         const struct { uint64_t h; size_t n; int c; } q[5] = {
-            {pc.a_query, (size_t)nv, 20}, {pc.b_g1_query, (size_t)nv, 20}, {pc.h_query, (size_t)N - 1, 20}, {pc.l_query, (size_t)nw, 20}, {pc.b_g2_query, (size_t)nv, 16}};
+            {pc.a_query, (size_t)nv, c1}, {pc.b_g1_query, (size_t)nv, c1}, {pc.h_query, (size_t)N - 1, c1}, {pc.l_query, (size_t)nw, c1}, {pc.b_g2_query, (size_t)nv, c2}};
         for (const auto& e : q)
             if (!rc && e.n >= big) rc = zl_bases_precompute(ctx, e.h, e.c);
     }

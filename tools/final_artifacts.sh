@@ -1,24 +1,43 @@
 #!/bin/bash
-# One gpurun call that regenerates every measured artifact of a round under gpurun_out/final/ (copy into profiles/ afterwards).
+# One gpurun call that regenerates the measured artifacts of round 2 under gpurun_out/final/ (copy into profiles/ afterwards).
 #   gpurun --timeout 2400 -- 'bash tools/final_artifacts.sh'
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-PMCARGS="--steps 1 --warmup 0 --no-cpu --no-ntt --no-skew --groth16-k 0"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o f -f csv -- python bench.py $PMCARGS > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o w -f csv -- python bench.py $PMCARGS > $O/pmc_write.log 2>&1
-python tools/pmc_summary.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) 22 > $O/pmc_traffic.json
-cp $O/pmc_traffic.json profiles/r01_pmc_traffic_final.json
-rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-python tools/prof_summary.py $(find $O/prof -name "*.db" | head -1) > $O/kernel_stats.txt
-rocprofv3 --kernel-trace --stats -d $O/prof_np -o bench -- python bench.py --no-pipeline --no-ntt --no-skew --no-cpu --groth16-k 0 > $O/bench_unpipelined.json 2> $O/bench_unpipelined.err
-python tools/prof_summary.py $(find $O/prof_np -name "*.db" | head -1) > $O/kernel_stats_unpipelined.txt
-python bench.py > $O/bench.json 2> $O/bench.err
-ZL_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --log-n 20 --ntt-log-n 20 > $O/bench_2rank_gloo_1gpu.json 2> $O/bench_2rank.err
-(./tools/fbench28; ./tools/fbench28r; ./tools/fbench_bfly) > $O/fbench_field_mul.log 2>&1
-python tools/msm_sweep.py 16 18 20 22 24 > $O/msm_sweep_plain.log 2>&1
-python tools/msm_sweep.py --g2 16 20 > $O/msm_sweep_g2.log 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/prof $O/prof_np
+csvof() { find $1 -name "*counter_collection.csv" | head -1; }
+dbof() { find $1 -name "*.db" | head -1; }
+# ---- HBM traffic (PMC; separate passes per counter, as the guide prescribes) -------------------------------------------------------
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o f -f csv -- python tools/msm_one.py 24 0 -1 1 > $O/pmc_msm_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o w -f csv -- python tools/msm_one.py 24 0 -1 1 > $O/pmc_msm_write.log 2>&1
+python tools/pmc_fold.py msm $(csvof $O/pf) $(csvof $O/pw) 24 19 0 > $O/r02_pmc_traffic.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf2 -o f -f csv -- python tools/msm_one.py 24 0 22 1 > $O/pmc_msmt_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw2 -o w -f csv -- python tools/msm_one.py 24 0 22 1 > $O/pmc_msmt_write.log 2>&1
+python tools/pmc_fold.py msm $(csvof $O/pf2) $(csvof $O/pw2) 24 22 1 > $O/r02_pmc_traffic_fixed_key.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf3 -o f -f csv -- python tools/ntt_one.py 24 2 > $O/pmc_ntt_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw3 -o w -f csv -- python tools/ntt_one.py 24 2 > $O/pmc_ntt_write.log 2>&1
+python tools/pmc_fold.py ntt $(csvof $O/pf3) $(csvof $O/pw3) 24 > $O/r02_pmc_traffic_ntt.json
+cp $O/r02_pmc_traffic.json $O/r02_pmc_traffic_ntt.json profiles/
+# ---- kernel stats ------------------------------------------------------------------------------------------------------------------
+rocprofv3 --kernel-trace --stats -d $O/p1 -o t -- python bench.py > $O/r02_bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+python tools/prof_summary.py $(dbof $O/p1) > $O/r02_kernel_stats_bench_default.txt
+rocprofv3 --kernel-trace --stats -d $O/p2 -o t -- python tools/msm_one.py 24 0 -1 3 > $O/msm_plain.log 2>&1
+python tools/prof_summary.py $(dbof $O/p2) reduce_tree > $O/r02_kernel_stats_msm_plain_single_call.txt
+rocprofv3 --kernel-trace --stats -d $O/p3 -o t -- python tools/msm_one.py 24 0 22 3 > $O/msm_table.log 2>&1
+python tools/prof_summary.py $(dbof $O/p3) > $O/r02_kernel_stats_msm_fixed_key_single_call.txt
+rocprofv3 --kernel-trace --stats -d $O/p4 -o t -- python tools/ntt_one.py 24 5 > $O/ntt_one.log 2>&1
+python tools/prof_summary.py $(dbof $O/p4) k_ntt_pass > $O/r02_kernel_stats_ntt_2_24.txt
+rocprofv3 --kernel-trace --stats -d $O/p5 -o t -- python tools/g16_one.py > $O/g16_one.log 2>&1
+python tools/prof_summary.py $(dbof $O/p5) > $O/r02_kernel_stats_groth16.txt
+rocprofv3 --kernel-trace --stats -d $O/p6 -o t -- python tools/msm_sweep.py --g2 20 > $O/g2_sweep.log 2>&1
+python tools/prof_summary.py $(dbof $O/p6) > $O/r02_kernel_stats_g2_2_20.txt
+# ---- bench lines and sweeps --------------------------------------------------------------------------------------------------------
+python bench.py > $O/r02_bench_final.json 2> $O/bench.err
+ZL_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --log-n 20 --ntt-log-n 20 --groth16-k 64 > $O/r02_bench_2rank_gloo_1gpu.json 2> $O/bench_2rank.err
+BATCH=6 CS=16,18,19,20 python tools/msm_sweep.py 16 18 20 22 24 > $O/r02_msm_sweep_plain.log 2>&1
+PRE=20,22 BATCH=6 python tools/msm_sweep.py 24 > $O/r02_msm_sweep_fixed_key.log 2>&1
+python tools/msm_sweep.py --g2 16 20 > $O/r02_msm_sweep_g2.log 2>&1
+./tools/mfma_mq 2 > $O/r02_mfma_mq_ubench.log 2>&1
+rm -rf $O/pf $O/pw $O/pf2 $O/pw2 $O/pf3 $O/pw3 $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6
 ls -la $O

@@ -16,5 +16,5 @@ for r in sel:
     e = (int(r["End_Timestamp"]) - base) / 1e6
     if e - s > 0.25:
         nm = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        nm = nm.replace("G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2LT<Fp28<BLS12_381_Fq28, BLS12_381_Fq>, false>, 255, 6>", "G2")
+        nm = nm.replace("G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2LT<Fp28<BLS12_381_Fq28, BLS12_381_Fq>, false>, 255, 6, 2>", "G2")
         print(f"{nm[:34]:34s} q={r['Queue_Id']:>2} {s:8.2f} -> {e:8.2f} ({e - s:6.2f})")
