@@ -17,6 +17,14 @@
 #include <vector>
 #include "zl_ctx.h"
 
+// first / last two-stage round fused with the global loads / stores (measured, 2^24: no gain over staging through LDS: the fused kernel needs
+// 145-158 VGPRs, one workgroup per CU, 3.0 ms; capped at 128 VGPRs it spills and ties with the unfused form at 2.6 ms)
+#ifndef ZL_NTT_FUSE_LOAD
+#define ZL_NTT_FUSE_LOAD 0
+#endif
+#ifndef ZL_NTT_FUSE_STORE
+#define ZL_NTT_FUSE_STORE 0
+#endif
 #define NTT_THREADS 512
 #define NTT_TILE 2048   // elements per workgroup tile (64 KiB of LDS)
 #define NTT_MAX_S 10
@@ -60,7 +68,7 @@ __device__ __forceinline__ F twiddle2(const F* lo, const F* hi, uint32_t L, uint
 }
 
 template <class FrP, bool LAST>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
+__global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_pass(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
     using F = Fp<FrP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                       // [8][NTT_TILE]
@@ -127,10 +135,9 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const Fp<FrP>* __restr
         }
     }
     __syncthreads();
-    // ---- load (+ Montgomery entry, coset scaling, inter-factor twiddle) ------------------------------------
-    for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
-        uint32_t r, col;
-        if (LAST && a.P > 1) { r = idx & (R - 1); col = idx >> s; } else { col = idx & (C - 1); r = idx >> logC; }
+    // ---- element access: load = global read + Montgomery entry / coset scaling / inter-factor twiddle; store = output row k of the tile
+    //      (+ coset / n^-1 scaling and Montgomery exit on the last pass) ----------------------------------------------------------
+    auto load_elem = [&](uint32_t r, uint32_t col) -> F {
         const uint64_t m = in_base + (uint64_t)r * in_row + (uint64_t)col * in_col;
         F x = in[m];
         if (a.p == 1) {
@@ -141,30 +148,9 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const Fp<FrP>* __restr
         } else {
             x = zl::mul(x, twiddle2(t_lo, t_hi, a.L, (uint64_t)r * (K0 + col)));
         }
-        lds_store(sh, tile_pos(r, col, logC), x);
-    }
-    __syncthreads();
-    // ---- 2^s-point DIF butterflies in LDS (all C columns) --------------------------------------------------
-    for (uint32_t hl = s; hl-- > 0;) {
-        const uint32_t h = 1u << hl;
-        for (uint32_t q = tid; q < (R >> 1) * C; q += NTT_THREADS) {
-            const uint32_t col = q & (C - 1), rr = q >> logC;
-            const uint32_t k = rr & (h - 1), blk = rr >> hl;
-            const uint32_t i = (blk << (hl + 1)) | k;
-            const uint32_t pu = tile_pos(i, col, logC), pv = tile_pos(i + h, col, logC);
-            const F u = lds_load<F>(sh, pu), v = lds_load<F>(sh, pv);
-            lds_store(sh, pu, zl::add(u, v));
-            F d = zl::sub(u, v);
-            if (k != 0) d = zl::mul(d, sh_w[k << (s - 1 - hl)]);
-            lds_store(sh, pv, d);
-        }
-        __syncthreads();
-    }
-    // ---- store: output row k sits at LDS row bitrev(k) ------------------------------------------------------
-    for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
-        const uint32_t col = idx & (C - 1), k = idx >> logC;
-        const uint32_t row = s ? (__brev(k) >> (32 - s)) : 0;
-        F x = lds_load<F>(sh, tile_pos(row, col, logC));
+        return x;
+    };
+    auto store_elem = [&](uint32_t k, uint32_t col, F x) {
         const uint64_t m = out_base + (uint64_t)k * out_row + col;
         if (LAST) {
             if (a.post_coset) {
@@ -178,6 +164,99 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const Fp<FrP>* __restr
             if (a.from_mont) x = zl::from_mont(x);
         }
         out[m] = x;
+    };
+    // two DIF stages on four rows of one column held in registers: stage (distance h) on the pairs (x0, x2), (x1, x3), then stage
+    // (distance h2 = h / 2) on (., .) -- rows i0, i0 + h2, i0 + h, i0 + h + h2 with i0 = (blk << (hl + 2)) | k2
+    auto quad = [&](F& x0, F& x1, F& x2, F& x3, uint32_t k2, uint32_t hl) {
+        const uint32_t h2 = 1u << hl, sh1 = s - 2 - hl;  // stage hl + 1: twiddle index k << (s - 2 - hl); stage hl: k << (s - 1 - hl)
+        const F a0 = zl::add(x0, x2), a1 = zl::add(x1, x3);
+        F a2 = zl::sub(x0, x2);
+        if (k2 != 0) a2 = zl::mul(a2, sh_w[k2 << sh1]);
+        const F a3 = zl::mul(zl::sub(x1, x3), sh_w[(k2 + h2) << sh1]);
+        x0 = zl::add(a0, a1);
+        x2 = zl::add(a2, a3);
+        x1 = zl::sub(a0, a1);
+        x3 = zl::sub(a2, a3);
+        if (k2 != 0) {
+            const F w = sh_w[k2 << (sh1 + 1)];
+            x1 = zl::mul(x1, w);
+            x3 = zl::mul(x3, w);
+        }
+    };
+    // ---- 2^s-point DIF butterflies (all C columns), two stages per round; the first round takes its rows straight from global memory, the
+    //      last one (even s >= 4) writes straight to global memory: three LDS round trips and three barriers per pass at s = 8 instead of
+    //      ten / nine with one stage per round trip.  (Radix-4 by register blocking only: w_4 is an ordinary field multiplication.)
+    const bool fuse_store = ZL_NTT_FUSE_STORE && (s & 1u) == 0 && s >= 4;
+    uint32_t hl = s;
+    if (ZL_NTT_FUSE_LOAD && s >= 2) {
+        hl -= 2;
+        const uint32_t h2 = 1u << hl;  // R / 4
+        for (uint32_t q = tid; q < (R >> 2) * C; q += NTT_THREADS) {
+            uint32_t k2, col;
+            if (LAST && a.P > 1) { k2 = q & (h2 - 1); col = q >> hl; } else { col = q & (C - 1); k2 = q >> logC; }  // consecutive lanes: contiguous memory
+            F x0 = load_elem(k2, col), x1 = load_elem(k2 + h2, col), x2 = load_elem(k2 + 2 * h2, col), x3 = load_elem(k2 + 3 * h2, col);
+            quad(x0, x1, x2, x3, k2, hl);
+            lds_store(sh, tile_pos(k2, col, logC), x0);
+            lds_store(sh, tile_pos(k2 + h2, col, logC), x1);
+            lds_store(sh, tile_pos(k2 + 2 * h2, col, logC), x2);
+            lds_store(sh, tile_pos(k2 + 3 * h2, col, logC), x3);
+        }
+    } else {
+        for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
+            const uint32_t col = idx & (C - 1), r = idx >> logC;
+            lds_store(sh, tile_pos(r, col, logC), load_elem(r, col));
+        }
+    }
+    __syncthreads();
+    while (hl >= (fuse_store ? 4u : 2u)) {
+        hl -= 2;
+        const uint32_t h2 = 1u << hl, h = h2 << 1;
+        for (uint32_t q = tid; q < (R >> 2) * C; q += NTT_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t k2 = rr & (h2 - 1), blk = rr >> hl;
+            const uint32_t i0 = (blk << (hl + 2)) | k2;
+            const uint32_t p0 = tile_pos(i0, col, logC), p1 = tile_pos(i0 + h2, col, logC), p2 = tile_pos(i0 + h, col, logC),
+                           p3 = tile_pos(i0 + h + h2, col, logC);
+            F x0 = lds_load<F>(sh, p0), x1 = lds_load<F>(sh, p1), x2 = lds_load<F>(sh, p2), x3 = lds_load<F>(sh, p3);
+            quad(x0, x1, x2, x3, k2, hl);
+            lds_store(sh, p0, x0);
+            lds_store(sh, p1, x1);
+            lds_store(sh, p2, x2);
+            lds_store(sh, p3, x3);
+        }
+        __syncthreads();
+    }
+    if (fuse_store) {
+        // last round (distances 2 and 1) from LDS, results straight to global memory: row i0 + j of the tile is output index bitrev_s(i0 + j)
+        for (uint32_t q = tid; q < (R >> 2) * C; q += NTT_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t i0 = rr << 2;
+            F x0 = lds_load<F>(sh, tile_pos(i0, col, logC)), x1 = lds_load<F>(sh, tile_pos(i0 + 1, col, logC)),
+              x2 = lds_load<F>(sh, tile_pos(i0 + 2, col, logC)), x3 = lds_load<F>(sh, tile_pos(i0 + 3, col, logC));
+            quad(x0, x1, x2, x3, 0u, 0u);
+            store_elem(__brev(i0) >> (32 - s), col, x0);
+            store_elem(__brev(i0 + 1) >> (32 - s), col, x1);
+            store_elem(__brev(i0 + 2) >> (32 - s), col, x2);
+            store_elem(__brev(i0 + 3) >> (32 - s), col, x3);
+        }
+        return;
+    }
+    if (hl == 1) {  // odd s: the last stage (distance 1) on its own
+        for (uint32_t q = tid; q < (R >> 1) * C; q += NTT_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t i = rr << 1;
+            const uint32_t pu = tile_pos(i, col, logC), pv = tile_pos(i + 1, col, logC);
+            const F u = lds_load<F>(sh, pu), v = lds_load<F>(sh, pv);
+            lds_store(sh, pu, zl::add(u, v));
+            lds_store(sh, pv, zl::sub(u, v));
+        }
+        __syncthreads();
+    }
+    // ---- store: output row k sits at LDS row bitrev(k) ------------------------------------------------------
+    for (uint32_t idx = tid; idx < R * C; idx += NTT_THREADS) {
+        const uint32_t col = idx & (C - 1), k = idx >> logC;
+        const uint32_t row = s ? (__brev(k) >> (32 - s)) : 0;
+        store_elem(k, col, lds_load<F>(sh, tile_pos(row, col, logC)));
     }
 }
 
@@ -208,11 +287,15 @@ static NttPlan ntt_plan(unsigned n) {
     uint32_t P = (n + 7) / 8;
     if (P > 4) P = 4;
     pl.P = P;
-    uint32_t rem = n;
-    for (uint32_t p = 0; p < P; p++) {
-        uint32_t s = (rem + (P - p) - 1) / (P - p);
-        pl.sizes[p] = s;
-        rem -= s;
+    // even factor sizes where possible (every pass then runs whole two-stage rounds, first and last fused with the global accesses):
+    // start from the largest even size <= n / P and hand the remainder out in steps of two, a final odd bit to the last factor
+    uint32_t base = (n / P) & ~1u, rem = n - base * P;
+    for (uint32_t p = 0; p < P; p++) pl.sizes[p] = base;
+    for (uint32_t p = 0; p < P && rem >= 2 && pl.sizes[p] + 2 <= NTT_MAX_S; p++) { pl.sizes[p] += 2; rem -= 2; }
+    for (uint32_t p = P; p-- > 0 && rem > 0;) {
+        const uint32_t room = NTT_MAX_S - pl.sizes[p], add = rem < room ? rem : room;
+        pl.sizes[p] += add;
+        rem -= add;
     }
     return pl;
 }
