@@ -164,6 +164,18 @@ public:
             if (zl::mul(eval(A_[i]), eval(B_[i])) != eval(C_[i])) return false;
         return true;
     }
+    // Repeated sub-circuits (a hash chain, a Merkle path, ...): append `copies` copies of the constraint rows [r0, r1); in copy j = 1..copies
+    // every witness index >= w_from is shifted by j * shift, all other variables (instance block, earlier witnesses) stay.  The caller
+    // supplies the values of the copies' witnesses (copies * shift of them, in allocation order).  This is exactly what synthesising the
+    // sub-circuit `copies` more times would append when it is wired the same way each time -- without redoing the symbolic
+    // linear-combination arithmetic (tests/test_host_mirror.py compares the result with the sequential Python builder).
+    void replicate_rows(size_t r0, size_t r1, size_t copies, uint32_t w_from, uint32_t shift, const std::vector<F>& new_witness_values);
+    static LC shifted(const LC& lc, uint32_t w_from, uint32_t delta) {
+        LC r = lc;
+        for (auto& t : r.terms)
+            if ((t.first & kWitnessBit) && (t.first & ~kWitnessBit) >= w_from) t.first += delta;  // order of the sorted keys is preserved
+        return r;
+    }
     uint32_t var_index(uint32_t key) const { return (key & kWitnessBit) ? (uint32_t)instance_.size() + (key & ~kWitnessBit) : key; }
     const std::vector<LC>& rows(int m) const { return m == 0 ? A_ : m == 1 ? B_ : C_; }
     const std::vector<F>& instance_assignment() const { return instance_; }
@@ -253,6 +265,29 @@ void permute_native(const Constants<FrP>& c, Fp<FrP> state[3]) {
         for (int i = 0; i < lanes; i++) {
             F x2 = zl::sqr(state[i]), x4 = zl::sqr(x2);
             state[i] = zl::mul(x4, state[i]);
+        }
+        F nx[3];
+        for (int i = 0; i < 3; i++) {
+            F acc = zl::mul(c.mds[i][0], state[0]);
+            acc = zl::add(acc, zl::mul(c.mds[i][1], state[1]));
+            nx[i] = zl::add(acc, zl::mul(c.mds[i][2], state[2]));
+        }
+        for (int i = 0; i < 3; i++) state[i] = nx[i];
+    }
+}
+// the same permutation, recording what the in-circuit version allocates: x^2, x^4, x^5 of every S-box whose input is not a constant
+// (lane 0 of the first round is: the capacity element 2^arity - 1 plus a round key), in allocation order
+template <class FrP>
+void permute_native_record(const Constants<FrP>& c, Fp<FrP> state[3], std::vector<Fp<FrP>>& rec) {
+    using F = Fp<FrP>;
+    const int half = c.FULL_ROUNDS / 2;
+    for (int rnd = 0; rnd < c.FULL_ROUNDS + c.PARTIAL_ROUNDS; rnd++) {
+        for (int i = 0; i < 3; i++) state[i] = zl::add(state[i], c.round_keys[3 * rnd + i]);
+        const int lanes = (rnd < half || rnd >= half + c.PARTIAL_ROUNDS) ? 3 : 1;
+        for (int i = 0; i < lanes; i++) {
+            const F x2 = zl::sqr(state[i]), x4 = zl::sqr(x2);
+            state[i] = zl::mul(x4, state[i]);
+            if (rnd != 0 || i != 0) { rec.push_back(x2); rec.push_back(x4); rec.push_back(state[i]); }
         }
         F nx[3];
         for (int i = 0; i < 3; i++) {

@@ -2,7 +2,9 @@
 // "host mirror" section).  Host code only; compiled by hipcc because it shares zl_field.h with the kernels.
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <thread>
 #include "zl_host.h"
@@ -36,6 +38,24 @@ template <class FrP>
 static Fp<FrP> pow_u64(const Fp<FrP>& a, uint64_t e) {
     const uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
     return zl::pow_words(a, w, 64);
+}
+
+template <class FrP>
+void R1CS<FrP>::replicate_rows(size_t r0, size_t r1, size_t copies, uint32_t w_from, uint32_t shift, const std::vector<F>& new_witness_values) {
+    const size_t rows = r1 - r0, base = A_.size();
+    witness_.insert(witness_.end(), new_witness_values.begin(), new_witness_values.end());
+    A_.resize(base + rows * copies);
+    B_.resize(base + rows * copies);
+    C_.resize(base + rows * copies);
+    parallel_chunks(rows * copies, 256, [&](size_t lo, size_t hi, size_t) {
+        for (size_t i = lo; i < hi; i++) {
+            const size_t j = i / rows + 1, r = r0 + i % rows;
+            const uint32_t delta = (uint32_t)(j * shift);
+            A_[base + i] = shifted(A_[r], w_from, delta);
+            B_[base + i] = shifted(B_[r], w_from, delta);
+            C_[base + i] = shifted(C_[r], w_from, delta);
+        }
+    });
 }
 
 template <class FrP>
@@ -386,7 +406,33 @@ static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<Fr
     FpVar<FrP> a = cs.new_witness(zl::to_mont(x0_canon));
     FpVar<FrP> b = cs.new_witness(x1);
     FpVar<FrP> cur = a;
-    for (uint32_t j = 0; j < k; j++) cur = poseidon::hash(consts, cur, b, cs);
+    // Links 1 and 2 are synthesised symbolically (link 1 takes a plain variable, every later link the previous link's output combination);
+    // links 3.. are copies of link 2's constraints with the witness indices shifted by one link each, their witness values recomputed
+    // natively.  Same circuit as k symbolic syntheses (the linear-combination arithmetic of a link is ~10^4 field multiplications and
+    // was 2.5 s of host time at k = 4096).
+    const uint32_t sym = k < 2 ? k : 2;
+    size_t rows0 = 0, wit0 = 0;
+    F hv = zl::to_mont(x0_canon);
+    for (uint32_t j = 0; j < sym; j++) {
+        rows0 = cs.constraint_count();
+        wit0 = cs.secret_variable_count();
+        cur = poseidon::hash(consts, cur, b, cs);
+        hv = cur.value;
+    }
+    if (k > sym) {
+        const size_t rows1 = cs.constraint_count(), per_link = cs.secret_variable_count() - wit0, copies = k - sym;
+        std::vector<F> vals;
+        vals.reserve(per_link * copies);
+        for (size_t j = 0; j < copies; j++) {
+            F st[3] = {zl::from_u64<FrP>(3), hv, x1};
+            poseidon::permute_native_record(consts, st, vals);
+            hv = st[0];
+        }
+        // every witness of links 1 and 2 (index >= 2: after x0, x1) moves with the copy; the instance block, x0 and x1 stay
+        cs.replicate_rows(rows0, rows1, copies, 2, (uint32_t)per_link, vals);
+        cur.lc = R1CS<FrP>::shifted(cur.lc, 2, (uint32_t)(copies * per_link));
+        cur.value = hv;
+    }
     cs.enforce_equal(cur, out_pub);
     return cs;
 }
@@ -421,8 +467,13 @@ int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, 
     if (curve == ZL_BLS12_381) {
         Fp<BLS12_381_Fr> a, b;
         memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
+        const auto t0 = std::chrono::steady_clock::now();
         c->bls = new R1CS<BLS12_381_Fr>(poseidon_chain<BLS12_381_Fr>(k, a, b));
+        const auto t1 = std::chrono::steady_clock::now();
         c->ex_bls.build(*c->bls);
+        if (getenv("ZL_DEBUG_TIMING"))
+            fprintf(stderr, "[zl] poseidon_chain %.3f s, export %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     } else {
         Fp<BN254_Fr> a, b;
         memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);

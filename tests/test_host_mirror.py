@@ -28,7 +28,7 @@ def test_native_poseidon_bn254_matches_python_model():
 
 
 @pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 2, 3, 6])
 def test_r1cs_compiler_builds_the_same_circuit_as_the_python_builder(curve, k):
     c = Circuit(curve.cid, k)
     cs = po.poseidon_chain_circuit(curve.fr, k)
