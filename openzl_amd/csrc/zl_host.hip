@@ -21,8 +21,9 @@ static void to_canon_words(uint64_t* out, const Fp<FrP>& mont) {
 // fn(lo, hi, chunk) over [0, n) on up to 64 host threads (the setup path is O(constraints) field work: Lagrange coefficients, the
 // transposed sparse products, exponent vectors; single-threaded it cost 3 s of a 4 s compile at 10^6 constraints)
 template <class Fn>
-static void parallel_chunks(size_t n, size_t min_chunk, Fn fn) {
-    size_t nt = std::min<size_t>(std::max<unsigned>(1u, std::thread::hardware_concurrency()), 64);
+static void parallel_chunks(size_t n, size_t min_chunk, Fn fn, size_t max_threads = 64) {
+    if (const char* e = getenv("ZL_HOST_THREADS")) max_threads = std::max(1, atoi(e));
+    size_t nt = std::min<size_t>(std::max<unsigned>(1u, std::thread::hardware_concurrency()), max_threads);
     nt = std::min(nt, std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
     if (nt <= 1) { fn((size_t)0, n, (size_t)0); return; }
     const size_t per = (n + nt - 1) / nt;
@@ -55,7 +56,7 @@ void R1CS<FrP>::replicate_rows(size_t r0, size_t r1, size_t copies, uint32_t w_f
             B_[base + i] = shifted(B_[r], w_from, delta);
             C_[base + i] = shifted(C_[r], w_from, delta);
         }
-    });
+    }, 16);  // millions of small allocations: beyond ~16 threads the page-fault / allocator contention costs more than it buys (measured: 0.7 s at 16, 2.2 s at 64)
 }
 
 template <class FrP>
@@ -411,6 +412,7 @@ static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<Fr
     // natively.  Same circuit as k symbolic syntheses (the linear-combination arithmetic of a link is ~10^4 field multiplications and
     // was 2.5 s of host time at k = 4096).
     const uint32_t sym = k < 2 ? k : 2;
+    const auto t0 = std::chrono::steady_clock::now();
     size_t rows0 = 0, wit0 = 0;
     F hv = zl::to_mont(x0_canon);
     for (uint32_t j = 0; j < sym; j++) {
@@ -419,6 +421,8 @@ static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<Fr
         cur = poseidon::hash(consts, cur, b, cs);
         hv = cur.value;
     }
+    const auto tA = std::chrono::steady_clock::now();
+    if (getenv("ZL_DEBUG_TIMING")) fprintf(stderr, "[zl] chain: native chain + 2 symbolic links %.3f s\n", std::chrono::duration<double>(tA - t0).count());
     if (k > sym) {
         const size_t rows1 = cs.constraint_count(), per_link = cs.secret_variable_count() - wit0, copies = k - sym;
         std::vector<F> vals;
@@ -428,8 +432,12 @@ static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<Fr
             poseidon::permute_native_record(consts, st, vals);
             hv = st[0];
         }
+        const auto tB = std::chrono::steady_clock::now();
         // every witness of links 1 and 2 (index >= 2: after x0, x1) moves with the copy; the instance block, x0 and x1 stay
         cs.replicate_rows(rows0, rows1, copies, 2, (uint32_t)per_link, vals);
+        if (getenv("ZL_DEBUG_TIMING"))
+            fprintf(stderr, "[zl] chain: native values %.3f s, replicate %.3f s\n", std::chrono::duration<double>(tB - tA).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count());
         cur.lc = R1CS<FrP>::shifted(cur.lc, 2, (uint32_t)(copies * per_link));
         cur.value = hv;
     }
