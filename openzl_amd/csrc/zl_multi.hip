@@ -11,6 +11,7 @@
 // the data movement pattern are identical, which is how the entry points are tested on a 1-GPU box.  openzl_amd/sharded.py keeps the
 // one-process-per-GPU variant over torch.distributed for callers that already live in that world (bench.py --gpus N).
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -103,7 +104,9 @@ int zl_ctx_create_multi(zl_mctx** out, const int* device_ids, int n_devices) {
     bool distinct = true;
     for (int a = 0; a < n_devices; a++)
         for (int b = a + 1; b < n_devices; b++) distinct = distinct && device_ids[a] != device_ids[b];
-    if (!rc && distinct && n_devices > 1) {
+    // ZL_FORCE_RCCL: also open a (one-rank) communicator for a single device, so that the RCCL branch -- dlopen, ncclCommInitAll, grouped
+    // ncclAllGather -- can at least be smoke-tested on a 1-GPU box
+    if (!rc && distinct && (n_devices > 1 || getenv("ZL_FORCE_RCCL"))) {
         // real multi-GPU: one communicator per device, created together (ncclCommInitAll = the single-process form of ncclCommInitRank)
         if (!m->rccl.load()) rc = ZL_ENODEV;
         if (!rc) {

@@ -97,3 +97,27 @@ def test_multi_argument_errors():
             mb.ntt_sharded(po.BLS12_381.cid, [1, 1, 1], 12)
     finally:
         mb.close()
+
+
+def test_msm_sharded_single_rank_through_rccl(monkeypatch):
+    """The RCCL branch of zl_msm_sharded (dlopen of librccl, ncclCommInitAll, grouped ncclAllGather of the partial sums) with a ONE-rank
+    communicator: the only form of it a 1-GPU box can run.  Multi-rank RCCL runs only on the driver's multi-GPU node."""
+    import torch
+
+    monkeypatch.setenv("ZL_FORCE_RCCL", "1")
+    curve = po.BLS12_381
+    n = 2000
+    mb = MultiBackend([0])
+    try:
+        assert mb.size == 1 and mb.uses_rccl
+        k = ol.random_scalars(curve, n, 7300)
+        S = ol.random_scalars(curve, n, 7301)
+        h = mb.ranks[0].bases_generate(curve.cid, k)
+        d = torch.from_numpy(S.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        got, inf = mb.msm_sharded([h], [d.data_ptr()], [n])
+        dot = sum(a * b for a, b in zip(ol.limbs_to_ints(k), ol.limbs_to_ints(S))) % curve.fr.p
+        assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
+        mb.ranks[0].bases_free(h)
+    finally:
+        mb.close()
