@@ -55,6 +55,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     for (auto& kv : ctx->bases) {
         if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
+        if (kv.second.d_inf) (void)hipFree(kv.second.d_inf);
     }
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
@@ -171,6 +172,7 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_pts) (void)hipFree(it->second.d_pts);
     if (it->second.d_table) (void)hipFree(it->second.d_table);
+    if (it->second.d_inf) (void)hipFree(it->second.d_inf);
     ctx->bases.erase(it);
     return ZL_OK;
 }

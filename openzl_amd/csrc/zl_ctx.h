@@ -70,6 +70,8 @@ struct zl_bases {
     void* d_pts = nullptr;  // Affine<F>[n], Montgomery
     void* d_table = nullptr;  // optional Affine<F>[W][n]: 2^(c w) P_i (zl_bases_precompute)
     int precomp_c = 0;
+    void* d_inf = nullptr;   // optional uint8[n]: 1 = the point at infinity (present only when the handle holds at least one)
+    size_t n_inf = 0;
     size_t n = 0;
     int curve = 0, group = 0;
     mutable std::vector<uint64_t> first_xy;  // canonical affine words of point 0, fetched once (Groth16: the z_0 = 1 term of a / b queries)

@@ -76,9 +76,9 @@ __device__ __forceinline__ bool zl_take_one(const uint32_t* s, uint32_t i, uint3
 template <int MODE>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ counters, uint32_t* __restrict__ entries,
-                                                    uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+                                                    uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
+    const bool live = i < n && !(inf && inf[i]);
     const uint32_t* s = scalars + (size_t)(live ? i : 0) * 8;
     uint32_t sv[8];
     for (int k = 0; k < 8; k++) sv[k] = live ? s[k] : 0u;
@@ -110,13 +110,13 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 // k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
 static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits,
-                                                             uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+                                                             uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
     ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
     uint4 lo = sp[0], hi = sp[1];
-    if (!live) lo = hi = make_uint4(0, 0, 0, 0);
+    if (!live || (inf && inf[i])) lo = hi = make_uint4(0, 0, 0, 0);  // a base at infinity contributes nothing: its scalar is dropped here
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;  // listed: contributes no digits
     if (!live) return;
@@ -219,13 +219,13 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 // (low bits of the point index) << spread_t | (magnitude - 1); the reduction weights those buckets by their low spread_t bits only.
 static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint32_t gw, int spread_t,
                                                                   uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
-                                                                  uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count) {
+                                                                  uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
     ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
     uint4 lo = sp[0], hi = sp[1];
-    if (!live) lo = hi = make_uint4(0, 0, 0, 0);
+    if (!live || (inf && inf[i])) lo = hi = make_uint4(0, 0, 0, 0);  // a base at infinity contributes nothing
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;
     if (!live) return;
@@ -994,6 +994,16 @@ __global__ void __launch_bounds__(128) k_bases_import(const uint32_t* __restrict
     }
     out[i] = p;
 }
+// flags[i] = 1 if bases[i] is the point at infinity; *count = how many (Groth16 query vectors hold many: a variable that appears in no row
+// of B has b_query[i] = 0 * G).  The recoder drops their scalars, so they cost neither a sort entry nor a (divergent, idle) accumulation step.
+template <class G>
+__global__ void __launch_bounds__(256) k_bases_inf_flags(const Affine<typename G::F>* __restrict__ in, uint32_t n, uint8_t* __restrict__ flags, uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inf = i < n && in[i].is_inf();
+    if (i < n) flags[i] = inf ? 1 : 0;
+    const uint64_t m = __ballot(inf);
+    if (m && (threadIdx.x & 63u) == 0) atomicAdd(count, (uint32_t)__popcll(m));
+}
 // out[i] = canonical affine x||y of bases[i]
 template <class G>
 __global__ void __launch_bounds__(128) k_bases_export(const Affine<typename G::F>* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
@@ -1189,6 +1199,7 @@ struct MsmJob {
     unsigned long long* d_bigsg_head = nullptr;
     X *d_buckets = nullptr, *d_partials = nullptr, *d_segs = nullptr, *d_stage1 = nullptr, *d_sets = nullptr, *d_ones_parts = nullptr, *d_giant_tmp = nullptr;
     const Affine<F>* d_bases = nullptr;
+    const uint8_t* d_inf = nullptr;  // per-base infinity flags of the range (null: the handle has no point at infinity)
     const uint32_t* sc = nullptr;
     // host results (pinned when pipelined)
     X* hw = nullptr;
@@ -1244,6 +1255,7 @@ struct MsmJob {
         max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
         max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
+        d_inf = bs.d_inf ? reinterpret_cast<const uint8_t*>(bs.d_inf) + first : nullptr;
         sc = reinterpret_cast<const uint32_t*>(d_scalars);
         hw_own.assign((size_t)SETS * roots_per_set + 1, X::inf());
         hw = hw_own.data();
@@ -1346,7 +1358,7 @@ struct MsmJob {
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count);
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count, d_inf);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
@@ -1400,7 +1412,7 @@ struct MsmJob {
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count);
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count, d_inf);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
@@ -1414,11 +1426,11 @@ struct MsmJob {
             hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {
             // wide windows without a table: histogram / scatter with global atomics
-            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count);
+            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count);
+            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count, d_inf);
         }
         ZL_HIP(ctx, hipGetLastError());
         return ZL_OK;
@@ -1654,6 +1666,30 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     return ZL_OK;
 }
 
+// attach the infinity flags to a freshly built handle (kept only when there is at least one point at infinity)
+template <class G>
+static int bases_flag_inf_t(zl_ctx* ctx, zl_bases* b) {
+    using F = typename G::F;
+    if (!b->n) return ZL_OK;
+    void* d = nullptr;
+    ZL_HIP(ctx, hipMalloc(&d, b->n + 16));
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(d) + ((b->n + 3) / 4) * 4);
+    hipStream_t st = ctx->stream;
+    uint32_t cnt = 0;
+    hipError_t e = hipMemsetAsync(d_cnt, 0, 4, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_bases_inf_flags<G>), dim3((uint32_t)((b->n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const Affine<F>*>(b->d_pts), (uint32_t)b->n,
+                           reinterpret_cast<uint8_t*>(d), d_cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(d); return ZL_EHIP; }
+    if (cnt == 0) { (void)hipFree(d); return ZL_OK; }
+    b->d_inf = d;
+    b->n_inf = cnt;
+    return ZL_OK;
+}
 // in (XYZZ / Jacobian, n elements) -> out (affine), sharing one inversion among the elements of a lane; prefix scratch in slot `slot`
 template <class G, int FORM>
 static int batch_affine_t(zl_ctx* ctx, const void* d_in, size_t n, Affine<typename G::F>* d_out, int slot, hipStream_t st) {
@@ -1848,6 +1884,7 @@ static int bases_upload_t(zl_ctx* ctx, const void* xy, size_t n, size_t stride, 
     }
     out->d_pts = d_pts;
     out->n = n;
+    if ((rc = bases_flag_inf_t<G>(ctx, out))) { (void)hipFree(d_pts); out->d_pts = nullptr; return rc; }
     return ZL_OK;
 }
 int ZL_GNAME(zl_bases_upload)(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out) {
@@ -1879,6 +1916,10 @@ static int bases_generate_t(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* 
     }
     out->d_pts = d_pts;
     out->n = n;
+    {
+        const int rc2 = bases_flag_inf_t<G>(ctx, out);  // k_i = 0 (mod r) gives the point at infinity
+        if (rc2) { (void)hipFree(d_pts); out->d_pts = nullptr; return rc2; }
+    }
     return ZL_OK;
 }
 int ZL_GNAME(zl_bases_generate)(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out) {
