@@ -72,3 +72,19 @@ def test_partials_sum_host_tail_matches_oracle(curve):
     assert inf == 1 and not xy.any()
     xy, inf = fold_partials(curve.cid, parts[:0])
     assert inf == 1
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/*.h must compile as strict C99 (no C++-isms outside the extern "C" guards), and a C program
+    must link against the library with nothing but -lzl_backend."""
+    import subprocess
+
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "zl_backend.h"\n#include "zl_backend_test.h"\n'
+                   "int main(void) { zl_ctx* c = 0; zl_mctx* m = 0; zl_timing t; (void)c; (void)m; (void)t;\n"
+                   "  return zl_strerror(ZL_OK) == 0; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "hdr.o")])
+    libdir = os.path.join(ROOT, "openzl_amd")
+    subprocess.check_call(["gcc", str(tmp_path / "hdr.o"), "-L", libdir, "-l:libzl_backend.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined",
+                           "-o", str(tmp_path / "hdr")])

@@ -4,7 +4,13 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bench import random_scalars_lt_r
-from openzl_amd import Backend, ZL_BLS12_381, ZL_G2
+from openzl_amd import Backend, ZL_BLS12_381, ZL_BN254, ZL_G2
+
+if os.environ.get("CURVE", "bls12_381") == "bn254":  # CURVE=bn254: the 8-limb field (32-bit carry-chain multiplier)
+    ZL_BLS12_381 = ZL_BN254
+    R_BN = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    _rs = random_scalars_lt_r
+    random_scalars_lt_r = lambda n, seed: _rs(n, seed, R_BN, 254)  # noqa: E731
 
 be = Backend(0); be.enable_timing(True)
 dev = torch.device("cuda", 0)
