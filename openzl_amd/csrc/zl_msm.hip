@@ -1143,9 +1143,9 @@ static int zl_tune(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 static int zl_pick_window(size_t n, int sc_bits) {
-    // accumulate: n mixed adds per window; per-bucket overhead (merge of cut buckets + hierarchical reduce, measured at 2^24: ~7) in
+    // accumulate: n mixed adds per window; per-bucket overhead (merge of cut buckets + tree reduce, fitted at 2^24 on both curves: ~5) in
     // mixed-add equivalents.  c <= 16: one-level LDS counting sort; 17..20: the three-level sort over W bucket sets (tools/msm_sweep.py).
-    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 70) / 10.0;
+    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 50) / 10.0;
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 20; c++) {
