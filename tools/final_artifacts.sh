@@ -11,7 +11,8 @@ dbof() { find $1 -name "*.db" | head -1; }
 # ---- HBM traffic (PMC; separate passes per counter, as the guide prescribes) -------------------------------------------------------
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o f -f csv -- python tools/msm_one.py 24 0 -1 1 > $O/pmc_msm_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o w -f csv -- python tools/msm_one.py 24 0 -1 1 > $O/pmc_msm_write.log 2>&1
-python tools/pmc_fold.py msm $(csvof $O/pf) $(csvof $O/pw) 24 19 0 > $O/r02_pmc_traffic.json
+CW=$(grep -o "c=[0-9]*" $O/pmc_msm_fetch.log | tail -1 | cut -d= -f2)   # the window the library picked for the plain path
+python tools/pmc_fold.py msm $(csvof $O/pf) $(csvof $O/pw) 24 $CW 0 > $O/r02_pmc_traffic.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf2 -o f -f csv -- python tools/msm_one.py 24 0 22 1 > $O/pmc_msmt_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw2 -o w -f csv -- python tools/msm_one.py 24 0 22 1 > $O/pmc_msmt_write.log 2>&1
 python tools/pmc_fold.py msm $(csvof $O/pf2) $(csvof $O/pw2) 24 22 1 > $O/r02_pmc_traffic_fixed_key.json
