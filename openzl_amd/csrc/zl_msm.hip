@@ -1176,7 +1176,7 @@ static int zl_pick_window_precomp(size_t n, int sc_bits) {
 
 // One MSM as three phases that only communicate through device buffers, so that consecutive MSMs can be pipelined on three streams
 // (sort of MSM i+2 | bucket accumulation of MSM i+1 | merge / reduction tail of MSM i): plan() sizes everything, alloc() binds one of
-// two buffer sets, sort() builds the bucket-sorted entry list, accumulate() is the dominant kernel, tail() leaves SETS window sums
+// three buffer sets, sort() builds the bucket-sorted entry list, accumulate() is the dominant kernel, tail() leaves SETS window sums
 // (+ the sum of the scalar-1 bases) in host memory, finish() does the host Horner.
 template <class G>
 struct MsmJob {

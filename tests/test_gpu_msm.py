@@ -320,8 +320,8 @@ def test_config4_eight_shards_of_2_23(backend):
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("table", [False, True], ids=["plain", "table"])
 def test_msm_pipelined_batch_equals_single_calls(backend, curve, table):
-    """zl_msm_batch_partial_dev (three-stream pipeline over two buffer sets) against one zl_msm_partial_dev per scalar vector, and the
-    oracle for the first one; 5 MSMs so that both buffer sets are reused."""
+    """zl_msm_batch_partial_dev (three-stream pipeline over three rotating buffer sets) against one zl_msm_partial_dev per scalar vector, and the
+    oracle for the first one; 5 MSMs so that buffer sets are reused."""
     import torch
 
     n = 6000
