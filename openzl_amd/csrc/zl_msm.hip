@@ -4,19 +4,22 @@
 // /root/reference/plugins/arkworks/src/groth16.rs:454 through ark-groth16's create_proof).
 // arkworks walks the windows serially with unsigned c-bit digits and 2^c - 1 Jacobian buckets per window.  This
 // backend is organised for a 256-CU / wave64 machine instead:
-//   1. msm_recode     signed-digit recoding of every scalar, once (u16 per digit; 2^(c-1) buckets per window)
-//   2. msm_hist_lds   per-(slice, window) histograms in LDS (no global atomics), slice prefix, 3-kernel exclusive scan
-//   3. msm_scatter_range  counting-sort scatter of (point index, sign) entries: one block owns a bucket range of one
-//                    window (LDS cursors), streams that window's digits with 16-B loads
-//   4. msm_accumulate  the hot kernel: the sorted entry array is cut into fixed chunks of <= 64 entries, one lane per
-//                    chunk, XYZZ mixed additions in ONE flat loop; a bucket inside one chunk is written directly, buckets
-//                    cut by chunk boundaries leave <= 2 partial sums per lane -> perfect load balance whatever the scalar
-//                    distribution (Groth16 witnesses are full of 0/1)
-//   5. msm_merge      one lane per bucket folds the partials of cut buckets (block-wide tree for giant buckets)
-//   6. msm_reduce_seg / msm_window_sum   sum_k k*B_k per bucket set by segmented running sums + block trees
-//   7. host           Horner over the W window sums (a few hundred field ops), returned as an XYZZ partial
-// With zl_bases_precompute (table of 2^(c w) P_i, W x the memory) all windows share ONE bucket set, c grows to 22 (12
-// instead of 16 additions per point) and the sort becomes two-level (partition by bucket >> 15, then the LDS sort).
+//   1. recode         signed-digit recoding of every scalar, once (2^(c-1) buckets per window); scalars equal to 1 go to a compact list,
+//                     scalars of bases at infinity are dropped
+//   2. sort           (window, bucket) counting sort of (point index, sign) entries without global atomics on the streaming paths:
+//                     c <= 16: per-(slice, window) LDS histograms + range-owned scatter; c = 17..20 and the table mode: three levels --
+//                     64..208 groups -> 128 sub-groups of 256 buckets -> one LDS-staged sort per sub-group (oversized sub-groups in tiles)
+//   3. msm_accumulate the hot kernel: the sorted entry array is cut into fixed chunks of <= 128 entries, one lane per chunk, XYZZ mixed
+//                     additions in ONE flat loop; a bucket inside one chunk is written directly, buckets cut by chunk boundaries leave
+//                     <= 2 partial sums per lane -> perfect load balance whatever the scalar distribution (Groth16 witnesses are full
+//                     of 0/1)
+//   4. msm_merge      one lane per bucket folds the partials of cut buckets (block-wide tree for big / giant buckets)
+//   5. reduce         sum_k k*B_k per bucket set: running sums over blocks of 8 buckets, then a binary tree whose nodes carry per-bit channel
+//                     sums (one independent addition per lane and level, no scalar multiples)
+//   6. host           ONE Horner over the bit positions of the scalar absorbs the channel sums and the window weights (~500 group
+//                     operations), returned as an XYZZ partial
+// Plain calls pick c from n (19-20 bits at 2^24: 13-14 additions per point).  With zl_bases_precompute (table of 2^(c w) P_i, W x the
+// memory) all windows share ONE bucket set and c grows to 22 (12 additions per point).
 // The result does not depend on c, on the digit signs or on the order entries land in a bucket (group law).
 #include <stdlib.h>
 #include <string.h>
