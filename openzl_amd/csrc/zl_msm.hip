@@ -1146,16 +1146,17 @@ static int zl_tune(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 static int zl_pick_window(size_t n, int sc_bits) {
-    // accumulate: n mixed adds per window; per-bucket overhead (merge of cut buckets + tree reduce, fitted at 2^24 on both curves: ~5) in
-    // mixed-add equivalents.  c <= 16: one-level LDS counting sort; 17..20: the three-level sort over W bucket sets (tools/msm_sweep.py).
-    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 50) / 10.0;
+    // cost in accumulated entries: n per window (+10 % for c <= 16: the one-level LDS counting sort streams every window's digits once per
+    // bucket range and is the slower sort at large n) + ~5.7 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
+    // single-call times at 2^20 .. 2^24, both curves (profiles/r02_msm_sweep_plain.log, r02_msm_sweep_bn254.log): picks 16 up to 2^21,
+    // 18 at 2^22 - 2^23, 19 at 2^24.  c = 17..20 run the three-level sort over W bucket sets (<= 255 sort groups).
+    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 57) / 10.0;
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 20; c++) {
         int W = (sc_bits + 1 + c - 1) / c;
         if (c > 16 && (((uint64_t)W << (c - 1)) >> 15) > 255) continue;
-        double cost = (double)n * W + per_bucket * W * (double)(1u << (c - 1));
-        if (c > 16) cost += 0.04 * (double)n * W;  // the wider sort costs more per entry
+        double cost = (double)n * W * (c <= 16 ? 1.10 : 1.0) + per_bucket * W * (double)(1u << (c - 1));
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
