@@ -351,6 +351,7 @@ struct Result {
     Error error;
 };
 
+template <class FrP> struct R1csExport;
 template <class E>
 struct Groth16 {
     using FrP = typename E::FrP;
@@ -376,7 +377,9 @@ struct Groth16 {
 
     static Compiler context_compiler() { return Compiler::for_contexts(); }  // groth16.rs:418-420
     static Compiler proof_compiler() { return Compiler::for_proofs(); }      // groth16.rs:423-425
-    static Result<std::pair<ProvingContext, VerifyingContext>> compile(zl_ctx* ctx, const Compiler& compiler, SplitMix64& rng);
+    // `exported`: the CSR export of `compiler` when the caller already holds one (the C hooks do): saves rebuilding it for the matrix upload
+    static Result<std::pair<ProvingContext, VerifyingContext>> compile(zl_ctx* ctx, const Compiler& compiler, SplitMix64& rng,
+                                                                        const R1csExport<FrP>* exported = nullptr);
     static Result<Proof> prove(const ProvingContext& context, const Compiler& compiler, SplitMix64& rng, F* r_out = nullptr, F* s_out = nullptr);
     // verify (groth16.rs:459-466): e(A, B) == e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta); input = public inputs (canonical)
     static Result<bool> verify(const VerifyingContext& vk, const Input& input, const Proof& proof);

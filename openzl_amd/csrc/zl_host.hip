@@ -118,7 +118,7 @@ static Fp<FrP> sample_nonzero_mont(SplitMix64& rng, Fp<FrP>* canon_out) {
 // fixed-base part runs on the device (zl_bases_generate); the trapdoor stays in the ProvingContext for exponent checks.
 template <class E>
 Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::VerifyingContext>> Groth16<E>::compile(zl_ctx* ctx, const Compiler& cs,
-                                                                                                                  SplitMix64& rng) {
+                                                                                                                  SplitMix64& rng, const R1csExport<FrP>* exported) {
     Result<std::pair<ProvingContext, VerifyingContext>> res{false, {}, Error{ZL_EINVAL}};
     if (!ctx) return res;
     const size_t nc = cs.constraint_count(), ni = cs.num_instance_variables(), nw = cs.secret_variable_count(), nv = ni + nw;
@@ -142,6 +142,14 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         if (!zt.is_zero()) break;
     }
     // Lagrange coefficients L_j = Z(tau)/N * w^j / (tau - w^j), batch inversion
+    const bool dbg = getenv("ZL_DEBUG_TIMING") != nullptr;
+    auto tmark = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zl] compile: %-28s %.3f s\n", what, std::chrono::duration<double>(now - tmark).count());
+        tmark = now;
+    };
     std::vector<F> L(N), den(N), pref(N);
     {
         const F scale = zl::mul(zt, zl::inv(zl::from_u64<FrP>((uint64_t)N)));
@@ -163,6 +171,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
             }
         });
     }
+    lap("lagrange");
     std::vector<F> u(nv, F::zero()), v(nv, F::zero()), ww(nv, F::zero());
     for (size_t j = 0; j < ni; j++) u[j] = L[nc + j];
     {
@@ -197,6 +206,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         tb.join();
         tc.join();
     }
+    lap("transposed products");
     const F dinv = zl::inv(delta), ginv = zl::inv(gamma);
     // exponent vectors (canonical) for the device generator
     std::vector<uint64_t> ea(nv * 4), eb(nv * 4), eh((N - 1) * 4), el(std::max<size_t>(nw, 1) * 4), single(5 * 4);
@@ -215,6 +225,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         F tp = zl::mul(zl::mul(zt, dinv), pow_u64<FrP>(tau, (uint64_t)lo));
         for (size_t j = lo; j < hi; j++) { to_canon_words<FrP>(&eh[4 * j], tp); tp = zl::mul(tp, tau); }
     });
+    lap("exponent vectors");
     ProvingContext pc;
     pc.ctx = ctx;
     pc.trapdoor = td;
@@ -226,6 +237,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G2, eb.data(), nv, &pc.b_g2_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eh.data(), N - 1, &pc.h_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, el.data(), nw, &pc.l_query);
+    lap("device generation (5 queries)");
     // Window tables for the queries of a large proving key (static per circuit, like the key itself): the five MSMs of every proof then
     // run on one merged bucket set each.  Measured at N = 2^20 (958 465 constraints): prove 33.5 -> 29.2 ms with c = 20 for the G1
     // queries (13 windows) and c = 16 for the G2 query; c = 19 / 21 are worse (14 windows / twice the buckets for the same 13).
@@ -240,12 +252,14 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         for (const auto& e : q)
             if (!rc && e.n >= big) rc = zl_bases_precompute(ctx, e.h, e.c);
     }
+    lap("window tables");
     if (!rc) {
-        R1csExport<FrP> ex;
-        ex.build(cs);
-        rc = zl_r1cs_upload(ctx, E::curve, &ex.view, &pc.r1cs);
+        R1csExport<FrP> own;
+        if (!exported) own.build(cs);
+        rc = zl_r1cs_upload(ctx, E::curve, exported ? &exported->view : &own.view, &pc.r1cs);
         pc.n_constraints = nc;
     }
+    lap("r1cs export + upload");
     // alpha*G1, beta*G1, delta*G1, beta*G2, delta*G2
     const size_t q1 = 2 * E::G1::FQ64, q2 = 4 * E::G1::FQ64;
     pc.alpha_g1.resize(q1); pc.beta_g1.resize(q1); pc.delta_g1.resize(q1); pc.beta_g2.resize(q2); pc.delta_g2.resize(q2);
@@ -290,6 +304,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         if (!rc) rc = zl_bases_download(ctx, h, 0, ni, vk.gamma_abc_g1.data());
         if (h) (void)zl_bases_free(ctx, h);
     }
+    lap("single points + vk");
     if (rc) {
         release(pc);
         res.error = Error{rc};
@@ -535,14 +550,14 @@ int zl_groth16_compile(zl_ctx* ctx, const zl_circuit* c, uint64_t seed, zl_g16_k
     SplitMix64 rng(seed);
     int rc = ZL_OK;
     if (c->curve == ZL_BLS12_381) {
-        auto r = Groth16<Bls12_381>::compile(ctx, *c->bls, rng);
+        auto r = Groth16<Bls12_381>::compile(ctx, *c->bls, rng, &c->ex_bls);
         if (!r.ok) rc = r.error.code; else {
             k->pc_bls = r.value.first;
             k->vk_bls = r.value.second;
             for (auto& g : r.value.second.gamma_abc_exponents) { uint64_t w[4]; to_canon_words<BLS12_381_Fr>(w, g); k->gamma_abc.insert(k->gamma_abc.end(), w, w + 4); }
         }
     } else {
-        auto r = Groth16<Bn254>::compile(ctx, *c->bn, rng);
+        auto r = Groth16<Bn254>::compile(ctx, *c->bn, rng, &c->ex_bn);
         if (!r.ok) rc = r.error.code; else {
             k->pc_bn = r.value.first;
             k->vk_bn = r.value.second;
