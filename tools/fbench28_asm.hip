@@ -1,7 +1,6 @@
 // tools/fbench28_asm.hip -- experiment: compiler-scheduled vs single-chain inline-asm 14 x 28-bit Montgomery product scan (same harness as
 // fbench28.hip, constants from zl_params.h so that the scan can use literal / SGPR modulus limbs).
 #include "../openzl_amd/csrc/zl_field28.h"
-#include "mul28_asm.h"
 #include <stdio.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 using A = BLS12_381_Fq28;
@@ -11,8 +10,10 @@ __global__ void k_chain(F* a, const F* b, int iters) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     F x = a[i], y = b[i];
     for (int k = 0; k < iters; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the asm scan (openzl_amd/csrc/zl_mul28_gfx950.h, via zl_field28.h) exists in the device pass only
         if (MODE == 0) x = zl::mul_body28(x, y);
         else { F r = x; mul28_asm<A>(r.l, x.l, y.l); x = r; }
+#endif
     }
     a[i] = x;
 }
