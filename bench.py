@@ -353,6 +353,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    leg_errors = {}
+
+    def _guard(name, fn):
+        """A secondary leg must never cost the headline line: an unexpected exception there (allocation failure, a missing tool on the
+        box) is recorded in the JSON line instead.  Failed self-checks raise SystemExit and still abort the run; with N > 1 the legs
+        contain collectives, so an exception is fatal there as before."""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise
+            leg_errors[name] = f"{type(e).__name__}: {e}"
+            print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+
     # ---- correctness gate before timing: the exact configuration that is timed, at full size, both scalar vectors ----------------------
     for j in (0, 1):
         xy_j, inf_j = fold_partials(ZL_BLS12_381, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
@@ -409,7 +423,8 @@ def main():
 
     # ---- PCIe-inclusive rate (SURVEY.md §8d config 2's timed region: scalars from host memory + kernels + result; never `value`) ---------
     pcie_info = None
-    if rank == 0 and world == 1:
+    def _leg_pcie_info():
+        nonlocal pcie_info
         be.msm(h, s_host)  # warm-up: staging buffer
         ts = []
         for _ in range(3):
@@ -421,8 +436,12 @@ def main():
         pcie_info = {"ms_per_msm": float(np.min(ts)) * 1e3, "points_per_s": n / float(np.min(ts)),
                      "note": "zl_msm: scalars copied from pageable host memory (32 B/point over PCIe) + all kernels + result D2H, bases resident"}
 
+    if rank == 0 and world == 1:
+        _guard("pcie_info", _leg_pcie_info)
+
     skew_info = None
-    if rank == 0 and world == 1 and not args.no_skew:
+    def _leg_skew_info():
+        nonlocal skew_info
         # SURVEY.md §8d's non-uniform variant: Groth16-witness-like scalars (50 % zeros, 25 % ones, rest uniform), same bases
         s2 = skewed(s_host)
         d2 = torch.from_numpy(s2.view(np.int64)).to(dev)
@@ -444,9 +463,13 @@ def main():
                              "in two stages; exactness of these paths: tests/test_gpu_msm.py (skewed cases), tests/test_gpu_msm_fuzz.py"}
         del d2
 
+    if rank == 0 and world == 1 and not args.no_skew:
+        _guard("skew_info", _leg_skew_info)
+
     # ---- fixed-key mode, reported beside the headline: table of 2^(c w) P_i built once per key (a Groth16 proving key is static) -------
     fixed_info = None
-    if args.fixed_key >= 0 and rank == 0 and world == 1 and not args.window:
+    def _leg_fixed_info():
+        nonlocal fixed_info
         c_fk = args.fixed_key if args.log_n >= 24 else 0  # let the library pick c for small inputs
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -484,8 +507,12 @@ def main():
                     "bases (a Groth16 proving key).  Same exact full-size checks as the headline.  NOT `value`: multi_scalar_mul(bases, scalars) has no per-key state.",
         }
 
+    if args.fixed_key >= 0 and rank == 0 and world == 1 and not args.window:
+        _guard("fixed_info", _leg_fixed_info)
+
     ntt_info = None
-    if not args.no_ntt:
+    def _leg_ntt_info():
+        nonlocal ntt_info
         # second half of the metric.  N > 1: (i) independent replicas, one 2^log_n transform per GPU (Groth16's a/b/c pipelines
         # are independent transforms) -- every rank measures, rank 0 reports max-over-ranks; (ii) further down, ONE
         # 2^(log_n + log2 N) transform spread over all ranks with a single RCCL all-to-all (openzl_amd/sharded.py).
@@ -544,8 +571,12 @@ def main():
         }
         del dx
 
+    if not args.no_ntt:
+        _guard("ntt_info", _leg_ntt_info)
+
     g16_info = None
-    if args.groth16_k > 0 and rank == 0 and world == 1:
+    def _leg_g16_info():
+        nonlocal g16_info
         # config 5: Groth16 prove of the Poseidon-hash chain circuit through the C++ host mirror (Groth16<E>::compile /
         # prove, csrc/zl_host.h): matrices + proving key device-resident, only the assignment travels per proof.
         from openzl_amd import Circuit, Groth16Keys
@@ -613,9 +644,16 @@ def main():
             c2.close()
         g16_info["small_circuits"] = small
 
+    if args.groth16_k > 0 and rank == 0 and world == 1:
+        _guard("g16_info", _leg_g16_info)
+
     cpu = None
-    if not args.no_cpu and rank == 0 and world == 1:
+    def _leg_cpu():
+        nonlocal cpu
         cpu = cpu_baseline(be, h, k64, s_host, exp_xy[0], args.cpu_threads, args.log_n)
+
+    if not args.no_cpu and rank == 0 and world == 1:
+        _guard("cpu", _leg_cpu)
 
     if rank == 0:
         pts = float(n) * world * args.steps
@@ -675,6 +713,8 @@ def main():
             "ntt": ntt_info,
             "groth16": g16_info,
         }
+        if leg_errors:
+            line["leg_errors"] = leg_errors
     else:
         line = None
     is_nccl = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
