@@ -1243,18 +1243,22 @@ struct MsmJob {
             g0 = (uint32_t)std::max(2, zl_tune("ZL_TUNE_SEG", (int)g0));
             while (g0 & (g0 - 1)) g0 &= g0 - 1;
             if (g0 > H) g0 = H;
+            // plain wide windows: spread the narrow top window over its whole bucket set (k_msm_recode_wide); the weight then lives in the
+            // low spread_t bits of the bucket index: all of level 0's bits must be on one side of that boundary (a very narrow top
+            // window, 0 < spread_t < log2 g0, shortens the level-0 blocks to 2^spread_t)
+            spread_t = -1;
+            if (wide && !pre) {
+                const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
+                if (top_bits - 1 < c - 1) {
+                    spread_t = top_bits - 1;
+                    if (spread_t > 0 && (1u << spread_t) < g0) g0 = 1u << spread_t;
+                }
+            }
             red_g0 = g0;
             red_lg0 = 31 - __builtin_clz(g0);
             red_blocks = H / g0;  // both powers of two
             red_levels = 31 - __builtin_clz(red_blocks);
             roots_per_set = red_levels + 2;
-            // plain wide windows: spread the narrow top window over its whole bucket set (k_msm_recode_wide); the weight then lives in the
-            // low spread_t bits of the bucket index: all of level 0's bits must be on one side of that boundary
-            spread_t = -1;
-            if (wide && !pre) {
-                const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
-                if (top_bits - 1 < c - 1 && (top_bits - 1 == 0 || top_bits - 1 >= (int)red_lg0)) spread_t = top_bits - 1;
-            }
         }
         scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
         max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
