@@ -1,0 +1,127 @@
+// batch_affine_ubench.hip -- measured answer to "would batched-affine bucket accumulation beat the XYZZ mixed addition on gfx950?" (VERDICT r1 item 3;
+// DESIGN.md §4.2.2).  Best case for the batched-affine side: no bucket structure, no P = +-Q / infinity handling, operands streamed with fully
+// coalesced accesses, Montgomery's trick per lane over K independent additions with ONE Fermat inversion per lane and batch:
+//   sweep 1   d_j = x2_j - x1_j, prefix_j = d_0 ... d_(j-1) stored to a scratch array                      (1 multiplication per addition)
+//   inversion u = (d_0 ... d_(K-1))^-1                                                                       (570 / K)
+//   sweep 2   1/d_j = u * prefix_j, u *= d_j, lambda = (y2 - y1) / d, x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1    (5)
+// against the accumulation kernel's inner operation: acc += P_j in XYZZ coordinates (9.5 multiplication-equivalents), same field code
+// (openzl_amd/csrc/zl_field28.h), same launch shape.  Prints additions / s and the HBM bytes each variant moves per addition.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/batch_affine_ubench.hip -o tools/batch_affine_ubench && ./tools/batch_affine_ubench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../openzl_amd/csrc/zl_curve.h"
+
+using F = Fp28<BLS12_381_Fq28, BLS12_381_Fq>;
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// lane t owns additions t, t + lanes, ... (K of them): coalesced 64-B accesses across the wave
+template <int K>
+__global__ void __launch_bounds__(64) k_batched_affine(const F* __restrict__ x1, const F* __restrict__ y1, const F* __restrict__ x2, const F* __restrict__ y2,
+                                                        F* __restrict__ prefix, F* __restrict__ x3, F* __restrict__ y3, uint32_t lanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    F acc = F::one();
+    for (int j = 0; j < K; j++) {
+        const size_t i = (size_t)j * lanes + t;
+        const F d = zl::subk<1>(x2[i], x1[i]);  // < 3q
+        prefix[i] = acc;
+        acc = zl::mul(acc, d);
+    }
+    F u = zl::inv(acc);
+    for (int j = K - 1; j >= 0; j--) {
+        const size_t i = (size_t)j * lanes + t;
+        const F a = x1[i], b = y1[i], c = x2[i], e = y2[i];
+        const F d = zl::subk<1>(c, a);
+        const F dinv = zl::mul(u, prefix[i]);
+        u = zl::mul(u, d);
+        const F lam = zl::mul(zl::subk<1>(e, b), dinv);                   // 3 * 2 -> < 2
+        const F xs = zl::subk<1>(zl::subk<1>(zl::sqr(lam), a), c);        // 2 + 2 + 2 -> < 6
+        const F ys = zl::subk<1>(zl::mul(lam, zl::subk<3>(a, xs)), b);    // 2 * 9 -> < 2; - y1 -> < 4
+        x3[i] = zl::wred(xs);
+        y3[i] = ys;
+    }
+}
+// the accumulation kernel's inner loop on the same stream of points: 2K mixed additions per lane into one XYZZ accumulator
+template <int K>
+__global__ void __launch_bounds__(64) k_xyzz_chain(const F* __restrict__ x1, const F* __restrict__ y1, const F* __restrict__ x2, const F* __restrict__ y2,
+                                                    XYZZ<F>* __restrict__ out, uint32_t lanes) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int j = 0; j < K; j++) {
+        const size_t i = (size_t)j * lanes + t;
+        zl::add_mixed(acc, x1[i], y1[i], false);
+        zl::add_mixed(acc, x2[i], y2[i], false);
+    }
+    out[t] = acc;
+}
+
+template <int K>
+static void run(const F* x1, const F* y1, const F* x2, const F* y2, F* prefix, F* x3, F* y3, XYZZ<F>* out, size_t n_adds) {
+    const uint32_t lanes = (uint32_t)(n_adds / K);
+    const dim3 grid((lanes + 63) / 64), block(64);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float ms_b = 0, ms_x = 0;
+    for (int rep = 0; rep < 2; rep++) {  // second repetition is the measurement
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_batched_affine<K>), grid, block, 0, 0, x1, y1, x2, y2, prefix, x3, y3, lanes);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms_b, e0, e1));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_xyzz_chain<K>), grid, block, 0, 0, x1, y1, x2, y2, out, lanes);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms_x, e0, e1));
+    }
+    // bytes per addition: batched = sweep 1 reads x1, x2 (128) + writes prefix (64); sweep 2 reads 4 coordinates + prefix (320), writes x3, y3 (128)
+    // XYZZ chain = 2 additions per (x1, y1, x2, y2) quadruple: 128 B per addition
+    const double adds_b = (double)lanes * K, adds_x = 2.0 * lanes * K;
+    printf("K = %3d (%7u lanes): batched affine %8.3f ms = %6.2f G additions/s (%4.0f B/add, %5.0f GB/s)   |   XYZZ mixed chain %8.3f ms = %6.2f G additions/s (128 B/add, %5.0f GB/s)   ratio %.2f\n",
+           K, lanes, ms_b, adds_b / ms_b / 1e6, 640.0, adds_b * 640.0 / ms_b / 1e6, ms_x, adds_x / ms_x / 1e6, adds_x * 128.0 / ms_x / 1e6,
+           (adds_b / ms_b) / (adds_x / ms_x));
+}
+
+int main() {
+    const size_t n = (size_t)1 << 25;  // additions per launch for the batched kernel (the XYZZ kernel does 2n)
+    std::vector<F> h(n);
+    F *x1, *y1, *x2, *y2, *prefix, *x3, *y3;
+    XYZZ<F>* out;
+    for (F** p : {&x1, &y1, &x2, &y2, &prefix, &x3, &y3}) CHECK(hipMalloc(p, n * sizeof(F)));
+    CHECK(hipMalloc(&out, (n / 16) * sizeof(XYZZ<F>)));
+    uint64_t s = 88172645463325252ull;
+    for (F** p : {&x1, &y1, &x2, &y2}) {
+        for (size_t i = 0; i < n; i++) {
+            h[i] = F::zero();
+            for (int k = 0; k < 13; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].l[k] = (uint32_t)s & 0xFFFFFFFu; }
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            h[i].l[13] = (uint32_t)s & 0xFFFFu;  // < 2^380 < q: a canonical residue
+        }
+        CHECK(hipMemcpy(*p, h.data(), n * sizeof(F), hipMemcpyHostToDevice));
+    }
+    printf("batched-affine addition (Montgomery's trick per lane, one Fermat inversion per K additions, streamed operands) vs the XYZZ mixed-addition chain, 14 x 28-bit BLS12-381 Fq\n");
+    run<16>(x1, y1, x2, y2, prefix, x3, y3, out, n);
+    run<64>(x1, y1, x2, y2, prefix, x3, y3, out, n);
+    run<256>(x1, y1, x2, y2, prefix, x3, y3, out, n);
+    // spot check of the batched kernel's last run (K = 256): (x2 - x1) * (y3 + y1) == lambda-relation is awkward without lambda; check instead that the point
+    // (x3, y3) satisfies the chord relation (y3 + y1) * (x2 - x1) == (y2 - y1) * (x1 - x3)  (mod q) on a sample, computed on the host
+    std::vector<F> a(64), b(64), c(64), e(64), px(64), py(64);
+    CHECK(hipMemcpy(a.data(), x1, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(b.data(), y1, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(c.data(), x2, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(e.data(), y2, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(px.data(), x3, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(py.data(), y3, 64 * sizeof(F), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < 64; i++) {
+        const F lhs = zl::mul(zl::add(py[i], b[i]), zl::subk<1>(c[i], a[i]));
+        const F rhs = zl::mul(zl::subk<1>(e[i], b[i]), zl::subk<3>(a[i], px[i]));
+        if (lhs != rhs) bad++;
+    }
+    printf("chord-relation check of 64 batched results on the host: %s\n", bad ? "FAILED" : "ok");
+    return bad != 0;
+}
