@@ -270,6 +270,48 @@ def test_msm_known_discrete_log_2_24(backend, mode):
         assert tm.window_bits == 22
 
 
+@pytest.mark.parametrize("case", ["uniform", "all_equal", "two_values_and_negations"])
+def test_msm_wide_path_unaligned_adversarial(backend, case):
+    """The three-level sort over (window, bucket) ids on a size that is a multiple of nothing (unaligned slices, partial tiles) and on
+    scalar distributions that put everything into a handful of buckets: all scalars equal (one giant bucket per window, merged in two
+    stages, sorted by the tiled fine sort) and two values with their negatives (P and -P meet in the same buckets).  Exact."""
+    import torch
+
+    from openzl_amd.selfcheck import dot_mod_r, expected_point
+
+    curve = po.BLS12_381
+    r = curve.fr.p
+    n = (1 << 21) + 12345
+    rng = np.random.Generator(np.random.PCG64(4242))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    if case == "uniform":
+        S = ol.random_scalars(curve, n, 4243)
+    elif case == "all_equal":
+        S = np.repeat(ol.ints_to_limbs([0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % r], 4), n, axis=0)
+    else:
+        a, b = 0x0FEDCBA987654321 << 130 | 0x777, (1 << 200) + 12345
+        vals = ol.ints_to_limbs([a, r - a, b, r - b], 4)
+        S = np.ascontiguousarray(vals[rng.integers(0, 4, size=n)])
+    h = backend.bases_generate(curve.cid, k)
+    d_s = torch.from_numpy(np.ascontiguousarray(S).view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    exp = expected_point(backend, curve.cid, dot_mod_r(np.ascontiguousarray(S), k64, r))
+    try:
+        for c in (0, 19):
+            backend.set_msm_window(c)
+            got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+            assert not inf and (got == exp).all(), (case, c)
+        backend.set_msm_window(0)
+        backend.bases_precompute(h, 20)  # the merged bucket set of the table mode on the same inputs
+        got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+        assert not inf and (got == exp).all(), (case, "table")
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
+
+
 def _dot_mod_r_u64k(S: np.ndarray, k64: np.ndarray, r: int) -> int:
     """sum_i S_i * k_i mod r for (n,4) u64 scalars and u64 multipliers, exact, vectorised (32-bit limb products split into halves
     so that 2^26 of them sum inside a u64)."""
