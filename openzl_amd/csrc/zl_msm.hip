@@ -44,7 +44,9 @@
 #define ZL_SIDE_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 #define ZL_CHUNK_MAX 64    // entries per lane in msm_accumulate (smaller for small inputs: more lanes, shorter chains)
-#define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block
+#define ZL_BIG_SPAN 64     // buckets cut into more chunks than this are merged by a whole block ...
+#define ZL_BIG_SPAN_SMALL 8  // ... 8 for small inputs: a lane folds its partials serially, and 64 dependent additions (1.2 ms for G1, 3 ms
+                             // for G2) were the whole tail of a small Groth16 proof; for large inputs the serial fold is the cheaper one
 #define ZL_GIANT_SPAN 4096 // ... and into more than this by ZL_GIANT_PARTS blocks (two stages)
 #define ZL_GIANT_PARTS 32
 
@@ -767,7 +769,7 @@ template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
-                                                   uint32_t ZL_CHUNK) {
+                                                   uint32_t ZL_CHUNK, uint32_t big_span) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,7 +779,7 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
     const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
     if (t0 == t1) return;  // written directly by msm_accumulate
     if (t1 - t0 + 1 > ZL_GIANT_SPAN) { giant_list[atomicAdd(giant_count, 1u)] = b; return; }
-    if (t1 - t0 + 1 > ZL_BIG_SPAN) { big_list[atomicAdd(big_count, 1u)] = b; return; }
+    if (t1 - t0 + 1 > big_span) { big_list[atomicAdd(big_count, 1u)] = b; return; }
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t t = t0; t <= t1; t++) {
         const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
@@ -1191,7 +1193,7 @@ struct MsmJob {
     int c = 0, W = 0;
     int spread_t = -1;  // >= 0: the top window's entries are spread over its bucket set, weights = low spread_t bits + 1
     bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
-    uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, scan_blocks = 0, max_big = 0, max_giant = 0, Gn = 0;
+    uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, scan_blocks = 0, max_big = 0, max_giant = 0, Gn = 0, big_span = ZL_BIG_SPAN;
     uint32_t red_g0 = 0, red_lg0 = 0, red_blocks = 0, red_levels = 0;  // bucket reduction: block length of level 0, blocks per set, tree levels
     uint32_t roots_per_set = 0;                                         // channels of a set's root node: T, A, S_0 .. S_(levels-1)
     uint64_t maxE = 0;
@@ -1261,7 +1263,8 @@ struct MsmJob {
             roots_per_set = red_levels + 2;
         }
         scan_blocks = (NB + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-        max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_BIG_SPAN)) + 1;
+        big_span = nchunks <= (1u << 17) ? (uint32_t)ZL_BIG_SPAN_SMALL : (uint32_t)ZL_BIG_SPAN;
+        max_big = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * big_span)) + 1;
         max_giant = (uint32_t)(maxE / ((uint64_t)ZL_CHUNK * ZL_GIANT_SPAN)) + 1;
         d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         d_inf = bs.d_inf ? reinterpret_cast<const uint8_t*>(bs.d_inf) + first : nullptr;
@@ -1450,7 +1453,7 @@ struct MsmJob {
         return ZL_OK;
     }
     int tail(zl_ctx* ctx, hipStream_t st) {
-        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
         hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
