@@ -41,6 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+MADS_PER_MIXED_ADD = 3542  # ISA of k_msm_accumulate<BlsG1>: 6 products x 392 + 2 squarings x 301 + one dual product scan x 588 v_mad_u64_u32
+MADS_PER_MUL = 392
+MULS_PER_MIXED_ADD = MADS_PER_MIXED_ADD / MADS_PER_MUL  # 9.04 multiplication-equivalents
 FQ_MUL_PEAK_G = 74.3  # measured: the multiplier of zl_field28.h alone, 2 waves/SIMD, MI355X (71.6 - 74.3 over two boxes of the pool; the higher one) (tools/fbench28_asm.hip, profiles/r01_fbench_field_mul_asm.log)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
@@ -698,10 +701,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json; null for any other configuration)",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
-                         "int_alu": {"unit": "G Fq-mul/s", "achieved": float(tm.entries) * 9.5 / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
-                                     "frac": float(tm.entries) * 9.5 / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
-                                     "note": "the roofline that actually binds: (point, window) pairs x 9.5 multiplication-equivalents per mixed add "
-                                             "(8M + 2S = 10 product scans, two of them sharing one Montgomery reduction: 3724 mads = 9.5 x 392) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
+                         "int_alu": {"unit": "G Fq-mul/s", "achieved": float(tm.entries) * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
+                                     "frac": float(tm.entries) * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
+                                     "mads_per_mixed_add": MADS_PER_MIXED_ADD, "muls_per_mixed_add": MULS_PER_MIXED_ADD,
+                                     "note": "the roofline that actually binds: (point, window) pairs x 9.04 multiplication-equivalents per mixed add "
+                                             "(6M + 2S + one dual product scan with a shared Montgomery reduction = 6 x 392 + 2 x 301 + 588 = 3542 v_mad_u64_u32, counted in the kernel's ISA; "
+                                             "rounds 1 and early 2 priced a squaring as a multiplication, 9.5, which overstated this fraction by 5 %) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
                                              "at the kernel's occupancy (tools/fbench28_asm.hip; profiles/r01_fbench_field_mul_asm.log)"},
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "

@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 // flat_set: the spread top window (k_msm_recode_wide): its buckets are weighted by their low spread_t bits only; level 0 is weightless
 // for it when spread_t == 0, and the host skips its S_b from bit spread_t on.
 template <class G>
-__global__ void __launch_bounds__(64, 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
+__global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
                                                            XYZZ<typename G::F>* __restrict__ out /* [set][block][2]: T, A */) {
     ZL_SIDE_PRIO();

@@ -4,7 +4,7 @@
 //   sweep 1   d_j = x2_j - x1_j, prefix_j = d_0 ... d_(j-1) stored to a scratch array                      (1 multiplication per addition)
 //   inversion u = (d_0 ... d_(K-1))^-1                                                                       (570 / K)
 //   sweep 2   1/d_j = u * prefix_j, u *= d_j, lambda = (y2 - y1) / d, x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1    (5)
-// against the accumulation kernel's inner operation: acc += P_j in XYZZ coordinates (9.5 multiplication-equivalents), same field code
+// against the accumulation kernel's inner operation: acc += P_j in XYZZ coordinates (3542 mads = 9.04 multiplication-equivalents), same field code
 // (openzl_amd/csrc/zl_field28.h), same launch shape.  Prints additions / s and the HBM bytes each variant moves per addition.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/batch_affine_ubench.hip -o tools/batch_affine_ubench && ./tools/batch_affine_ubench
 #include <hip/hip_runtime.h>
