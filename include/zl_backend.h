@@ -226,6 +226,28 @@ int zl_point_from_bytes(zl_curve_t curve, zl_group_t group, const uint8_t* in, u
 size_t zl_groth16_proof_bytes(zl_curve_t curve);
 int zl_groth16_proof_to_bytes(zl_curve_t curve, const zl_g16_proof* proof, uint8_t* out);
 int zl_groth16_proof_from_bytes(zl_curve_t curve, const uint8_t* in, size_t len, zl_g16_proof* proof);
+/* Uncompressed form (ark's serialize_uncompressed / serialize_unchecked): x then y, flags on the last byte of y; a finite point
+ * carries no flag bits, infinity is written as (0, 1) with bit 6 set.  check = 0 is deserialize_unchecked (coordinates must be canonical
+ * integers, nothing else is verified); check != 0 also requires a point of the prime-order subgroup (ZL_ENOTCURVE otherwise). */
+size_t zl_point_bytes_uncompressed(zl_curve_t curve, zl_group_t group);
+int zl_point_to_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint8_t inf, uint8_t* out);
+int zl_point_from_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const uint8_t* in, int check, uint64_t* xy, uint8_t* inf);
+/* ProvingContext<E> on the wire (its codec::Encode / Decode, /root/reference/plugins/arkworks/src/groth16.rs:142-179): the
+ * ark_groth16::ProvingKey<E> written with serialize_unchecked -- vk (alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1), beta_g1,
+ * delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query; every point uncompressed, every Vec prefixed with its u64 little-endian
+ * length.  Same caveat as above: restated from the published ark-serialize / ark-groth16 0.3 layout, not checked against arkworks bytes.
+ * to_bytes: *len receives the size; out == NULL with cap == 0 only queries it; cap < size with a buffer is ZL_EINVAL.  The queries are
+ * downloaded from the device.
+ * from_bytes: uploads the five queries to ctx (flags: 0, or ZL_CHECK = the device verifies the curve equation of every query point),
+ * builds the window tables a compiled key of that size gets, and returns keys that prove / verify like compiled ones; they hold no
+ * trapdoor (zl_groth16_keys_trapdoor -> ZL_EINVAL) and learn their circuit at the first zl_groth16_prove_circuit (which uploads the
+ * matrices and rejects a circuit whose variable counts or evaluation domain do not match the key).  ZL_EINVAL = malformed input. */
+int zl_groth16_keys_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len);
+int zl_groth16_keys_from_bytes(zl_ctx* ctx, zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags, zl_g16_keys** out);
+/* ark_groth16::VerifyingKey<E>::serialize (compressed points): alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (u64 length first).
+ * (The reference's VerifyingContext wire format additionally carries ark's prepared-G2 line coefficients and e(alpha, beta); those are
+ * internal to ark-ec's Miller loop and are not restated.) */
+int zl_groth16_vk_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len);
 
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
 typedef struct zl_timing {

@@ -29,6 +29,8 @@ ABI_SYMBOLS = [
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
     "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
+    "zl_point_bytes_uncompressed", "zl_point_to_bytes_uncompressed", "zl_point_from_bytes_uncompressed", "zl_groth16_keys_to_bytes", "zl_groth16_keys_from_bytes",
+    "zl_groth16_vk_to_bytes",
 ]
 
 
@@ -121,6 +123,13 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_proof_bytes.restype = C.c_size_t
     L.zl_groth16_proof_to_bytes.argtypes = [C.c_int, C.POINTER(G16ProofC), u8p]
     L.zl_groth16_proof_from_bytes.argtypes = [C.c_int, u8p, C.c_size_t, C.POINTER(G16ProofC)]
+    L.zl_point_bytes_uncompressed.argtypes = [C.c_int, C.c_int]
+    L.zl_point_bytes_uncompressed.restype = C.c_size_t
+    L.zl_point_to_bytes_uncompressed.argtypes = [C.c_int, C.c_int, u64p, C.c_uint8, u8p]
+    L.zl_point_from_bytes_uncompressed.argtypes = [C.c_int, C.c_int, u8p, C.c_int, u64p, u8p]
+    L.zl_groth16_keys_to_bytes.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.zl_groth16_keys_from_bytes.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_uint, C.POINTER(vp)]
+    L.zl_groth16_vk_to_bytes.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     # multi-GPU in one process
     L.zl_ctx_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
     L.zl_mctx_destroy.argtypes = [vp]
@@ -480,6 +489,29 @@ def point_from_bytes(curve: int, group: int, data: bytes):
     return xy, inf.value
 
 
+def point_to_bytes_uncompressed(curve: int, group: int, xy: np.ndarray, inf: int = 0) -> bytes:
+    """arkworks serialize_uncompressed of one affine point given as canonical limbs (host code, no GPU)."""
+    L = load_library()
+    out = (C.c_uint8 * L.zl_point_bytes_uncompressed(curve, group))()
+    rc = L.zl_point_to_bytes_uncompressed(curve, group, _p64(np.ascontiguousarray(xy, dtype=np.uint64)), int(inf), out)
+    if rc:
+        raise BackendError(rc, "zl_point_to_bytes_uncompressed")
+    return bytes(out)
+
+
+def point_from_bytes_uncompressed(curve: int, group: int, data: bytes, check: bool = False):
+    L = load_library()
+    if len(data) != L.zl_point_bytes_uncompressed(curve, group):
+        raise BackendError(-1, "zl_point_from_bytes_uncompressed", "wrong length")
+    xy = np.zeros(2 * group * FQ_LIMBS[curve], dtype=np.uint64)
+    inf = C.c_uint8(0)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    rc = L.zl_point_from_bytes_uncompressed(curve, group, buf, int(check), _p64(xy), C.byref(inf))
+    if rc:
+        raise BackendError(rc, "zl_point_from_bytes_uncompressed")
+    return xy, inf.value
+
+
 def proof_to_bytes(curve: int, proof) -> bytes:
     """proof = (a, a_inf, b, b_inf, c, c_inf) as returned by Groth16Keys.prove -> 192 (BLS12-381) / 128 (BN254) bytes"""
     L = load_library()
@@ -554,14 +586,19 @@ class Circuit:
 
 
 class Groth16Keys:
-    """Groth16<E>::compile result (ProvingContext on the device)."""
+    """Groth16<E>::compile result (ProvingContext on the device), or -- from_bytes -- a ProvingContext decoded from its wire format."""
 
-    def __init__(self, backend: Backend, circuit: Circuit, seed: int):
+    def __init__(self, backend: Backend, circuit: Circuit, seed: int, _encoded: bytes = None, _flags: int = 0):
         self.L = backend.L
         self.backend = backend
         self.circuit = circuit
         self._k = C.c_void_p()
-        backend._check(self.L.zl_groth16_compile(backend._ctx, circuit._c, seed, C.byref(self._k)), "zl_groth16_compile")
+        if _encoded is None:
+            backend._check(self.L.zl_groth16_compile(backend._ctx, circuit._c, seed, C.byref(self._k)), "zl_groth16_compile")
+        else:
+            buf = (C.c_uint8 * max(1, len(_encoded))).from_buffer_copy(_encoded if _encoded else b"\0")
+            backend._check(self.L.zl_groth16_keys_from_bytes(backend._ctx, circuit.curve, buf, len(_encoded), _flags, C.byref(self._k)),
+                           "zl_groth16_keys_from_bytes")
         self.pk = G16PkC()
         self.L.zl_groth16_keys_pk(self._k, C.byref(self.pk))
         n_c, n_i, n_w = circuit.shape
@@ -571,9 +608,29 @@ class Groth16Keys:
                                ("b_g2_query", nv, ZL_G2)):
             backend._bases[getattr(self.pk, name)] = (circuit.curve, grp, cnt)  # so Backend.bases_download works on them
 
+    @classmethod
+    def from_bytes(cls, backend: Backend, circuit: Circuit, data: bytes, check: bool = False) -> "Groth16Keys":
+        """codec::Decode for ProvingContext (zl_groth16_keys_from_bytes); `circuit` is the circuit the key belongs to (proofs need it)"""
+        return cls(backend, circuit, 0, _encoded=data, _flags=ZL_CHECK if check else 0)
+
+    def _bytes_of(self, fn, what: str) -> bytes:
+        n = C.c_size_t(0)
+        self.backend._check(fn(self._k, None, 0, C.byref(n)), what)
+        out = (C.c_uint8 * max(1, n.value))()
+        self.backend._check(fn(self._k, out, n.value, C.byref(n)), what)
+        return C.string_at(C.addressof(out), n.value)
+
+    def to_bytes(self) -> bytes:
+        """codec::Encode for ProvingContext: ark_groth16::ProvingKey serialize_unchecked (uncompressed)"""
+        return self._bytes_of(self.L.zl_groth16_keys_to_bytes, "zl_groth16_keys_to_bytes")
+
+    def vk_to_bytes(self) -> bytes:
+        """ark_groth16::VerifyingKey serialize (compressed)"""
+        return self._bytes_of(self.L.zl_groth16_vk_to_bytes, "zl_groth16_vk_to_bytes")
+
     def trapdoor(self):
         out = np.zeros((5, 4), dtype=np.uint64)
-        self.L.zl_groth16_keys_trapdoor(self._k, _p64(out))
+        self.backend._check(self.L.zl_groth16_keys_trapdoor(self._k, _p64(out)), "zl_groth16_keys_trapdoor")
         return [sum(int(v) << (64 * j) for j, v in enumerate(row)) for row in out]
 
     def pk_dict(self) -> dict:

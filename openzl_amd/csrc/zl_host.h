@@ -361,11 +361,14 @@ struct Groth16 {
     struct ProvingContext {                                 // ProvingContext<E>(pub ProvingKey<E>) groth16.rs:127-140
         zl_ctx* ctx = nullptr;
         uint64_t a_query = 0, b_g1_query = 0, h_query = 0, l_query = 0, b_g2_query = 0;
-        uint64_t r1cs = 0;  // device-resident constraint matrices (static per circuit, uploaded by compile)
-        size_t n_constraints = 0;
+        // device-resident constraint matrices (static per circuit): uploaded by compile; a context decoded from bytes does not know its
+        // circuit, so the first prove() uploads them (hence mutable)
+        mutable uint64_t r1cs = 0;
+        mutable size_t n_constraints = 0;
         std::vector<uint64_t> alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2;
         size_t n_instance = 0, n_witness = 0, domain_size = 0;
         Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it
+        bool has_trapdoor = false;  // false for a context decoded from bytes
     };
     struct VerifyingContext {  // ark_groth16::VerifyingKey (the reference holds it prepared, groth16.rs:181-186); canonical affine points
         std::vector<uint64_t> alpha_g1, beta_g2, gamma_g2, delta_g2;
@@ -384,6 +387,15 @@ struct Groth16 {
     // verify (groth16.rs:459-466): e(A, B) == e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta); input = public inputs (canonical)
     static Result<bool> verify(const VerifyingContext& vk, const Input& input, const Proof& proof);
     static void release(ProvingContext& context);
+    // Wire format of ProvingContext<E> (codec::Encode / Decode, groth16.rs:142-179): ark_groth16::ProvingKey<E> written with
+    // serialize_unchecked = the uncompressed form (zl_serialize.h).  The key carries its VerifyingKey, so encode takes both halves of
+    // compile()'s result and decode returns both.  decode uploads the five queries (flags: ZL_CHECK verifies every point on the
+    // device) and builds the same window tables as compile; like the reference's deserialize_unchecked it trusts the bytes otherwise.
+    static Result<std::vector<uint8_t>> encode(const ProvingContext& context, const VerifyingContext& vk);
+    static Result<std::pair<ProvingContext, VerifyingContext>> decode(zl_ctx* ctx, const uint8_t* bytes, size_t len, unsigned flags = 0);
+    // ark_groth16::VerifyingKey<E>::serialize (compressed): alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1
+    static std::vector<uint8_t> encode_verifying_key(const VerifyingContext& vk);
+    static int build_window_tables(const ProvingContext& context);  // the per-query tables of a large key (compile and decode)
 };
 
 // CSR export of a compiler (what ark hands to the prover as ConstraintMatrices + assignments)

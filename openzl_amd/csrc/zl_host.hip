@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <atomic>
 #include <thread>
 #include "zl_host.h"
 #include "zl_serialize.h"
@@ -229,6 +230,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     ProvingContext pc;
     pc.ctx = ctx;
     pc.trapdoor = td;
+    pc.has_trapdoor = true;
     pc.n_instance = ni;
     pc.n_witness = nw;
     pc.domain_size = N;
@@ -238,20 +240,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, eh.data(), N - 1, &pc.h_query);
     if (!rc) rc = zl_bases_generate(ctx, E::curve, ZL_G1, el.data(), nw, &pc.l_query);
     lap("device generation (5 queries)");
-    // Window tables for the queries of a large proving key (static per circuit, like the key itself): the five MSMs of every proof then
-    // run on one merged bucket set each.  Measured at N = 2^20 (958 465 constraints): prove 33.5 -> 29.2 ms with c = 20 for the G1
-    // queries (13 windows) and c = 16 for the G2 query; c = 19 / 21 are worse (14 windows / twice the buckets for the same 13).
-    // Memory: 13 x 128 B per G1 point, 16 x 256 B per G2 point (about 11 GB for this key).  Small keys stay on the plain path.
-    if (!rc) {
-        const size_t big = (size_t)1 << 19;
-        const char* e1 = getenv("ZL_TUNE_G1_TABLE_C");
-        const char* e2 = getenv("ZL_TUNE_G2_TABLE_C");
-        const int c1 = e1 ? atoi(e1) : 20, c2 = e2 ? atoi(e2) : 16;
-        const struct { uint64_t h; size_t n; int c; } q[5] = {
-            {pc.a_query, (size_t)nv, c1}, {pc.b_g1_query, (size_t)nv, c1}, {pc.h_query, (size_t)N - 1, c1}, {pc.l_query, (size_t)nw, c1}, {pc.b_g2_query, (size_t)nv, c2}};
-        for (const auto& e : q)
-            if (!rc && e.n >= big) rc = zl_bases_precompute(ctx, e.h, e.c);
-    }
+    if (!rc) rc = build_window_tables(pc);
     lap("window tables");
     if (!rc) {
         R1csExport<FrP> own;
@@ -361,6 +350,184 @@ Result<bool> Groth16<E>::verify(const VerifyingContext& vk, const Input& input, 
     return res;
 }
 
+// Window tables for the queries of a large proving key (static per circuit, like the key itself): the five MSMs of every proof then
+// run on one merged bucket set each.  Measured at N = 2^20 (958 465 constraints): prove 33.5 -> 29.2 ms with c = 20 for the G1
+// queries (13 windows) and c = 16 for the G2 query; c = 19 / 21 are worse (14 windows / twice the buckets for the same 13).
+// Memory: 13 x 128 B per G1 point, 16 x 256 B per G2 point (about 11 GB for this key).  Small keys stay on the plain path.
+template <class E>
+int Groth16<E>::build_window_tables(const ProvingContext& pc) {
+    const size_t big = (size_t)1 << 19, nv = pc.n_instance + pc.n_witness;
+    const char* e1 = getenv("ZL_TUNE_G1_TABLE_C");
+    const char* e2 = getenv("ZL_TUNE_G2_TABLE_C");
+    const int c1 = e1 ? atoi(e1) : 20, c2 = e2 ? atoi(e2) : 16;
+    const struct { uint64_t h; size_t n; int c; } q[5] = {
+        {pc.a_query, nv, c1}, {pc.b_g1_query, nv, c1}, {pc.h_query, pc.domain_size - 1, c1}, {pc.l_query, pc.n_witness, c1}, {pc.b_g2_query, nv, c2}};
+    int rc = ZL_OK;
+    for (const auto& e : q)
+        if (!rc && e.n >= big) rc = zl_bases_precompute(pc.ctx, e.h, e.c);
+    return rc;
+}
+
+template <class E> struct CodecOf;
+template <> struct CodecOf<Bls12_381> { using type = serialize::BlsCodec; };
+template <> struct CodecOf<Bn254> { using type = serialize::BnCodec; };
+
+static void put_u64le(std::vector<uint8_t>& out, uint64_t v) {
+    for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i)));
+}
+static bool all_zero_words(const uint64_t* w, size_t n) {
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n; i++) acc |= w[i];
+    return acc == 0;
+}
+
+template <class E>
+std::vector<uint8_t> Groth16<E>::encode_verifying_key(const VerifyingContext& vk) {
+    using C = typename CodecOf<E>::type;
+    const size_t q1 = 2 * E::G1::FQ64, ni = vk.gamma_abc_g1.size() / q1;
+    std::vector<uint8_t> out(C::G1_BYTES + 3 * C::G2_BYTES);
+    uint8_t* p = out.data();
+    C::g1_to_bytes(vk.alpha_g1.data(), all_zero_words(vk.alpha_g1.data(), q1), p); p += C::G1_BYTES;
+    for (const auto* g : {&vk.beta_g2, &vk.gamma_g2, &vk.delta_g2}) { C::g2_to_bytes(g->data(), all_zero_words(g->data(), 2 * q1), p); p += C::G2_BYTES; }
+    put_u64le(out, ni);
+    const size_t at = out.size();
+    out.resize(at + ni * C::G1_BYTES);
+    for (size_t i = 0; i < ni; i++) C::g1_to_bytes(&vk.gamma_abc_g1[i * q1], all_zero_words(&vk.gamma_abc_g1[i * q1], q1), out.data() + at + i * C::G1_BYTES);
+    return out;
+}
+
+template <class E>
+Result<std::vector<uint8_t>> Groth16<E>::encode(const ProvingContext& pc, const VerifyingContext& vk) {
+    using C = typename CodecOf<E>::type;
+    Result<std::vector<uint8_t>> res{false, {}, Error{ZL_EINVAL}};
+    if (!pc.ctx) return res;
+    const size_t q1 = 2 * E::G1::FQ64, q2 = 2 * q1, ni = pc.n_instance, nv = pc.n_instance + pc.n_witness;
+    if (vk.gamma_abc_g1.size() != ni * q1 || pc.domain_size < 2) return res;
+    std::vector<uint8_t>& out = res.value;
+    auto put_g1 = [&](const uint64_t* xy) { const size_t at = out.size(); out.resize(at + C::G1_UNC_BYTES); C::g1_to_uncompressed(xy, all_zero_words(xy, q1), out.data() + at); };
+    auto put_g2 = [&](const uint64_t* xy) { const size_t at = out.size(); out.resize(at + C::G2_UNC_BYTES); C::g2_to_uncompressed(xy, all_zero_words(xy, q2), out.data() + at); };
+    // vk
+    put_g1(vk.alpha_g1.data()); put_g2(vk.beta_g2.data()); put_g2(vk.gamma_g2.data()); put_g2(vk.delta_g2.data());
+    put_u64le(out, ni);
+    for (size_t i = 0; i < ni; i++) put_g1(&vk.gamma_abc_g1[i * q1]);
+    put_g1(pc.beta_g1.data()); put_g1(pc.delta_g1.data());
+    // the five queries: downloaded as canonical affine words, re-encoded in place (only infinity records differ from the raw words)
+    const struct { uint64_t h; size_t n; bool g2; } q[5] = {
+        {pc.a_query, nv, false}, {pc.b_g1_query, nv, false}, {pc.b_g2_query, nv, true}, {pc.h_query, pc.domain_size - 1, false}, {pc.l_query, pc.n_witness, false}};
+    for (const auto& e : q) {
+        put_u64le(out, e.n);
+        const size_t rec = e.g2 ? C::G2_UNC_BYTES : C::G1_UNC_BYTES, words = rec / 8, at = out.size();
+        out.resize(at + e.n * rec);
+        if (!e.n) continue;
+        std::vector<uint64_t> tmp(e.n * words);
+        const int rc = zl_bases_download(pc.ctx, e.h, 0, e.n, tmp.data());
+        if (rc) { res.error = Error{rc}; res.value.clear(); return res; }
+        uint8_t* base = out.data() + at;
+        parallel_chunks(e.n, 16384, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t* xy = &tmp[i * words];
+                if (e.g2) C::g2_to_uncompressed(xy, all_zero_words(xy, words), base + i * rec);
+                else C::g1_to_uncompressed(xy, all_zero_words(xy, words), base + i * rec);
+            }
+        });
+    }
+    res.ok = true;
+    return res;
+}
+
+template <class E>
+Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::VerifyingContext>> Groth16<E>::decode(zl_ctx* ctx, const uint8_t* in, size_t len,
+                                                                                                                   unsigned flags) {
+    using C = typename CodecOf<E>::type;
+    Result<std::pair<ProvingContext, VerifyingContext>> res{false, {}, Error{ZL_EINVAL}};
+    if (!ctx || !in) return res;
+    const size_t q1 = 2 * E::G1::FQ64, q2 = 2 * q1;
+    const bool check = (flags & ZL_CHECK) != 0;
+    size_t pos = 0;
+    int rc = ZL_OK;
+    auto take = [&](size_t n) -> const uint8_t* {  // nullptr: the input ends early
+        if (rc || n > len - pos) { if (!rc) rc = ZL_EINVAL; return nullptr; }
+        const uint8_t* p = in + pos;
+        pos += n;
+        return p;
+    };
+    auto get_g1 = [&](std::vector<uint64_t>& xy) {
+        xy.assign(q1, 0);
+        uint8_t inf = 0;
+        if (const uint8_t* p = take(C::G1_UNC_BYTES)) rc = C::g1_from_uncompressed(p, check, xy.data(), &inf);
+    };
+    auto get_g2 = [&](std::vector<uint64_t>& xy) {
+        xy.assign(q2, 0);
+        uint8_t inf = 0;
+        if (const uint8_t* p = take(C::G2_UNC_BYTES)) rc = C::g2_from_uncompressed(p, check, xy.data(), &inf);
+    };
+    auto get_len = [&](size_t rec) -> size_t {  // Vec<T> length prefix, bounded by what the remaining input can hold
+        const uint8_t* p = take(8);
+        if (!p) return 0;
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i);
+        if (v > (len - pos) / rec) { rc = ZL_EINVAL; return 0; }
+        return (size_t)v;
+    };
+    ProvingContext& pc = res.value.first;
+    VerifyingContext& vk = res.value.second;
+    pc.ctx = ctx;
+    get_g1(vk.alpha_g1); get_g2(vk.beta_g2); get_g2(vk.gamma_g2); get_g2(vk.delta_g2);
+    const size_t ni = get_len(C::G1_UNC_BYTES);
+    vk.gamma_abc_g1.assign(ni * q1, 0);
+    for (size_t i = 0; i < ni && !rc; i++) {
+        std::vector<uint64_t> t;
+        get_g1(t);
+        memcpy(&vk.gamma_abc_g1[i * q1], t.data(), q1 * 8);
+    }
+    get_g1(pc.beta_g1); get_g1(pc.delta_g1);
+    pc.alpha_g1 = vk.alpha_g1;
+    pc.beta_g2 = vk.beta_g2;
+    pc.delta_g2 = vk.delta_g2;
+    // the five queries: validated and converted to the all-zero infinity encoding on the host, then uploaded
+    size_t count[5] = {0, 0, 0, 0, 0};
+    uint64_t* handle[5] = {&pc.a_query, &pc.b_g1_query, &pc.b_g2_query, &pc.h_query, &pc.l_query};
+    for (int k = 0; k < 5 && !rc; k++) {
+        const bool g2 = k == 2;
+        const size_t rec = g2 ? C::G2_UNC_BYTES : C::G1_UNC_BYTES, words = rec / 8;
+        const size_t n = count[k] = get_len(rec);
+        const uint8_t* p = take(n * rec);
+        if (rc) break;
+        if (n == 0) continue;  // an empty query (a circuit without witnesses) has no handle; prove() never reads it
+        std::vector<uint64_t> xy(n * words);
+        std::atomic<int> bad{ZL_OK};
+        parallel_chunks(n, 16384, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; i++) {
+                uint8_t inf = 0;
+                // subgroup membership on the host would cost a scalar multiplication per point: with ZL_CHECK the device verifies the
+                // curve equation of every uploaded point instead (zl_bases_upload)
+                const int r = g2 ? C::g2_from_uncompressed(p + i * rec, false, &xy[i * words], &inf) : C::g1_from_uncompressed(p + i * rec, false, &xy[i * words], &inf);
+                if (r) bad.store(r);
+            }
+        });
+        if ((rc = bad.load())) break;
+        rc = zl_bases_upload(ctx, E::curve, g2 ? ZL_G2 : ZL_G1, xy.data(), n, 0, -1, ZL_CANON | (check ? ZL_CHECK : 0u), handle[k]);
+    }
+    if (!rc && pos != len) rc = ZL_EINVAL;  // trailing bytes
+    // shape: a, b1, b2 cover every variable; h has N - 1 entries for a power-of-two domain N >= 2; l covers the witnesses
+    if (!rc) {
+        const size_t nv = count[0], N = count[3] + 1;
+        if (ni < 1 || nv < ni || count[1] != nv || count[2] != nv || count[4] != nv - ni || N < 2 || (N & (N - 1))) rc = ZL_EINVAL;
+        pc.n_instance = ni;
+        pc.n_witness = nv - ni;
+        pc.domain_size = N;
+    }
+    if (!rc) rc = build_window_tables(pc);
+    if (rc) {
+        release(pc);
+        res.value = {};
+        res.error = Error{rc};
+        return res;
+    }
+    res.ok = true;
+    return res;
+}
+
 template <class E>
 void Groth16<E>::release(ProvingContext& pc) {
     if (!pc.ctx) return;
@@ -378,7 +545,20 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
     if (r_out) *r_out = r;
     if (s_out) *s_out = s;
-    if (cs.constraint_count() != pc.n_constraints) return res;
+    if (pc.r1cs && cs.constraint_count() != pc.n_constraints) return res;
+    if (!pc.r1cs) {
+        // a context decoded from bytes (Groth16::decode) does not know its circuit: the first proof uploads the matrices, after checking
+        // that the compiler's evaluation domain is the one the key's h_query was generated for
+        const size_t nc = cs.constraint_count();
+        size_t N = 2;
+        while (N < nc + pc.n_instance) N <<= 1;
+        if (N != pc.domain_size) return res;
+        R1csExport<FrP> ex;
+        ex.build(cs);
+        const int rc_up = zl_r1cs_upload(pc.ctx, E::curve, &ex.view, &pc.r1cs);
+        if (rc_up) { res.error = Error{rc_up}; return res; }
+        pc.n_constraints = nc;
+    }
     // only the assignment travels per proof; the matrices and the proving key are device-resident
     const auto& inst = cs.instance_assignment();
     const auto& wit = cs.witness_assignment();
@@ -587,6 +767,7 @@ int zl_groth16_keys_pk(const zl_g16_keys* k, zl_g16_pk* pk) {
 }
 int zl_groth16_keys_trapdoor(const zl_g16_keys* k, uint64_t* out20) {
     if (!k || !out20) return ZL_EINVAL;
+    if (!(k->curve == ZL_BLS12_381 ? k->pc_bls.has_trapdoor : k->pc_bn.has_trapdoor)) return ZL_EINVAL;  // keys decoded from bytes carry none
     if (k->curve == ZL_BLS12_381) {
         const auto& t = k->pc_bls.trapdoor;
         const Fp<BLS12_381_Fr>* v[5] = {&t.alpha, &t.beta, &t.gamma, &t.delta, &t.tau};
@@ -617,6 +798,54 @@ int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit
         if (s_out) memcpy(s_out, s.l, 32);
     }
     return ZL_OK;
+}
+
+// ---- ProvingContext / VerifyingKey wire formats (Groth16<E>::encode / decode / encode_verifying_key) ------------------------------
+int zl_groth16_keys_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len) {
+    if (!k || !len || (!out && cap)) return ZL_EINVAL;
+    Result<std::vector<uint8_t>> r = k->curve == ZL_BLS12_381 ? Groth16<Bls12_381>::encode(k->pc_bls, k->vk_bls) : Groth16<Bn254>::encode(k->pc_bn, k->vk_bn);
+    if (!r.ok) return r.error.code;
+    *len = r.value.size();
+    if (cap < r.value.size()) return out ? ZL_EINVAL : ZL_OK;  // out == NULL, cap == 0: size query
+    memcpy(out, r.value.data(), r.value.size());
+    return ZL_OK;
+}
+int zl_groth16_keys_from_bytes(zl_ctx* ctx, zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags, zl_g16_keys** out) {
+    if (!ctx || !in || !out || (curve != ZL_BLS12_381 && curve != ZL_BN254) || (flags & ~ZL_CHECK)) return ZL_EINVAL;
+    zl_g16_keys* k = new (std::nothrow) zl_g16_keys();
+    if (!k) return ZL_ENOMEM;
+    k->curve = curve;
+    int rc = ZL_OK;
+    if (curve == ZL_BLS12_381) {
+        auto r = Groth16<Bls12_381>::decode(ctx, in, len, flags);
+        if (!r.ok) rc = r.error.code; else { k->pc_bls = r.value.first; k->vk_bls = r.value.second; }
+    } else {
+        auto r = Groth16<Bn254>::decode(ctx, in, len, flags);
+        if (!r.ok) rc = r.error.code; else { k->pc_bn = r.value.first; k->vk_bn = r.value.second; }
+    }
+    if (rc) { delete k; return rc; }
+    *out = k;
+    return ZL_OK;
+}
+int zl_groth16_vk_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len) {
+    if (!k || !len || (!out && cap)) return ZL_EINVAL;
+    const std::vector<uint8_t> v = k->curve == ZL_BLS12_381 ? Groth16<Bls12_381>::encode_verifying_key(k->vk_bls) : Groth16<Bn254>::encode_verifying_key(k->vk_bn);
+    *len = v.size();
+    if (cap < v.size()) return out ? ZL_EINVAL : ZL_OK;
+    memcpy(out, v.data(), v.size());
+    return ZL_OK;
+}
+size_t zl_point_bytes_uncompressed(zl_curve_t curve, zl_group_t group) { return 2 * zl_point_bytes(curve, group); }
+int zl_point_to_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const uint64_t* xy, uint8_t inf, uint8_t* out) {
+    if (!xy || !out || !zl_point_bytes(curve, group)) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) { if (group == ZL_G1) serialize::BlsCodec::g1_to_uncompressed(xy, inf != 0, out); else serialize::BlsCodec::g2_to_uncompressed(xy, inf != 0, out); }
+    else { if (group == ZL_G1) serialize::BnCodec::g1_to_uncompressed(xy, inf != 0, out); else serialize::BnCodec::g2_to_uncompressed(xy, inf != 0, out); }
+    return ZL_OK;
+}
+int zl_point_from_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const uint8_t* in, int check, uint64_t* xy, uint8_t* inf) {
+    if (!xy || !in || !inf || !zl_point_bytes(curve, group)) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) return group == ZL_G1 ? serialize::BlsCodec::g1_from_uncompressed(in, check != 0, xy, inf) : serialize::BlsCodec::g2_from_uncompressed(in, check != 0, xy, inf);
+    return group == ZL_G1 ? serialize::BnCodec::g1_from_uncompressed(in, check != 0, xy, inf) : serialize::BnCodec::g2_from_uncompressed(in, check != 0, xy, inf);
 }
 
 // e(P, Q) after the final exponentiation: 12 canonical Fq coefficients of the w-polynomial (tests vs the oracle)

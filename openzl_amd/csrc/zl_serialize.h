@@ -10,6 +10,10 @@
 //   proof      = A (G1) || B (G2) || C (G1): 192 bytes for BLS12-381, 128 for BN254
 // Decompression solves y^2 = x^3 + b (q = 3 mod 4 for both curves: y = a^((q+1)/4); Fq2 through the norm), picks the root the flag
 // names and, like ark-ec's deserializer, rejects points outside the prime-order subgroup.
+//   uncompressed = x || y, flags on the last byte of y (bit 6 = infinity, written as (0, 1); a finite point has no flag bits); Vec<T> = u64
+//                little-endian length, then the elements; ProvingKey<E> = vk (alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1), beta_g1,
+//                delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query in declaration order (ark-groth16 0.3 data_structures.rs) --
+//                the reference writes its ProvingContext with serialize_unchecked = this form (groth16.rs:142-179)
 // NOT VERIFIED against bytes produced by arkworks: the reference holds no serialized vector and cannot be built here.  The
 // tests pin it to an independent Python restatement (oracle/pyoracle.py) and to round trips only.
 #pragma once
@@ -154,6 +158,56 @@ struct Codec {
         *inf = 0;
         return ZL_OK;
     }
+    // ---- uncompressed form (serialize_uncompressed / serialize_unchecked): x then y, SWFlags on the last byte of y.  A finite point carries
+    // no flag bits (SWFlags::default() = NegativeY = 0: the sign bit is only meaningful in the compressed form), infinity is
+    // GroupAffine::zero() = (0, 1) with bit 6 set.  This is what ProvingContext's codec::Encode writes (groth16.rs:166-179).
+    static constexpr size_t G1_UNC_BYTES = 2 * NB, G2_UNC_BYTES = 4 * NB;
+    static void g1_to_uncompressed(const uint64_t* xy, bool inf, uint8_t* out) {
+        if (inf) { memset(out, 0, G1_UNC_BYTES); out[NB] = 1; out[G1_UNC_BYTES - 1] |= 0x40; return; }
+        memcpy(out, xy, G1_UNC_BYTES);  // canonical little-endian words ARE the little-endian bytes
+    }
+    static void g2_to_uncompressed(const uint64_t* xy, bool inf, uint8_t* out) {
+        if (inf) { memset(out, 0, G2_UNC_BYTES); out[2 * NB] = 1; out[G2_UNC_BYTES - 1] |= 0x40; return; }
+        memcpy(out, xy, G2_UNC_BYTES);
+    }
+    // check = false: deserialize_unchecked (coordinates must be canonical integers; nothing else is verified, as in the reference's
+    // Decode for ProvingContext, groth16.rs:147-164); check = true additionally requires a point of the prime-order subgroup
+    static bool canon_lt_q(const uint32_t* w) {
+        for (int i = F::N - 1; i >= 0; i--)
+            if (w[i] != FqP::mod(i)) return w[i] < FqP::mod(i);
+        return false;
+    }
+    template <int K>  // K base-field elements: 2 (G1) or 4 (G2)
+    static int from_uncompressed(const uint8_t* in, bool check, uint64_t* xy, uint8_t* inf) {
+        const uint8_t flags = in[K * NB - 1] & 0xC0;
+        uint32_t w[K][F::N];
+        for (int i = 0; i < K; i++) {
+            memcpy(w[i], in + i * NB, NB);
+            if (i + 1 < K) { if (w[i][F::N - 1] >> 30) return ZL_EINVAL; }  // only the last element carries flags
+            else w[i][F::N - 1] &= 0x3FFFFFFFu;
+            if (!canon_lt_q(w[i])) return ZL_EINVAL;  // ark-ff rejects integers >= q
+        }
+        memset(xy, 0, K * NB);
+        if (flags == 0xC0) return ZL_EINVAL;
+        if (flags & 0x40) { *inf = 1; return ZL_OK; }  // coordinates of an infinity record are ignored (GroupAffine::new(x, y, true))
+        *inf = 0;
+        if (check) {
+            F c[K];
+            for (int i = 0; i < K; i++) { memcpy(c[i].l, w[i], NB); c[i] = zl::to_mont(c[i]); }
+            if constexpr (K == 2) {
+                if (zl::sqr(c[1]) != zl::add(zl::mul(zl::sqr(c[0]), c[0]), b1())) return ZL_ENOTCURVE;
+                if (!in_subgroup(c[0], c[1])) return ZL_ENOTCURVE;
+            } else {
+                const F2 x{c[0], c[1]}, y{c[2], c[3]};
+                if (zl::sqr(y) != zl::add(zl::mul(zl::sqr(x), x), b2())) return ZL_ENOTCURVE;
+                if (!in_subgroup(x, y)) return ZL_ENOTCURVE;
+            }
+        }
+        memcpy(xy, w, K * NB);
+        return ZL_OK;
+    }
+    static int g1_from_uncompressed(const uint8_t* in, bool check, uint64_t* xy, uint8_t* inf) { return from_uncompressed<2>(in, check, xy, inf); }
+    static int g2_from_uncompressed(const uint8_t* in, bool check, uint64_t* xy, uint8_t* inf) { return from_uncompressed<4>(in, check, xy, inf); }
 };
 
 using BlsCodec = Codec<BLS12_381_Fq, BLS12_381_Fr, BLS12_381_G1, BLS12_381_G2>;

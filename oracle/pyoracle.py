@@ -1108,3 +1108,47 @@ def g2_decompress(c: CurveParams, data: bytes) -> Point2:
 
 def groth16_proof_bytes(c: CurveParams, A: Point, B: Point2, C_: Point) -> bytes:
     return g1_compress(c, A) + g2_compress(c, B) + g1_compress(c, C_)
+
+
+# ---- wire format: uncompressed points, ProvingKey / VerifyingKey (what the reference's ProvingContext codec writes, groth16.rs:142-179) ----
+# Restated from the published ark-serialize / ark-ec / ark-groth16 0.3 layout: serialize_uncompressed (= serialize_unchecked) of an affine
+# point is x then y with SWFlags on the last byte of y; a finite point carries SWFlags::default() = no bits, infinity is
+# GroupAffine::zero() = (0, 1) with bit 6; a Vec is its u64 little-endian length followed by the elements; derived struct impls write the
+# fields in declaration order.  UNPINNED like the compressed form above.
+def g1_uncompressed(c: CurveParams, P: Point) -> bytes:
+    nb = _fq_bytes(c)
+    if P is None:
+        out = bytearray(bytes(nb) + (1).to_bytes(nb, "little"))
+        out[-1] |= 0x40
+        return bytes(out)
+    return P[0].to_bytes(nb, "little") + P[1].to_bytes(nb, "little")
+
+
+def g2_uncompressed(c: CurveParams, P: Point2) -> bytes:
+    nb = _fq_bytes(c)
+    if P is None:
+        out = bytearray(bytes(2 * nb) + (1).to_bytes(nb, "little") + bytes(nb))
+        out[-1] |= 0x40
+        return bytes(out)
+    (x0, x1), (y0, y1) = P
+    return b"".join(v.to_bytes(nb, "little") for v in (x0, x1, y0, y1))
+
+
+def _vec(items: Sequence[bytes]) -> bytes:
+    return len(items).to_bytes(8, "little") + b"".join(items)
+
+
+def groth16_vk_bytes(c: CurveParams, vk: dict, compressed: bool = True) -> bytes:
+    """ark_groth16::VerifyingKey: alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1"""
+    e1 = g1_compress if compressed else g1_uncompressed
+    e2 = g2_compress if compressed else g2_uncompressed
+    return (e1(c, vk["alpha_g1"]) + e2(c, vk["beta_g2"]) + e2(c, vk["gamma_g2"]) + e2(c, vk["delta_g2"])
+            + _vec([e1(c, P) for P in vk["gamma_abc_g1"]]))
+
+
+def groth16_pk_bytes(c: CurveParams, pk: dict) -> bytes:
+    """ark_groth16::ProvingKey, serialize_unchecked: vk, beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query"""
+    return (groth16_vk_bytes(c, pk["vk"], compressed=False) + g1_uncompressed(c, pk["beta_g1"]) + g1_uncompressed(c, pk["delta_g1"])
+            + _vec([g1_uncompressed(c, P) for P in pk["a_query"]]) + _vec([g1_uncompressed(c, P) for P in pk["b_g1_query"]])
+            + _vec([g2_uncompressed(c, P) for P in pk["b_g2_query"]]) + _vec([g1_uncompressed(c, P) for P in pk["h_query"]])
+            + _vec([g1_uncompressed(c, P) for P in pk["l_query"]]))

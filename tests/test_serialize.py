@@ -119,3 +119,56 @@ def test_bls_g1_point_outside_the_subgroup_is_rejected():
     with pytest.raises(zb.BackendError) as e:
         zb.point_from_bytes(curve.cid, 1, bytes(data))
     assert e.value.code == -6
+
+
+# ---- uncompressed form (serialize_uncompressed / serialize_unchecked: what the ProvingContext codec writes, groth16.rs:142-179) ----------
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_uncompressed_points_match_restatement_and_round_trip(curve):
+    nb = 48 if curve.cid == 1 else 32
+    L = zb.load_library()
+    assert L.zl_point_bytes_uncompressed(curve.cid, 1) == 2 * nb and L.zl_point_bytes_uncompressed(curve.cid, 2) == 4 * nb
+    for P in _g1_points(curve, 4, 31) + [None, po.g1_generator(curve)]:
+        data = zb.point_to_bytes_uncompressed(curve.cid, 1, _g1_limbs(curve, P), inf=int(P is None))
+        assert data == po.g1_uncompressed(curve, P)
+        for check in (False, True):
+            xy, inf = zb.point_from_bytes_uncompressed(curve.cid, 1, data, check=check)
+            assert inf == int(P is None) and (xy == _g1_limbs(curve, P)).all()
+    for P in _g2_points(curve, 3, 32) + [None, po.g2_generator(curve)]:
+        data = zb.point_to_bytes_uncompressed(curve.cid, 2, _g2_limbs(curve, P), inf=int(P is None))
+        assert data == po.g2_uncompressed(curve, P)
+        for check in (False, True):
+            xy, inf = zb.point_from_bytes_uncompressed(curve.cid, 2, data, check=check)
+            assert inf == int(P is None) and (xy == _g2_limbs(curve, P)).all()
+    # a finite point carries no flag bits; the infinity record is (0, 1) with bit 6 of the last byte
+    assert po.g1_uncompressed(curve, po.g1_generator(curve))[-1] & 0xC0 == 0
+    z = po.g1_uncompressed(curve, None)
+    assert z[:nb] == bytes(nb) and z[nb] == 1 and z[-1] == 0x40
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_uncompressed_malformed_and_checked(curve):
+    nb, p = (48 if curve.cid == 1 else 32), curve.fq.p
+    G = po.g1_generator(curve)
+    good = bytearray(po.g1_uncompressed(curve, G))
+    bad = bytearray(good); bad[-1] |= 0xC0  # both flags
+    with pytest.raises(zb.BackendError):
+        zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(bad))
+    bad = bytearray(good); bad[nb - 1] |= 0x80  # flag bits on x
+    with pytest.raises(zb.BackendError):
+        zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(bad))
+    bad = bytearray(p.to_bytes(nb, "little") + good[nb:])  # x = q is not canonical
+    with pytest.raises(zb.BackendError):
+        zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(bad))
+    with pytest.raises(zb.BackendError):  # wrong length
+        zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(good[:-1]))
+    # unchecked takes any canonical pair (deserialize_unchecked), checked rejects a pair that is not on the curve
+    off = G[0].to_bytes(nb, "little") + ((G[1] + 1) % p).to_bytes(nb, "little")
+    xy, inf = zb.point_from_bytes_uncompressed(curve.cid, 1, off, check=False)
+    assert inf == 0
+    with pytest.raises(zb.BackendError) as e:
+        zb.point_from_bytes_uncompressed(curve.cid, 1, off, check=True)
+    assert e.value.code == -6
+    # an infinity record ignores its coordinates
+    junk = bytearray(good); junk[-1] |= 0x40
+    xy, inf = zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(junk))
+    assert inf == 1 and not xy.any()

@@ -20,3 +20,15 @@ for _ in range(4):
     t0 = time.perf_counter()
     keys.prove(seed=3)
     print(f"prove {(time.perf_counter() - t0) * 1e3:.2f} ms (device {be.last_timing().total_ms:.2f})", flush=True)
+if os.environ.get("G16_WIRE"):
+    # ProvingContext wire format at full size: encode (queries downloaded from the device), decode (upload + window tables), prove
+    from openzl_amd import backend as zb
+    t0 = time.perf_counter(); data = keys.to_bytes(); t1 = time.perf_counter()
+    p1, _, _ = keys.prove(seed=5)
+    keys.close()
+    t2 = time.perf_counter(); keys2 = Groth16Keys.from_bytes(be, circ, data); t3 = time.perf_counter()
+    p2, _, _ = keys2.prove(seed=5)
+    same = zb.proof_to_bytes(ZL_BLS12_381, p1) == zb.proof_to_bytes(ZL_BLS12_381, p2)
+    for _ in range(3):
+        t4 = time.perf_counter(); keys2.prove(seed=3); t5 = time.perf_counter()
+    print(f"wire: {len(data) / 1e6:.1f} MB  encode {t1 - t0:.2f} s  decode {t3 - t2:.2f} s  prove after decode {(t5 - t4) * 1e3:.2f} ms  same proof: {same}", flush=True)
