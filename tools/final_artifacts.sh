@@ -42,5 +42,6 @@ python tools/msm_sweep.py --g2 16 20 > $O/r02_msm_sweep_g2.log 2>&1
 ./tools/mfma_mq 2 > $O/r02_mfma_mq_ubench.log 2>&1
 ./tools/batch_affine_ubench > $O/r02_batch_affine_ubench.log 2>&1
 CURVE=bn254 BATCH=6 CS=16,19,20 python tools/msm_sweep.py 20 24 > $O/r02_msm_sweep_bn254.log 2>&1
+G16_WIRE=1 python tools/g16_one.py 2>&1 | grep -v amdgpu.ids > $O/r02_g16_key_wire.log
 rm -rf $O/pf $O/pw $O/pf2 $O/pw2 $O/pf3 $O/pw3 $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6
 ls -la $O
