@@ -44,7 +44,7 @@ R_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 MADS_PER_MIXED_ADD = 3542  # ISA of k_msm_accumulate<BlsG1>: 6 products x 392 + 2 squarings x 301 + one dual product scan x 588 v_mad_u64_u32
 MADS_PER_MUL = 392
 MULS_PER_MIXED_ADD = MADS_PER_MIXED_ADD / MADS_PER_MUL  # 9.04 multiplication-equivalents
-FQ_MUL_PEAK_G = 74.3  # measured: the multiplier of zl_field28.h alone, 2 waves/SIMD, MI355X (71.6 - 74.3 over two boxes of the pool; the higher one) (tools/fbench28_asm.hip, profiles/r01_fbench_field_mul_asm.log)
+FQ_MUL_PEAK_G = 78.6  # measured: the multiplier of zl_field28.h alone at the accumulate kernel's occupancy, 3 waves/SIMD (166 registers; 68.4 / 76.6 / 78.6 / 80.0 / 80.6 G/s at 1..5 waves, tools/fbench28_asm.hip, profiles/r02_fbench28_asm_occupancy.log; rounds 1 and early 2 used 74.3 = two waves on a slower box)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
@@ -707,7 +707,7 @@ def main():
                                      "note": "the roofline that actually binds: (point, window) pairs x 9.04 multiplication-equivalents per mixed add "
                                              "(6M + 2S + one dual product scan with a shared Montgomery reduction = 6 x 392 + 2 x 301 + 588 = 3542 v_mad_u64_u32, counted in the kernel's ISA; "
                                              "rounds 1 and early 2 priced a squaring as a multiplication, 9.5, which overstated this fraction by 5 %) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
-                                             "at the kernel's occupancy (tools/fbench28_asm.hip; profiles/r01_fbench_field_mul_asm.log)"},
+                                             "at the kernel's occupancy, 3 waves/SIMD (tools/fbench28_asm.hip; profiles/r02_fbench28_asm_occupancy.log)"},
                          "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},

@@ -19,10 +19,14 @@ def main(path):
         "on k.name = t.name where k.duration > 0.5 * t.m group by k.name")}
     total = sum(r[2] for r in rows) or 1
     print(f"# rocprofv3 --kernel-trace --stats summary of {path}")
-    print(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>11} {'max_us':>11} {'big_n':>5} {'big_avg_us':>11} {'%':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7} {'scratch':>7} {'grid':>10} {'wg':>5}")
+    # rocprofv3's vgpr_count is HALF the allocation of a wave64 kernel on this stack (checked against hipcc -S: k_msm_accumulate<BlsG1>
+    # NumVgprs 166 -> 84 here; <BlsG2> 256 + 172 AGPRs -> 216): print the allocation
+    print("# regs = registers allocated per lane (VGPR + AGPR, unified file) = 2 x the vgpr_count rocprofv3 reports on this stack for wave64 kernels "
+          "(checked against hipcc -S: k_msm_accumulate<BlsG1> NumVgprs 166 -> rocprofv3 84; <BlsG2> 256 + 172 AGPRs -> 216); waves per SIMD = floor(512 / regs)")
+    print(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>11} {'max_us':>11} {'big_n':>5} {'big_avg_us':>11} {'%':>6} {'regs':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7} {'scratch':>7} {'grid':>10} {'wg':>5}")
     for r in rows:
         name = r[0].split("(")[0].replace("void ", "")
-        print(f"{name:<70} {r[1]:>6} {r[2]/1e3:>12.1f} {r[3]/1e3:>11.1f} {r[4]/1e3:>11.1f} {r[5]/1e3:>11.1f} {big[r[0]][0]:>5} {big[r[0]][1]/1e3:>11.1f} {100*r[2]/total:>6.2f} {r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>7} {r[11]:>10} {r[12]:>5}")
+        print(f"{name:<70} {r[1]:>6} {r[2]/1e3:>12.1f} {r[3]/1e3:>11.1f} {r[4]/1e3:>11.1f} {r[5]/1e3:>11.1f} {big[r[0]][0]:>5} {big[r[0]][1]/1e3:>11.1f} {100*r[2]/total:>6.2f} {2*r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>7} {r[11]:>10} {r[12]:>5}")
 
 
 def launches(path, substr, limit=40):
