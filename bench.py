@@ -525,12 +525,12 @@ def main():
         torch.cuda.synchronize()
         # canonical -> (treated as Montgomery limbs: any residue < r is a valid Montgomery representative)
         fwd, inv = [], []
-        for it in range(3 + 5):  # 3 untimed round trips (twiddle tables, clocks), 5 timed
+        for it in range(8 + 8):  # 8 untimed round trips (twiddle tables; the clocks of an idle device take ~6 transforms to settle), 8 timed
             be.ntt_dev(ZL_BLS12_381, dx.data_ptr(), ln, inverse=False, mont=True)
             f = be.last_timing().total_ms
             be.ntt_dev(ZL_BLS12_381, dx.data_ptr(), ln, inverse=True, mont=True)
             i = be.last_timing().total_ms
-            if it >= 3:
+            if it >= 8:
                 fwd.append(f)
                 inv.append(i)
         back = dx.cpu().numpy().view(np.uint64)

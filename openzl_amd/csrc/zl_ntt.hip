@@ -322,9 +322,10 @@ static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twidd
     const unsigned L = (n + 1) / 2;
     tw.lo_bits = L;
     const uint32_t n_lo = 1u << L, n_hi = 1u << (n - L);
-    // layout: t_lo | t_hi | g_lo | g_hi | small tables for s = 1..NTT_MAX_S (2^(s-1) each)
+    // layout: t_lo | t_hi | g_lo | g_hi | small tables for s = 1..NTT_MAX_S (2^(s-1) each) | inverse only: n^-1 * t_hi (the last pass of a
+    // multi-pass inverse transform takes its inter-factor twiddles from it, so the 1/n scaling costs no multiplication of its own)
     const size_t small_total = (1u << NTT_MAX_S);
-    const size_t total = (size_t)2 * (n_lo + n_hi) + small_total;
+    const size_t total = (size_t)2 * (n_lo + n_hi) + small_total + (inverse ? n_hi : 0);
     F* d;
     ZL_HIP(ctx, hipMalloc((void**)&d, total * sizeof(F)));
     hipStream_t st = ctx->stream;
@@ -338,6 +339,7 @@ static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twidd
     hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_hi + 255) / 256), dim3(256), 0, st, t_hi, n_hi, L, w, one);
     hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_lo + 255) / 256), dim3(256), 0, st, g_lo, n_lo, 0u, g, one);
     hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_hi + 255) / 256), dim3(256), 0, st, g_hi, n_hi, L, g, scale);
+    if (inverse) hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((n_hi + 255) / 256), dim3(256), 0, st, small + small_total, n_hi, L, w, scale);
     // small[s] at offset 2^(s-1): w_(2^s)^i = w^(i << (n - s)), i < 2^(s-1)
     for (unsigned s = 1; s <= NTT_MAX_S && s <= n; s++) {
         const uint32_t cnt = 1u << (s - 1);
@@ -409,6 +411,10 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         a.from_mont = (last && !mont_out) ? 1 : 0;
         a.post_coset = (last && coset && inverse) ? 1 : 0;
         a.post_scale = (last && inverse && !coset) ? 1 : 0;
+        if (a.post_scale && pl.P > 1) {  // n^-1 rides on the last pass's twiddles (ntt_tables)
+            a.t_hi = small + ((size_t)1 << NTT_MAX_S);
+            a.post_scale = 0;
+        }
         for (int k = 0; k < 8; k++) a.ninv[k] = ninv.l[k];
         // columns per tile
         uint32_t cols_avail_log;
