@@ -45,7 +45,8 @@ def test_circuit_shape_and_oracle_proof_satisfies_groth16_equation(curve):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("curve,k", [(po.BLS12_381, 1), (po.BN254, 1), (po.BLS12_381, 8)], ids=["bls-k1", "bn254-k1", "bls-k8"])
+@pytest.mark.parametrize("curve,k", [(po.BLS12_381, 1), (po.BN254, 1), (po.BLS12_381, 8), (po.BN254, 8), (po.BLS12_381, 64)],
+                         ids=["bls-k1", "bn254-k1", "bls-k8", "bn254-k8", "bls-k64"])  # k = 64: BASELINE config 5's middle size (N = 2^14)
 def test_gpu_groth16_prove_matches_oracle(backend, curve, k):
     cs, pk, arrays, z, r, s = _case(curve, k)
     n = 1 << cs.domain_log()
