@@ -23,6 +23,10 @@ cp $O/r02_pmc_traffic.json $O/r02_pmc_traffic_ntt.json profiles/
 # ---- kernel stats ------------------------------------------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats -d $O/p1 -o t -- python bench.py > $O/r02_bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python tools/prof_summary.py $(dbof $O/p1) > $O/r02_kernel_stats_bench_default.txt
+# the headline leg alone (no fixed-key / skewed / NTT / Groth16 / CPU legs): every big k_msm_accumulate launch in this trace is one timed or warm-up step of `value`,
+# so the table's big_avg_us is directly comparable with roofline.kernel_ms of the JSON line written by the same command
+rocprofv3 --kernel-trace --stats -d $O/p7 -o t -- python bench.py --no-skew --fixed-key -1 --no-ntt --groth16-k 0 --no-cpu > $O/r02_bench_headline_under_rocprof.json 2> $O/bench_headline_under_rocprof.err
+python tools/prof_summary.py $(dbof $O/p7) > $O/r02_kernel_stats_bench_headline.txt
 rocprofv3 --kernel-trace --stats -d $O/p2 -o t -- python tools/msm_one.py 24 0 -1 3 > $O/msm_plain.log 2>&1
 python tools/prof_summary.py $(dbof $O/p2) reduce_tree > $O/r02_kernel_stats_msm_plain_single_call.txt
 rocprofv3 --kernel-trace --stats -d $O/p3 -o t -- python tools/msm_one.py 24 0 22 3 > $O/msm_table.log 2>&1
@@ -41,7 +45,9 @@ PRE=20,22 BATCH=6 python tools/msm_sweep.py 24 > $O/r02_msm_sweep_fixed_key.log 
 python tools/msm_sweep.py --g2 16 20 > $O/r02_msm_sweep_g2.log 2>&1
 ./tools/mfma_mq 2 > $O/r02_mfma_mq_ubench.log 2>&1
 ./tools/batch_affine_ubench > $O/r02_batch_affine_ubench.log 2>&1
+./tools/fbench28_asm > $O/r02_fbench28_asm_occupancy.log 2>&1
+./tools/fbench28_pair > $O/r02_fbench28_pair.log 2>&1
 CURVE=bn254 BATCH=6 CS=16,19,20 python tools/msm_sweep.py 20 24 > $O/r02_msm_sweep_bn254.log 2>&1
 G16_WIRE=1 python tools/g16_one.py 2>&1 | grep -v amdgpu.ids > $O/r02_g16_key_wire.log
-rm -rf $O/pf $O/pw $O/pf2 $O/pw2 $O/pf3 $O/pw3 $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6
+rm -rf $O/pf $O/pw $O/pf2 $O/pw2 $O/pf3 $O/pw3 $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7
 ls -la $O
