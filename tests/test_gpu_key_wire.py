@@ -123,3 +123,37 @@ def test_proving_context_decode_rejects_malformed_input(backend):
     finally:
         keys.close()
         circ.close()
+
+
+def test_proving_context_decode_survives_random_corruption(backend):
+    """Byte flips anywhere in the encoding: decode either refuses (ZL_EINVAL / ZL_ENOTCURVE) or returns keys that still prove without
+    faulting (deserialize_unchecked semantics: canonical garbage coordinates are taken as given) -- never a crash, and with ZL_CHECK a
+    flipped coordinate of a finite point is always caught."""
+    curve = po.BLS12_381
+    circ = Circuit(curve.cid, 1)
+    keys = Groth16Keys(backend, circ, seed=11)
+    try:
+        data = keys.to_bytes()
+        rng = np.random.default_rng(20260928)
+        accepted = refused = 0
+        for trial in range(40):
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                k2 = Groth16Keys.from_bytes(backend, circ, bytes(bad), check=bool(trial & 1))
+            except zb.BackendError as e:
+                assert e.code in (-1, -6)
+                refused += 1
+                continue
+            try:
+                k2.prove(seed=trial)  # whatever the points are, the prover must come back
+                accepted += 1
+            finally:
+                k2.close()
+        assert refused > 0 and accepted + refused == 40
+        # the intact encoding still decodes after all of that
+        Groth16Keys.from_bytes(backend, circ, data, check=True).close()
+    finally:
+        keys.close()
+        circ.close()
