@@ -42,6 +42,9 @@ def _units():
         # G1 device code inlines the multiplier: -4.5 % on the accumulate kernel vs the out-of-line call (host code keeps the call).
         if g.endswith("G1"):
             extra = extra + ["-DZL_INLINE_MUL_DEVICE"]
+        if g == "BlsG1":
+            # three waves per SIMD (<= 168 registers): what the accumulation kernel needs anyway (162); without the cap the compiler spreads to 185 = two waves
+            extra = extra + ["-DZL_ACC_WAVES=3"]
         units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"] + extra))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
 

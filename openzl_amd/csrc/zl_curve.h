@@ -205,6 +205,47 @@ ZL_HD constexpr void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg
     p.zz = mul(p.zz, pp);                                     // < 2
     p.zzz = mul(p.zzz, ppp);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same mixed addition for the lazily reduced 28-bit field on the device, with two savings in ordinary (non-mad) instructions -- the kernel
+// is bound by instruction issue, and the carry pass of a lazy add / sub is 39 of them:
+//  * a lazy operand that ONLY feeds a product scan stays un-carried (subk_scan / negk_scan, zl_field28.h): -qy (multiplied by zzz), q - x3 and
+//    -y (the inner operands of the dual product scan).  Operands that are squared, tested for zero or stored (pp_, r, x3) are carried as before.
+//  * x3 = r^2 - ppp - 2q is formed in one pass over a 6q bias whose limbs 0..12 are >= 3 * 2^28 - 1 (>= ppp_i + 2 q_i for carried ppp, q).
+// Bounds in units of q beside every line; the un-carried forms take the next larger bias (see subk_scan), which the product budget
+// (sum of bound products <= 2500) absorbs: 10 * 18 + 16 * 2.  x3 is the generic routine's value exactly.
+// Measured on one box: k_msm_accumulate 33.4 -> 32.5 ms at 2^24, 38.0 -> 37.5 ms per pipelined MSM.
+template <class A, class B>
+__device__ __forceinline__ void add_mixed(XYZZ<Fp28<A, B>>& p, const Fp28<A, B>& qx, const Fp28<A, B>& qy_in, bool neg_q) {
+    using F = Fp28<A, B>;
+    constexpr int L = A::L;
+    const F qy = neg_q ? negk_scan<2>(qy_in) : qy_in;         // qy_in < 2 -> < 4, un-carried when negated: feeds the product with zzz only
+    if (p.is_inf()) {
+        p.x = qx; p.y = neg_q ? negk<1>(qy_in) : qy_in; p.zz = F::one(); p.zzz = F::one();
+        return;
+    }
+    const F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);          // 16, 4 * 8 -> < 2
+    const F pp_ = subk<3>(u2, p.x), r = subk<3>(s2, p.y);     // < 10, carried (squared / tested below)
+    if (pp_.is_zero()) {
+        if (r.is_zero()) { p = dbl_affine(qx, neg_q ? negk<1>(qy_in) : qy_in); return; }
+        p = XYZZ<F>::inf();
+        return;
+    }
+    const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2, carried (scan outputs)
+    const F rr = sqr(r);                                      // 100 -> < 2
+    F x3 = rr;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        // 6q = biased 2q + biased 4q, one more 2^28 borrowed from the next limb: limbs 0..12 in [3 * 2^28 - 1, 5 * 2^28)
+        const uint32_t b6 = A::kq(1, i) + A::kq(2, i) + (i < L - 1 ? (1u << 28) : 0u) - (i > 0 ? 1u : 0u);
+        x3.l[i] = rr.l[i] + b6 - ppp.l[i] - 2u * q.l[i];      // < 2^28 + 5 * 2^28 < 2^31; the top limb is settled by the carry pass (mod 2^32)
+    }
+    carry28(x3);                                              // r^2 + 6q - ppp - 2q_: (2 + 2) + 4 -> < 8, stored
+    p.y = muladd(r, subk_scan<4>(q, x3), negk_scan<4>(p.y), ppp);  // r (q - x3) - y1 ppp: 10 * 18 + 16 * 2 -> < 2   (x3, y1 < 8 = 2^(4-1))
+    p.x = x3;
+    p.zz = mul(p.zz, pp);                                     // < 2
+    p.zzz = mul(p.zzz, ppp);
+}
+#endif
 // p += q (add-2008-s)
 template <class F>
 ZL_HD constexpr void add_full(XYZZ<F>& p, const XYZZ<F>& q) {

@@ -90,6 +90,38 @@ template <int J, class A, class B>
 ZL_HD Fp28<A, B> negk(const Fp28<A, B>& a) {
     return subk<J>(Fp28<A, B>::zero(), a);
 }
+// a - b + 2^J q and 2^J q - b WITHOUT the carry pass ("fat": limbs 0..12 < 2^30), for an operand that ONLY feeds a product scan (never a
+// squaring, a zero test, another subtraction or memory): the scans take any 32-bit limbs as long as their 64-bit columns hold, and a column
+// of 28 products fat x carried (< 2^58 each) plus 14 of the reduction (< 2^56) stays below 2^63.  Needs a, b carried and b < 2^(J-1) q: the
+// bias has one unit borrowed out of its top limb, so the top limb of 2^J q - b must be non-negative ON ITS OWN here (the carried forms
+// let the carry pass absorb a wrap), which b < 2^(J-1) q guarantees (top limb of b <= that of 2^(J-1) q <= (that of 2^J q) / 2).
+template <class A>
+constexpr bool kq_limbs_biased() {
+    for (int j = 1; j <= 6; j++) {
+        for (int i = 0; i < A::L - 1; i++)
+            if (A::kq(j, i) < (1u << 28) || A::kq(j, i) >= (1u << 29)) return false;
+        if (j > 1 && A::kq(j, A::L - 1) + 1 < 2 * (A::kq(j - 1, A::L - 1) + 1)) return false;  // top limbs: that of 2^j q is at least twice that of 2^(j-1) q
+    }
+    return true;
+}
+#if defined(__HIPCC__)
+template <int J, class A, class B>
+__device__ __forceinline__ Fp28<A, B> subk_scan(const Fp28<A, B>& a, const Fp28<A, B>& b) {  // device only: the host's 56-bit fast path packs carried limbs
+    static_assert(J >= 2 && J <= 6 && kq_limbs_biased<A>(), "bias table: limbs 0..12 of 2^j q in [2^28, 2^29)");
+    Fp28<A, B> r = a;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) r.l[i] = a.l[i] + A::kq(J, i) - b.l[i];
+    return r;
+}
+template <int J, class A, class B>
+__device__ __forceinline__ Fp28<A, B> negk_scan(const Fp28<A, B>& b) {
+    static_assert(J >= 2 && J <= 6 && kq_limbs_biased<A>(), "bias table: limbs 0..12 of 2^j q in [2^28, 2^29)");
+    Fp28<A, B> r = b;
+#pragma unroll
+    for (int i = 0; i < A::L; i++) r.l[i] = A::kq(J, i) - b.l[i];
+    return r;
+}
+#endif
 // generic spellings used by code that is shared with the 32-bit field (conservative biases)
 template <class A, class B> ZL_HD Fp28<A, B> sub(const Fp28<A, B>& a, const Fp28<A, B>& b) { return subk<4>(a, b); }  // b < 16q
 template <class A, class B> ZL_HD Fp28<A, B> neg(const Fp28<A, B>& a) { return negk<4>(a); }

@@ -85,6 +85,26 @@ def _check_field(be):
         for (a, b, c, d), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (a * b + c * d + a * d + c * b) * RP_INV % Q
+    if be is not None:
+        # device only: un-carried operands of a product scan (subk_scan / negk_scan).  19: a (b - c + 16q) + (16q - d) a with b, c, d carried,
+        # c, d < 8q (the bias is one step larger than the carried form's, so that the top limb never wraps); 20: (4q - a) b with a < 2q
+        A, Bv, Cv, D = edge_values(10, rng, 24), edge_values(2, rng, 24), edge_values(8, rng, 24), edge_values(8, rng, 24)
+        Cv = [min(c, 8 * Q - 1) for c in Cv]
+        D = [min(d, 8 * Q - 1) for d in D]
+        n = min(map(len, (A, Bv, Cv, D)))
+        rows = [(A[i], Bv[(3 * i) % n], Cv[(5 * i) % n], D[(7 * i) % n]) for i in range(n)]
+        rows += [(10 * Q - 1, 2 * Q - 1, 0, 0), (10 * Q - 1, 0, 8 * Q - 1, 8 * Q - 1), (10 * Q - 1, 2 * Q - 1, 8 * Q - 1, 0), (1, 0, 8 * Q - 1, 8 * Q - 1)]
+        out = _run_field(be, 19, rows)
+        for (a, b, c, d), o in zip(rows, out):
+            v = from_limbs(o)
+            assert v < 2 * Q and (o <= M28).all() and v % Q == (a * (b - c + 16 * Q) + (16 * Q - d) * a) * RP_INV % Q, (a // Q, b // Q, c // Q, d // Q)
+        A2 = [min(a, 2 * Q - 1) for a in edge_values(2, rng, 24)]
+        B2 = edge_values(8, rng, len(A2))
+        rows = [(a, b, 0, 0) for a, b in zip(A2, B2)] + [(2 * Q - 1, 8 * Q, 0, 0), (0, 8 * Q, 0, 0)]
+        out = _run_field(be, 20, rows)
+        for (a, b, _, _), o in zip(rows, out):
+            v = from_limbs(o)
+            assert v < 2 * Q and (o <= M28).all() and v % Q == (4 * Q - a) * b * RP_INV % Q
     # add / dbl: exact integer results, normalised limbs
     A, Bv = edge_values(1000, rng, 24), edge_values(1000, rng, 24)
     out = _run_field(be, 3, [(a, b, 0, 0) for a, b in zip(A, Bv)])
