@@ -26,8 +26,8 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
  * op: 0 mul(a,b)  1 sqr(a)  2 muladd(a,b,c,d)  3 add(a,b)  4 dbl(a)  5..10 subk<1..6>(a,b)  11 wred(a)  12 canon(a)
  *     13 is_zero(a)  14 a == b  15 muladd4(a,b,c,d,a,d,c,b)  16 load_mont32 . store_canon round trip is op 17/18:
  *     17 load_canon(12 words in a) -> limbs   18 store_canon(a) -> 12 words
- *     device only (un-carried operands of a product scan, zl_field28.h subk_scan / negk_scan; b, c, d carried, c, d < 8q, a < 2q for op 20):
- *     19 muladd(a, b - c + 16q, 16q - d, a)   20 mul(4q - a, b) */
+ *     scan-only operand forms (un-carried on the device, zl_field28.h subk_scan / negk_scan / x3_of; b, c, d carried, c, d < 8q in op 19, a < 2q in op 20):
+ *     19 muladd(a, b - c + 16q, 16q - d, a)   20 mul(4q - a, b)   21 a - b - 2c + 6q (b, c < 2^28 per limb) */
 int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out);
 
 /* Point formulas of zl_curve.h over that field.  group: ZL_G1 (coordinate = 14 words) or ZL_G2 (coordinate = 2 x 14 words);

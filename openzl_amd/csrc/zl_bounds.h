@@ -63,9 +63,20 @@ constexpr BF canon(const BF& a) { return BF{wred(a).b > 0 ? 1 : 0}; }
 constexpr BF inv(const BF& a) {  // Fermat ladder: acc = sqr(acc); acc = mul(acc, a) with acc < 2q throughout
     return mul(sqr(BF{2}), a);
 }
+// scan-only operands of the 28-bit field (zl_field28.h subk_scan / negk_scan): un-carried on the device, so even the TOP limb of
+// 2^J q - b must be non-negative without a carry pass: b <= 2^(J-1) q
+template <int J>
+constexpr BF subk_scan(const BF& a, const BF& b) {
+    static_assert(J >= 2 && J <= 6, "bias table holds 2q .. 64q");
+    if (2 * b.b > (1 << J)) bound_contract_violated();
+    return bf_chk(a.b + (1 << J));
+}
+template <int J>
+constexpr BF negk_scan(const BF& b) { return subk_scan<J>(BF::zero(), b); }
+template <> struct ScanBias<BF> { static constexpr int J = 4; };  // the G1 model follows the 28-bit field
 // the called Fq2 flavour computes the same dual scans out of line
 constexpr Fp2LT<BF, false> fq2_mul_called(const Fp2LT<BF, false>& a, const Fp2LT<BF, false>& b) {
-    return Fp2LT<BF, false>{muladd(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
+    return Fp2LT<BF, false>{muladd(a.c0, b.c0, a.c1, negk_scan<5>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
 }
 constexpr Fp2LT<BF, false> fq2_sqr_called(const Fp2LT<BF, false>& a) {
     return Fp2LT<BF, false>{mul(add(a.c0, a.c1), subk<4>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};

@@ -89,6 +89,19 @@ template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> sub(const Fp2LT<B, I>& a,
 template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> neg(const Fp2LT<B, I>& a) { return negk<4>(a); }
 template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> wred(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{wred(a.c0), wred(a.c1)}; }
 template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> canon(const Fp2LT<B, I>& a) { return Fp2LT<B, I>{canon(a.c0), canon(a.c1)}; }
+// ---- operands that ONLY feed a product scan ---------------------------------------------------------------------------------------
+// The kernels are bound by instruction issue and the carry pass of a lazy add / sub is 39 ordinary instructions, so an operand that goes
+// straight into a product scan (never a squaring, a zero test, another subtraction or memory) may skip it: zl_field28.h overloads these
+// for the 28-bit field on the device ("un-carried": the scans take any 32-bit limbs as long as their 64-bit columns hold).  The price is
+// one bias step more (2^J q with the subtrahend < 2^(J-1) q), which the product budget absorbs.  Everywhere else -- host code, the 32-bit
+// field, Fq2 (its products negate an operand component internally, which needs carried limbs <= 16q) -- these are the carried forms.
+template <class F> struct ScanBias { static constexpr int J = 3; };  // bias step of the mixed addition's un-stored differences (8q: the carried forms)
+template <class A, class B> struct ScanBias<Fp28<A, B>> { static constexpr int J = 4; };
+template <int J, class F> ZL_HD constexpr F subk_scan(const F& a, const F& b) { return subk<J>(a, b); }
+template <int J, class F> ZL_HD constexpr F negk_scan(const F& b) { return negk<J>(b); }
+// r^2 - ppp - 2q + 6q (the x coordinate of a sum): < 8 for r^2, ppp, q < 2
+template <class F> ZL_HD constexpr F x3_of(const F& rr, const F& ppp, const F& q) { return subk<2>(subk<1>(rr, ppp), dbl(q)); }
+
 // out-of-line Fq2 products (the INL = false flavour): one call per product, operands as scalar words (zl_field28.h)
 template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_mul_called(const Fp2LT<Fp28<A, P>, false>& a, const Fp2LT<Fp28<A, P>, false>& b) {
     Fp2LT<Fp28<A, P>, false> r;
@@ -100,9 +113,10 @@ template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_sqr_called(const 
     unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
     return r;
 }
-// (a0 + a1 u)(b0 + b1 u): each component ONE dual product scan; operand components <= 16q, result components < 2q
+// (a0 + a1 u)(b0 + b1 u): each component ONE dual product scan; operand components <= 16q, result components < 2q; -b1 is a scan-only
+// operand (32q - b1, un-carried on the device)
 template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> mul(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b) {
-    if constexpr (I) return Fp2LT<B, I>{muladd(a.c0, b.c0, a.c1, negk<4>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};
+    if constexpr (I) return Fp2LT<B, I>{muladd(a.c0, b.c0, a.c1, negk_scan<5>(b.c1)), muladd(a.c0, b.c1, a.c1, b.c0)};  // 16*16 + 16*32 <= 2500
     else return fq2_mul_called(a, b);
 }
 template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> sqr(const Fp2LT<B, I>& a) {
@@ -114,7 +128,7 @@ template <class B, bool I> ZL_HD constexpr Fp2LT<B, I> sqr(const Fp2LT<B, I>& a)
 template <class B, bool I>
 ZL_HD constexpr Fp2LT<B, I> muladd(const Fp2LT<B, I>& a, const Fp2LT<B, I>& b, const Fp2LT<B, I>& c, const Fp2LT<B, I>& d) {
     if constexpr (I) {
-        return Fp2LT<B, I>{muladd4(a.c0, b.c0, a.c1, negk<4>(b.c1), c.c0, d.c0, c.c1, negk<4>(d.c1)),
+        return Fp2LT<B, I>{muladd4(a.c0, b.c0, a.c1, negk_scan<5>(b.c1), c.c0, d.c0, c.c1, negk_scan<5>(d.c1)),  // 2 * (16*16 + 16*32) <= 2500
                            muladd4(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0)};
     } else {
         return add(mul(a, b), mul(c, d));
@@ -186,66 +200,26 @@ ZL_HD constexpr void dbl_inplace(XYZZ<F>& p) {
 // p += (qx, qy) (affine, canonical or < 2q, q must not be infinity); neg_q selects p -= q.   madd-2008-s
 template <class F>
 ZL_HD constexpr void add_mixed(XYZZ<F>& p, const F& qx, const F& qy_in, bool neg_q) {
-    const F qy = neg_q ? negk<1>(qy_in) : qy_in;              // < 2
-    if (p.is_inf()) {
-        p.x = qx; p.y = qy; p.zz = F::one(); p.zzz = F::one();
-        return;
-    }
-    const F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);          // 16 -> < 2
-    const F pp_ = subk<3>(u2, p.x), r = subk<3>(s2, p.y);     // < 10
-    if (pp_.is_zero()) {
-        if (r.is_zero()) { p = dbl_affine(qx, qy); return; }
-        p = XYZZ<F>::inf();
-        return;
-    }
-    const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2
-    const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q));       // (2 + 2) + 4 -> < 8
-    p.y = muladd(r, subk<3>(q, x3), negk<3>(p.y), ppp);       // r (q - x3) - y1 ppp, one reduction: 10*10 + 8*2 -> < 2
-    p.x = x3;
-    p.zz = mul(p.zz, pp);                                     // < 2
-    p.zzz = mul(p.zzz, ppp);
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-// The same mixed addition for the lazily reduced 28-bit field on the device, with two savings in ordinary (non-mad) instructions -- the kernel
-// is bound by instruction issue, and the carry pass of a lazy add / sub is 39 of them:
-//  * a lazy operand that ONLY feeds a product scan stays un-carried (subk_scan / negk_scan, zl_field28.h): -qy (multiplied by zzz), q - x3 and
-//    -y (the inner operands of the dual product scan).  Operands that are squared, tested for zero or stored (pp_, r, x3) are carried as before.
-//  * x3 = r^2 - ppp - 2q is formed in one pass over a 6q bias whose limbs 0..12 are >= 3 * 2^28 - 1 (>= ppp_i + 2 q_i for carried ppp, q).
-// Bounds in units of q beside every line; the un-carried forms take the next larger bias (see subk_scan), which the product budget
-// (sum of bound products <= 2500) absorbs: 10 * 18 + 16 * 2.  x3 is the generic routine's value exactly.
-// Measured on one box: k_msm_accumulate 33.4 -> 32.5 ms at 2^24, 38.0 -> 37.5 ms per pipelined MSM.
-template <class A, class B>
-__device__ __forceinline__ void add_mixed(XYZZ<Fp28<A, B>>& p, const Fp28<A, B>& qx, const Fp28<A, B>& qy_in, bool neg_q) {
-    using F = Fp28<A, B>;
-    constexpr int L = A::L;
-    const F qy = neg_q ? negk_scan<2>(qy_in) : qy_in;         // qy_in < 2 -> < 4, un-carried when negated: feeds the product with zzz only
+    constexpr int J = ScanBias<F>::J;                         // 3 (carried: bounds as annotated) or 4 (28-bit field: un-carried, in brackets)
     if (p.is_inf()) {
         p.x = qx; p.y = neg_q ? negk<1>(qy_in) : qy_in; p.zz = F::one(); p.zzz = F::one();
         return;
     }
-    const F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);          // 16, 4 * 8 -> < 2
-    const F pp_ = subk<3>(u2, p.x), r = subk<3>(s2, p.y);     // < 10, carried (squared / tested below)
+    const F qy = neg_q ? negk_scan<2>(qy_in) : qy_in;         // < 4: feeds the product with zzz only
+    const F u2 = mul(qx, p.zz), s2 = mul(qy, p.zzz);          // 16, 32 -> < 2
+    const F pp_ = subk<3>(u2, p.x), r = subk<3>(s2, p.y);     // < 10 (squared / tested below: carried)
     if (pp_.is_zero()) {
         if (r.is_zero()) { p = dbl_affine(qx, neg_q ? negk<1>(qy_in) : qy_in); return; }
         p = XYZZ<F>::inf();
         return;
     }
-    const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2, carried (scan outputs)
-    const F rr = sqr(r);                                      // 100 -> < 2
-    F x3 = rr;
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        // 6q = biased 2q + biased 4q, one more 2^28 borrowed from the next limb: limbs 0..12 in [3 * 2^28 - 1, 5 * 2^28)
-        const uint32_t b6 = A::kq(1, i) + A::kq(2, i) + (i < L - 1 ? (1u << 28) : 0u) - (i > 0 ? 1u : 0u);
-        x3.l[i] = rr.l[i] + b6 - ppp.l[i] - 2u * q.l[i];      // < 2^28 + 5 * 2^28 < 2^31; the top limb is settled by the carry pass (mod 2^32)
-    }
-    carry28(x3);                                              // r^2 + 6q - ppp - 2q_: (2 + 2) + 4 -> < 8, stored
-    p.y = muladd(r, subk_scan<4>(q, x3), negk_scan<4>(p.y), ppp);  // r (q - x3) - y1 ppp: 10 * 18 + 16 * 2 -> < 2   (x3, y1 < 8 = 2^(4-1))
+    const F pp = sqr(pp_), ppp = mul(pp_, pp), q = mul(p.x, pp);  // 100, 20, 16 -> < 2
+    const F x3 = x3_of(sqr(r), ppp, q);                       // (2 + 2) + 4 -> < 8 (stored: carried)
+    p.y = muladd(r, subk_scan<J>(q, x3), negk_scan<J>(p.y), ppp);  // r (q - x3) - y1 ppp, one reduction: 10*10 + 8*2 [10*18 + 16*2] -> < 2
     p.x = x3;
     p.zz = mul(p.zz, pp);                                     // < 2
     p.zzz = mul(p.zzz, ppp);
 }
-#endif
 // p += q (add-2008-s)
 template <class F>
 ZL_HD constexpr void add_full(XYZZ<F>& p, const XYZZ<F>& q) {

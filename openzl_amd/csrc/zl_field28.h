@@ -90,6 +90,7 @@ template <int J, class A, class B>
 ZL_HD Fp28<A, B> negk(const Fp28<A, B>& a) {
     return subk<J>(Fp28<A, B>::zero(), a);
 }
+// Device forms of zl_curve.h's scan-only operands:
 // a - b + 2^J q and 2^J q - b WITHOUT the carry pass ("fat": limbs 0..12 < 2^30), for an operand that ONLY feeds a product scan (never a
 // squaring, a zero test, another subtraction or memory): the scans take any 32-bit limbs as long as their 64-bit columns hold, and a column
 // of 28 products fat x carried (< 2^58 each) plus 14 of the reduction (< 2^56) stays below 2^63.  Needs a, b carried and b < 2^(J-1) q: the
@@ -104,24 +105,49 @@ constexpr bool kq_limbs_biased() {
     }
     return true;
 }
-#if defined(__HIPCC__)
 template <int J, class A, class B>
-__device__ __forceinline__ Fp28<A, B> subk_scan(const Fp28<A, B>& a, const Fp28<A, B>& b) {  // device only: the host's 56-bit fast path packs carried limbs
+ZL_HD Fp28<A, B> subk_scan(const Fp28<A, B>& a, const Fp28<A, B>& b) {
     static_assert(J >= 2 && J <= 6 && kq_limbs_biased<A>(), "bias table: limbs 0..12 of 2^j q in [2^28, 2^29)");
+#if defined(__HIP_DEVICE_COMPILE__)
     Fp28<A, B> r = a;
 #pragma unroll
     for (int i = 0; i < A::L; i++) r.l[i] = a.l[i] + A::kq(J, i) - b.l[i];
     return r;
+#else
+    return subk<J>(a, b);  // host: carried (the 56-bit fast path packs carried limbs)
+#endif
 }
 template <int J, class A, class B>
-__device__ __forceinline__ Fp28<A, B> negk_scan(const Fp28<A, B>& b) {
+ZL_HD Fp28<A, B> negk_scan(const Fp28<A, B>& b) {
     static_assert(J >= 2 && J <= 6 && kq_limbs_biased<A>(), "bias table: limbs 0..12 of 2^j q in [2^28, 2^29)");
+#if defined(__HIP_DEVICE_COMPILE__)
     Fp28<A, B> r = b;
 #pragma unroll
     for (int i = 0; i < A::L; i++) r.l[i] = A::kq(J, i) - b.l[i];
     return r;
-}
+#else
+    return negk<J>(b);
 #endif
+}
+// r^2 - ppp - 2q + 6q in ONE pass (device): the 6q bias is biased 2q + biased 4q with one more 2^28 borrowed from the next limb, so its limbs
+// 0..12 lie in [3 * 2^28 - 1, 5 * 2^28) >= ppp_i + 2 q_i for carried ppp, q (scan outputs); the top limb is settled by the carry pass mod 2^32
+template <class A, class B>
+ZL_HD Fp28<A, B> x3_of(const Fp28<A, B>& rr, const Fp28<A, B>& ppp, const Fp28<A, B>& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int L = A::L;
+    static_assert(kq_limbs_biased<A>(), "bias table");
+    Fp28<A, B> x3 = rr;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const uint32_t b6 = A::kq(1, i) + A::kq(2, i) + (i < L - 1 ? (1u << 28) : 0u) - (i > 0 ? 1u : 0u);
+        x3.l[i] = rr.l[i] + b6 - ppp.l[i] - 2u * q.l[i];  // < 2^28 + 5 * 2^28 < 2^31
+    }
+    carry28(x3);
+    return x3;
+#else
+    return subk<2>(subk<1>(rr, ppp), dbl(q));
+#endif
+}
 // generic spellings used by code that is shared with the 32-bit field (conservative biases)
 template <class A, class B> ZL_HD Fp28<A, B> sub(const Fp28<A, B>& a, const Fp28<A, B>& b) { return subk<4>(a, b); }  // b < 16q
 template <class A, class B> ZL_HD Fp28<A, B> neg(const Fp28<A, B>& a) { return negk<4>(a); }
@@ -491,7 +517,7 @@ ZL_NOINLINE_HD Pair28 fq2_mul_call28(ZL_P14(wa), ZL_P14(wb), ZL_P14(wc), ZL_P14(
     static_assert(A::L == 14, "Fq2 helpers are written for 14 limbs");
     Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
     ZL_S14(a0, wa); ZL_S14(a1, wb); ZL_S14(b0, wc); ZL_S14(b1, wd);
-    const Fp28<A, B> nb1 = negk<4>(b1);
+    const Fp28<A, B> nb1 = negk_scan<5>(b1);  // scan-only operand: 32q - b1, un-carried on the device (b1 <= 16q)
     return pair28(muladd(a0, b0, a1, nb1), muladd(a0, b1, a1, b0));
 }
 template <class A, class B>

@@ -116,10 +116,9 @@ ZL_HD static void fp28_op(int op, const uint32_t* in, uint32_t* out) {
     case 13: r.l[0] = a.is_zero() ? 1u : 0u; break;
     case 14: r.l[0] = (a == b) ? 1u : 0u; break;
     case 15: r = zl::muladd4(a, b, c, d, a, d, c, b); break;
-#if defined(__HIP_DEVICE_COMPILE__)  // the un-carried operand forms exist for the device scans only (the host's 56-bit fast path packs carried limbs)
-    case 19: r = zl::muladd(a, zl::subk_scan<4>(b, c), zl::negk_scan<4>(d), a); break;  // a (b - c + 16q) + (16q - d) a
+    case 19: r = zl::muladd(a, zl::subk_scan<4>(b, c), zl::negk_scan<4>(d), a); break;  // a (b - c + 16q) + (16q - d) a: scan-only operands (un-carried on the device)
     case 20: r = zl::mul(zl::negk_scan<2>(a), b); break;                                  // (4q - a) b
-#endif
+    case 21: r = zl::x3_of(a, b, c); break;                                               // a - b - 2c + 6q in one pass (device), b, c carried
     case 17: r = FieldIO<F28>::load_canon(in); break;
     case 18: {
         uint32_t w[12];
@@ -209,7 +208,7 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
 
 int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) {
     if ((!in || !out) && n) return ZL_EINVAL;
-    if (op < 0 || op > 20 || op == 16 || n >= (1u << 24) || (!ctx && op > 18)) return ZL_EINVAL;
+    if (op < 0 || op > 21 || op == 16 || n >= (1u << 24)) return ZL_EINVAL;
     if (!n) return ZL_OK;
     if (!ctx) {
         for (size_t i = 0; i < n; i++) fp28_op(op, in + i * 56, out + i * 14);

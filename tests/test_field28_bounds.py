@@ -85,8 +85,8 @@ def _check_field(be):
         for (a, b, c, d), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (a * b + c * d + a * d + c * b) * RP_INV % Q
-    if be is not None:
-        # device only: un-carried operands of a product scan (subk_scan / negk_scan).  19: a (b - c + 16q) + (16q - d) a with b, c, d carried,
+    if True:
+        # scan-only operand forms (subk_scan / negk_scan / x3_of: un-carried on the device, carried on the host).  19: a (b - c + 16q) + (16q - d) a with b, c, d carried,
         # c, d < 8q (the bias is one step larger than the carried form's, so that the top limb never wraps); 20: (4q - a) b with a < 2q
         A, Bv, Cv, D = edge_values(10, rng, 24), edge_values(2, rng, 24), edge_values(8, rng, 24), edge_values(8, rng, 24)
         Cv = [min(c, 8 * Q - 1) for c in Cv]
@@ -105,6 +105,12 @@ def _check_field(be):
         for (a, b, _, _), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (4 * Q - a) * b * RP_INV % Q
+        # 21: x3 = a - b - 2c + 6q in one pass; b, c carried values (scan outputs < 2q in the formulas; any carried value is admissible)
+        A3, B3, C3 = edge_values(2, rng, 24), edge_values(2, rng, 24), edge_values(2, rng, 24)
+        rows = [(a, b, c, 0) for a, b, c in zip(A3, B3, C3)] + [(0, 2 * Q - 1, 2 * Q - 1, 0), (2 * Q - 1, 0, 0, 0), (0, 0, 0, 0)]
+        out = _run_field(be, 21, rows)
+        for (a, b, c, _), o in zip(rows, out):
+            assert from_limbs(o) == a - b - 2 * c + 6 * Q and (o[:13] <= M28).all()
     # add / dbl: exact integer results, normalised limbs
     A, Bv = edge_values(1000, rng, 24), edge_values(1000, rng, 24)
     out = _run_field(be, 3, [(a, b, 0, 0) for a, b in zip(A, Bv)])
