@@ -234,8 +234,9 @@ ZL_HD constexpr void add_full(XYZZ<F>& p, const XYZZ<F>& q) {
         return;
     }
     const F pp = sqr(pp_), ppp = mul(pp_, pp), q_ = mul(u1, pp);  // < 2
-    const F x3 = subk<2>(subk<1>(sqr(r), ppp), dbl(q_));      // < 8
-    p.y = muladd(r, subk<3>(q_, x3), negk<1>(s1), ppp);       // 4*10 + 2*2 -> < 2
+    constexpr int J = ScanBias<F>::J;
+    const F x3 = x3_of(sqr(r), ppp, q_);                      // < 8
+    p.y = muladd(r, subk_scan<J>(q_, x3), negk_scan<2>(s1), ppp);  // 4*10 + 4*2 [4*18 + 4*2] -> < 2
     p.x = x3;
     p.zz = mul(mul(p.zz, q.zz), pp);
     p.zzz = mul(mul(p.zzz, q.zzz), ppp);
