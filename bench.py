@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the MI355X MSM / NTT backend (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 24] [--no-cpu] [--no-ntt]
+    python bench.py --gpus N                       # N > 1 launched bare: re-executes itself under torch.distributed.run (one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --transport mctx      # ONE process, zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded (RCCL inside the library)
 
 A "step" is one variable-base MSM over 2^log_n random BLS12-381 G1 points and random scalars < r per GPU, bases and
 scalars already resident in HBM, through the C ABI (zl_msm_batch_partial_dev / zl_msm_partial_dev), with NO per-key precomputation:
@@ -14,8 +16,16 @@ on every rank (zl_partials_sum).  Rank 0 prints ONE JSON line.  Extra objects on
                 §8d) / its HIP-event duration on the backend's stream, vs 8 TB/s; .int_alu = the integer-multiply roofline
                 that actually binds; .traffic = PMC bytes of the same configuration (profiles/)
   cpu_baseline  the CPU oracle (arkworks-algorithm restatement, NOT the arkworks binary) timed on this box's cores on the same input
-                (N = 1 only): all-core (chunk x window) grid on the complete input (value; must equal the GPU result bit for bit), window-parallel
-                (arkworks `parallel`) and single-threaded (the reference's configuration) on bounded samples
+                (N = 1 only): all-core (chunk x window) grid on the complete input (must equal the GPU result bit for bit), window-parallel
+                (arkworks `parallel`) and single-threaded (the reference's configuration) on bounded samples; value = the faster multi-threaded one
+  configs       BASELINE.json's five configurations on this line: "1" 2^16 BN254 (GPU + CPU oracle, equal), "2" 2^20 BLS12-381 (single call /
+                pipelined, integer-ALU fraction of the whole call), "3" -> ntt, "4" 2^26 as 8 shards (N = 1: 8 virtual ranks through
+                zl_msm_sharded, functional; N > 1: scaling.config4), "5" -> groth16
+  scaling       N > 1: weak (2^log_n per GPU = the headline), config4 (2^26 points over the N ranks) and strong (2^24 points over the N ranks),
+                each checked exactly against the all-shard dot product and each with per_gpu_efficiency = (time of the same per-GPU
+                MSM on rank 0 alone, measured in this process) / (time with all ranks)
+  mctx          N > 1: the one-process transport (zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded) timed by a child process of
+                rank 0 after the ranks are done; .rccl_ranks = size of the RCCL communicator the library created
   pcie_inclusive    the same MSM with the scalars coming from host memory (zl_msm); never `value`
   msm_fixed_key     the precomputed-table mode (zl_bases_precompute, c = 22) with its build time, bytes and break-even count; never `value`
   msm_skewed_scalars  the same MSM on Groth16-witness-like scalars (N = 1 only)
@@ -249,12 +259,409 @@ def distributed_ntt_leg(be, dist, torch, dev, rank, world, log_m):
             "self_check": "iNTT(NTT(x)) == x on every rank; bit-exact parity of the legs in tests/test_gpu_sharded_ntt.py"}
 
 
+R_BN = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+_TORCHRUN_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_RUN_ID",
+                 "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING")
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_launch(n_gpus: int):
+    """`python bench.py --gpus N` launched bare (no torchrun environment): replace this process by the one-rank-per-GPU launcher the
+    contract names, with the same arguments."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a torchrun environment: re-launching as %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+class Run:
+    """what every leg needs: the backend of this rank, its device, and the process group (if any)"""
+
+    def __init__(self, args, torch, dist, be, dev, rank, world):
+        self.args, self.torch, self.dist, self.be, self.dev, self.rank, self.world = args, torch, dist, be, dev, rank, world
+        self.is_nccl = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
+        self.coll_dev = dev if self.is_nccl else None  # tensors of collectives: device memory over RCCL, host memory over gloo
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, vals):
+        if self.world == 1:
+            return [float(v) for v in vals]
+        tt = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in tt.cpu().tolist()]
+
+
+class MsmInputs:
+    """One rank's shard of a synthetic MSM: bases P_i = k_i G with known 63-bit k_i from the device generator (resident in HBM), two
+    different scalar vectors (consecutive steps of a pipelined batch alternate between them, so a cross-job buffer race in the
+    three-stream pipeline cannot hide behind identical inputs), and the exact expected answers (sum s_i k_i mod r) G -- of this shard
+    and of all shards together -- from one O(n) dot product per vector."""
+
+    def __init__(self, R: Run, n: int, seed: int, curve=None, r_mod: int = R_BLS, bits: int = 255):
+        from openzl_amd import ZL_BLS12_381
+        from openzl_amd.selfcheck import dot_mod_r, expected_point
+
+        torch, be = R.torch, R.be
+        self.R, self.n, self.curve = R, n, curve or ZL_BLS12_381
+        rng = np.random.Generator(np.random.PCG64(seed * 7919 + 1000 + R.rank))
+        self.k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+        k = np.zeros((n, 4), dtype=np.uint64)
+        k[:, 0] = self.k64
+        t0 = time.perf_counter()
+        self.h = be.bases_generate(self.curve, k)
+        self.t_generate = time.perf_counter() - t0
+        del k
+        self.vecs = [random_scalars_lt_r(n, seed * 7919 + 2000 + R.rank, r_mod, bits), random_scalars_lt_r(n, seed * 7919 + 4000 + R.rank, r_mod, bits)]
+        if R.args.scalars == "skewed":
+            self.vecs = [skewed(v) for v in self.vecs]
+        self.d_vecs = [torch.from_numpy(v.view(np.int64)).to(R.dev) for v in self.vecs]
+        torch.cuda.synchronize()
+        self.dots = [dot_mod_r(v, self.k64, r_mod) for v in self.vecs]
+        self.exp_xy = [expected_point(be, self.curve, d) for d in self.dots]   # this rank's shard
+        self.exp_all = self.exp_xy                                              # all ranks together
+        if R.world > 1:
+            mine = torch.tensor([(d >> (32 * j)) & 0xFFFFFFFF for d in self.dots for j in range(8)], dtype=torch.int64, device=R.coll_dev)
+            allv = torch.empty(R.world * 16, dtype=torch.int64, device=mine.device)
+            R.dist.all_gather_into_tensor(allv, mine)
+            allv = allv.cpu().numpy().reshape(R.world, 2, 8)
+            tot = [sum(sum(int(allv[g, j, w]) << (32 * w) for w in range(8)) for g in range(R.world)) % r_mod for j in (0, 1)]
+            self.exp_all = [expected_point(be, self.curve, d) for d in tot]
+
+    def free(self):
+        if self.h is not None:
+            self.R.be.bases_free(self.h)
+            self.h = None
+        self.d_vecs = []
+        self.R.torch.cuda.empty_cache()
+
+
+def msm_leg(R: Run, inp: MsmInputs, steps: int, warmup: int, pipelined: bool, solo: bool, what: str):
+    """Gate (exact, full size, both scalar vectors, single call + pipelined batch + all ranks) -> `warmup` untimed steps -> EXACTLY `steps`
+    timed steps between barriers, max over ranks -> every timed step checked exactly.  solo (N > 1): the same `steps` local MSMs on
+    rank 0 alone while the other ranks wait: the N = 1 reference of the same per-GPU size for per_gpu_efficiency."""
+    from openzl_amd.sharded import fold_partials, sharded_msm, sharded_msm_batch
+
+    be, n, h, d_vecs, curve = R.be, inp.n, inp.h, inp.d_vecs, inp.curve
+
+    def fail(msg):
+        raise SystemExit(f"MSM self-check failed ({what}; {msg}): result != (sum s_i k_i) G at full size")
+
+    def step(j=0):
+        # local Pippenger -> 1 partial sum; N > 1: all_gather over RCCL + fold on every rank (openzl_amd/sharded.py)
+        return sharded_msm(lambda: be.msm_partial_dev(h, d_vecs[j].data_ptr(), n), curve, device=R.coll_dev)
+
+    def local_batch(cnt):
+        # cnt MSMs as ONE pipelined batch (zl_msm_batch_partial_dev: sort of step i+2 | accumulation of step i+1 | tail of step i on three streams)
+        return be.msm_batch_partial_dev(h, [d_vecs[i % 2].data_ptr() for i in range(cnt)], n)
+
+    def steps_pipelined(cnt):
+        # every step a complete MSM with its own result; N > 1: one all_gather of the K partials per rank, K folds
+        return sharded_msm_batch(local_batch(cnt), curve, device=R.coll_dev)
+
+    # ---- correctness gate before timing: the exact configuration that is timed, at full size, both scalar vectors ----------------------
+    for j in (0, 1):
+        xy_j, inf_j = fold_partials(curve, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
+        if inf_j or not (np.asarray(xy_j) == inp.exp_xy[j]).all():
+            fail("single call")
+    if R.world > 1:  # the folded all-rank result must be (sum over ALL shards of s_i k_i) G
+        for j in (0, 1):
+            xy_j, inf_j = step(j)
+            if inf_j or not (np.asarray(xy_j) == inp.exp_all[j]).all():
+                fail("all ranks, single call")
+    pipelined = pipelined and steps > 1
+    if pipelined:
+        # setup, untimed like the base upload: one 3-deep batch creates the side streams and grows all three buffer sets
+        for i, part in enumerate(local_batch(3)):
+            xy_i, inf_i = fold_partials(curve, part.reshape(1, -1))
+            if inf_i or not (np.asarray(xy_i) == inp.exp_xy[i % 2]).all():
+                fail("pipelined batch")
+        if warmup:
+            steps_pipelined(warmup)
+    else:
+        for _ in range(warmup):
+            step()
+    dom_ms, tot_ms = [], []
+    R.barrier()
+    t0 = time.perf_counter()
+    if pipelined:
+        results = steps_pipelined(steps)
+        tm = be.last_timing()
+        dom_ms.append(tm.dominant_ms)   # mean accumulation-kernel duration over the K steps (HIP events on its stream)
+        tot_ms.append(tm.total_ms)      # device time per step, pipelined
+    else:
+        results = []
+        for i in range(steps):
+            results.append(step(i % 2))
+            tm = be.last_timing()
+            dom_ms.append(tm.dominant_ms)
+            tot_ms.append(tm.total_ms)
+    R.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = be.last_timing()
+    for i, (xy_i, inf_i) in enumerate(results):  # every timed step is checked exactly (N > 1: against the sum over all shards)
+        if inf_i or not (np.asarray(xy_i) == inp.exp_all[i % 2]).all():
+            fail("timed step")
+    elapsed = R.max_over_ranks([elapsed])[0]
+    # latency of one un-pipelined MSM call, for the record
+    R.torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
+    single_ms = (time.perf_counter() - t1) * 1e3
+    single_dev = be.last_timing()
+    out = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "dom_ms": float(np.mean(dom_ms)), "tot_ms": float(np.mean(tot_ms)),
+           "window_bits": int(tm.window_bits), "entries": float(tm.entries), "pipelined": pipelined,
+           "single_call_latency_ms": single_ms, "single_call_device_ms": float(single_dev.total_ms)}
+    if solo and R.world > 1:
+        # the same per-GPU work on ONE GPU with the others idle (rank 0, same process, same inputs, no collective): the N = 1 reference
+        R.barrier()
+        solo_ms = 0.0
+        if R.rank == 0:
+            t2 = time.perf_counter()
+            if pipelined:
+                local_batch(steps)
+            else:
+                for i in range(steps):
+                    be.msm_partial_dev(h, d_vecs[i % 2].data_ptr(), n)
+            R.torch.cuda.synchronize()
+            solo_ms = (time.perf_counter() - t2) / steps * 1e3
+        R.barrier()
+        out["solo_ms_per_step"] = R.max_over_ranks([solo_ms])[0]
+    return out
+
+
+def scaling_entry(R: Run, name: str, total_desc: str, n_local: int, leg: dict, steps: int):
+    tot = float(n_local) * R.world  # (ragged totals: every rank reports its own n; the legs below use equal shards)
+    e = {"points_total": tot, "points_per_gpu": n_local, "what": total_desc, "ms_per_step": leg["ms_per_step"], "points_per_s": tot * steps / leg["elapsed"],
+         "window_bits": leg["window_bits"], "kernel_ms": leg["dom_ms"], "checked_exactly": True,
+         "result_check": "gate + every timed step equal (sum over ALL shards of s_i k_i) G exactly"}
+    if "solo_ms_per_step" in leg:
+        e["single_gpu_ms_per_step"] = leg["solo_ms_per_step"]
+        e["per_gpu_efficiency"] = leg["solo_ms_per_step"] / leg["ms_per_step"]
+        e["efficiency_note"] = "time of the same per-GPU MSMs on rank 0 alone (same process, same inputs, other ranks idle, no collective) / time with all ranks + all_gather + fold"
+    return e
+
+
+def config1_leg(R: Run, no_cpu: bool):
+    """BASELINE config 1: 2^16 BN254 G1 variable-base MSM -- GPU single call / pipelined, exact against the known discrete logs, and (cpu_baseline
+    part) the CPU oracle single-threaded on the same bases and scalars (the reference's CPU path as configured), results equal bit for bit."""
+    from openzl_amd import ZL_BN254
+
+    be, torch = R.be, R.torch
+    n = 1 << 16
+    inp = MsmInputs(R, n, 16, curve=ZL_BN254, r_mod=R_BN, bits=254)
+    try:
+        d = inp.d_vecs[0]
+        for _ in range(3):
+            xy, inf = be.msm_dev(inp.h, d.data_ptr(), n)
+        if inf or not (np.asarray(xy) == inp.exp_xy[0]).all():
+            raise SystemExit("config 1 self-check failed: 2^16 BN254 MSM != (sum s_i k_i) G")
+        ts, dv = [], []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            be.msm_dev(inp.h, d.data_ptr(), n)
+            ts.append(time.perf_counter() - t0)
+            dv.append(be.last_timing().total_ms)
+        tm = be.last_timing()
+        be.msm_batch_partial_dev(inp.h, [inp.d_vecs[i % 2].data_ptr() for i in range(6)], n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        be.msm_batch_partial_dev(inp.h, [inp.d_vecs[i % 2].data_ptr() for i in range(6)], n)
+        batch_ms = (time.perf_counter() - t0) / 6 * 1e3
+        out = {"config": "2^16 BN254 G1 variable-base MSM", "gpu_single_call_ms": float(np.min(ts)) * 1e3, "gpu_single_call_median_ms": float(np.median(ts)) * 1e3,
+               "gpu_device_ms": float(np.median(dv)), "gpu_pipelined_ms_per_msm": batch_ms, "window_bits": int(tm.window_bits),
+               "gpu_points_per_s": n / float(np.min(ts)), "checked_exactly": True}
+        if not no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as ol
+            from oracle_lib import po
+
+            bases = be.bases_download(inp.h)
+            cxy, cinf, sec = ol.oracle_msm_g1_timed(po.BN254, bases, inp.vecs[0], algo=0, threads=1)
+            if cinf or not (np.asarray(cxy) == np.asarray(xy)).all():
+                raise SystemExit("config 1 parity check failed: the CPU oracle's 2^16 BN254 MSM differs from the GPU result")
+            out["cpu_baseline"] = {"value": n / sec, "unit": "points/s", "cores": 1, "kind": "port", "ms": sec * 1e3,
+                                   "sample": "the complete 2^16 input, single thread, ark window rule (c = 13): the reference's CPU configuration", "parity_full_size": True}
+        return out
+    finally:
+        inp.free()
+
+
+def config2_leg(R: Run):
+    """BASELINE config 2: 2^20 BLS12-381 G1 MSM on one GPU: single call, pipelined batch, integer-ALU fraction of the WHOLE call."""
+    be, torch = R.be, R.torch
+    n = 1 << 20
+    inp = MsmInputs(R, n, 20)
+    try:
+        leg = msm_leg(R, inp, 6, 2, True, False, "config 2")
+        d = inp.d_vecs[0]
+        ts, dv, ac = [], [], []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            be.msm_partial_dev(inp.h, d.data_ptr(), n)
+            ts.append(time.perf_counter() - t0)
+            tm = be.last_timing()
+            dv.append(tm.total_ms)
+            ac.append(tm.dominant_ms)
+        single = float(np.min(ts)) * 1e3
+        mul_eq = float(tm.entries) * MULS_PER_MIXED_ADD
+        return {"config": "2^20 BLS12-381 G1 MSM, uniform scalars < r, bases k_i G resident", "single_call_ms": single, "single_call_median_ms": float(np.median(ts)) * 1e3,
+                "single_call_device_ms": float(np.median(dv)), "kernel_ms": float(np.median(ac)), "pipelined_ms_per_msm": leg["ms_per_step"],
+                "window_bits": int(tm.window_bits), "points_per_s_single": n / (single * 1e-3), "points_per_s_pipelined": n / (leg["ms_per_step"] * 1e-3),
+                "int_alu_frac_single_call": mul_eq / (single * 1e-3) / 1e9 / FQ_MUL_PEAK_G, "int_alu_frac_pipelined": mul_eq / (leg["ms_per_step"] * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
+                "int_alu_frac_kernel": mul_eq / (float(np.median(ac)) * 1e-3) / 1e9 / FQ_MUL_PEAK_G, "checked_exactly": True,
+                "note": "int_alu_frac_* = (point, window) pairs x 9.04 multiplication-equivalents / time / the multiplier's standalone rate (78.6 G/s): whole call wall time, "
+                        "pipelined time per MSM, accumulation kernel alone"}
+    finally:
+        inp.free()
+
+
+def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup):
+    """ONE process, G devices: zl_ctx_create_multi (RCCL communicator inside the library when the devices are distinct) + zl_msm_sharded
+    (complete local Pippenger per device on its own host thread -> ncclAllGather of the partials -> fold) and zl_ntt_sharded (cross step ->
+    grouped ncclSend / ncclRecv all-to-all -> local transform).  Returns the result dict; every MSM result is checked exactly."""
+    import torch
+    from openzl_amd import ZL_BLS12_381
+    from openzl_amd.backend import MultiBackend
+    from openzl_amd.selfcheck import dot_mod_r, expected_point
+
+    mb = MultiBackend(devices)
+    G = mb.size
+    n = 1 << log_n
+    hs, d_s, dots = [], [], [0, 0]
+    try:
+        for g in range(G):
+            dev = torch.device("cuda", devices[g])
+            rng = np.random.Generator(np.random.PCG64(77000 + g))
+            k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+            k = np.zeros((n, 4), dtype=np.uint64)
+            k[:, 0] = k64
+            hs.append(mb.ranks[g].bases_generate(ZL_BLS12_381, k))
+            vs = [random_scalars_lt_r(n, 78000 + 2 * g), random_scalars_lt_r(n, 78001 + 2 * g)]
+            d_s.append([torch.from_numpy(v.view(np.int64)).to(dev) for v in vs])
+            for j in (0, 1):
+                dots[j] = (dots[j] + dot_mod_r(vs[j], k64, R_BLS)) % R_BLS
+            del k, vs
+        for g in set(devices):
+            torch.cuda.synchronize(g)
+        exp = [expected_point(mb.ranks[0], ZL_BLS12_381, d) for d in dots]
+
+        def call(j):
+            return mb.msm_sharded(hs, [d_s[g][j].data_ptr() for g in range(G)], [n] * G)
+
+        for j in (0, 1):
+            xy, inf = call(j)
+            if inf or not (np.asarray(xy) == exp[j]).all():
+                raise SystemExit("zl_msm_sharded self-check failed: result != (sum over all shards of s_i k_i) G")
+        for i in range(warmup):
+            call(i % 2)
+        t0 = time.perf_counter()
+        res = [call(i % 2) for i in range(steps)]
+        el = time.perf_counter() - t0
+        for i, (xy, inf) in enumerate(res):
+            if inf or not (np.asarray(xy) == exp[i % 2]).all():
+                raise SystemExit("zl_msm_sharded self-check failed (timed step)")
+        # the same per-GPU MSM on rank 0's ctx alone (single calls, as zl_msm_sharded issues them)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            mb.ranks[0].msm_partial_dev(hs[0], d_s[0][i % 2].data_ptr(), n)
+        solo = (time.perf_counter() - t1) / steps
+        out = {"transport": "mctx: one process, zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded (include/zl_backend.h)", "n_gpus": G, "devices": list(devices),
+               "rccl_ranks": G if mb.uses_rccl else 0, "exchange": "RCCL (ncclCommInitAll; ncclAllGather / grouped ncclSend+ncclRecv)" if mb.uses_rccl else
+               "virtual ranks sharing a device: device-to-device copies with the same data movement pattern (RCCL refuses duplicate devices)",
+               "msm": {"points_per_gpu": n, "points_total": float(n) * G, "steps": steps, "ms_per_step": el / steps * 1e3, "points_per_s": float(n) * G * steps / el,
+                       "single_gpu_ms_per_step": solo * 1e3, "per_gpu_efficiency": solo / (el / steps), "checked_exactly": True,
+                       "issued_as": "separate zl_msm_sharded calls (not pipelined)"}}
+        for hh, r in zip(hs, mb.ranks):
+            r.bases_free(hh)
+        hs, d_s = [], []
+        torch.cuda.empty_cache()
+        log_g = G.bit_length() - 1
+        if ntt_log_m and (1 << log_g) == G and 1 <= log_g <= 4 and 2 * log_g <= ntt_log_m + log_g:
+            M = 1 << ntt_log_m
+            xs = [random_scalars_lt_r(M, 79000 + g) for g in range(G)]
+            dx = [torch.from_numpy(x.view(np.int64)).to(torch.device("cuda", devices[g])) for g, x in enumerate(xs)]
+            ptrs = [t.data_ptr() for t in dx]
+            f_ms, i_ms = [], []
+            for it in range(1 + 3):
+                for inverse, acc in ((False, f_ms), (True, i_ms)):
+                    for g in set(devices):
+                        torch.cuda.synchronize(g)
+                    t0 = time.perf_counter()
+                    mb.ntt_sharded(ZL_BLS12_381, ptrs, ntt_log_m + log_g, inverse=inverse, mont=True)
+                    if it:
+                        acc.append((time.perf_counter() - t0) * 1e3)
+            ok = all(bool((t.cpu().numpy().view(np.uint64) == x).all()) for t, x in zip(dx, xs))
+            if not ok:
+                raise SystemExit("zl_ntt_sharded self-check failed: iNTT(NTT(x)) != x")
+            tot = float(M) * G
+            out["ntt"] = {"log_n": ntt_log_m + log_g, "elements_per_gpu": M, "forward_ms": float(np.mean(f_ms)), "inverse_ms": float(np.mean(i_ms)),
+                          "forward_elems_per_s": tot / (float(np.mean(f_ms)) * 1e-3), "inverse_elems_per_s": tot / (float(np.mean(i_ms)) * 1e-3),
+                          "self_check": "iNTT(NTT(x)) == x on every rank; bit-exact parity of the entry point in tests/test_gpu_multi.py"}
+        return out
+    finally:
+        for hh, r in zip(hs, mb.ranks):
+            try:
+                r.bases_free(hh)
+            except Exception:  # noqa: BLE001
+                pass
+        mb.close()
+
+
+def main_mctx(args):
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    devices = [int(x) for x in args.mctx_devices.split(",")] if args.mctx_devices else list(range(args.gpus))
+    res = mctx_run(args, devices, args.log_n, 0 if args.no_ntt else args.ntt_log_n, args.steps, args.warmup)
+    m = res["msm"]
+    line = {"metric": "MSM points/sec (BLS12-381 G1)", "value": m["points_per_s"], "unit": "points/s", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"bls12_381_g1_msm_2^{args.log_n}_per_gpu", "points_per_gpu": 1 << args.log_n, "parallelism": f"mctx{len(devices)}",
+                       "transport": res["transport"]}, "mctx": res}
+    print(json.dumps(line), flush=True)
+
+
+def mctx_child(args, devices, timeout_s=240):
+    """time the one-process transport in a child process (this process may still hold a process group / its GPU); fail-soft"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_ENV}
+    cmd = [sys.executable, os.path.abspath(__file__), "--transport", "mctx", "--gpus", str(len(devices)), "--mctx-devices", ",".join(str(d) for d in devices),
+           "--log-n", str(args.log_n), "--ntt-log-n", str(args.ntt_log_n), "--steps", str(max(2, min(args.steps, 6))), "--warmup", "1"]
+    if args.no_ntt:
+        cmd.append("--no-ntt")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not rows:
+            return {"error": f"child exited with {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        return json.loads(rows[-1])["mctx"]
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=24, help="log2 points per GPU (BASELINE metric: 24; config 4 at 8 GPUs: 23)")
+    ap.add_argument("--log-n", type=int, default=24, help="log2 points per GPU of the headline (BASELINE metric: 24)")
     ap.add_argument("--window", type=int, default=0, help="force the Pippenger window width (0 = auto)")
     ap.add_argument("--fixed-key", type=int, default=22,
                     help="window width of the precomputed-table mode reported BESIDE the headline as msm_fixed_key (zl_bases_precompute: "
@@ -263,98 +670,58 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-skew", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1 / 2 / 4 legs (N = 1) and the config-4 / strong-scaling legs (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="issue the K steps as K separate calls instead of one pipelined batch")
     ap.add_argument("--scalars", choices=["uniform", "skewed"], default="uniform", help="skewed: 50%% zeros, 25%% ones, rest uniform (profiling aid)")
     ap.add_argument("--ntt-log-n", type=int, default=24)
     ap.add_argument("--groth16-k", type=int, default=4096, help="config 5: chained Poseidon hashes (4096 -> domain 2^20); 0 = skip")
+    ap.add_argument("--transport", choices=["ranks", "mctx"], default="ranks",
+                    help="ranks: one process per GPU over torch.distributed (RCCL); mctx: ONE process, zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded")
+    ap.add_argument("--mctx-devices", default="", help="mctx: comma-separated device ids (may repeat: virtual ranks on one GPU); default 0..N-1")
+    ap.add_argument("--config4-log-total", type=int, default=26, help="N > 1: total points of the config-4 leg (BASELINE: 2^26 over 8 GPUs)")
+    ap.add_argument("--strong-log-total", type=int, default=24, help="N > 1: total points of the strong-scaling leg")
+    ap.add_argument("--no-mctx", action="store_true", help="N > 1: skip the child-process run of the one-process transport")
     args = ap.parse_args()
+
+    if args.transport == "mctx":
+        return main_mctx(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
     from openzl_amd import Backend, ZL_BLS12_381
     from openzl_amd.selfcheck import dot_mod_r, expected_point
+    from openzl_amd.sharded import fold_partials
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` or with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    if os.environ.get("ZL_DIST_BACKEND", "nccl") != "nccl":
+    is_nccl = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
+    if not is_nccl:
         local_rank = local_rank % torch.cuda.device_count()  # test mode: ranks may share a GPU
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # nccl = RCCL over xGMI.  ZL_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a single-GPU box.
-        backend = os.environ.get("ZL_DIST_BACKEND", "nccl")
-        if backend == "nccl":
+        if is_nccl:
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=os.environ["ZL_DIST_BACKEND"])
 
     be = Backend(local_rank)
     be.enable_timing(True)
     if args.window:
         be.set_msm_window(args.window)
     n = 1 << args.log_n
-
-    # ---- synthetic inputs, generated per rank, resident in HBM before the timed region ---------------------------
-    # bases P_i = k_i * G with 63-bit k_i (device generator): known discrete logs make every full-size result checkable exactly
-    rng = np.random.Generator(np.random.PCG64(1000 + rank))
-    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-    k = np.zeros((n, 4), dtype=np.uint64)
-    k[:, 0] = k64
-    t0 = time.perf_counter()
-    h = be.bases_generate(ZL_BLS12_381, k)
-    t_generate = time.perf_counter() - t0
-    del k
-    # two different scalar vectors: consecutive steps of the pipelined batch alternate between them, so a cross-job buffer race in the
-    # three-stream pipeline cannot hide behind identical inputs
-    vecs = [random_scalars_lt_r(n, 2000 + rank), random_scalars_lt_r(n, 4000 + rank)]
-    if args.scalars == "skewed":
-        vecs = [skewed(v) for v in vecs]
-    d_vecs = [torch.from_numpy(v.view(np.int64)).to(dev) for v in vecs]
-    torch.cuda.synchronize()
-    # exact expected answers at FULL size: (sum s_i k_i mod r) * G -- one O(n) dot product per vector, one point from the device generator
-    dots = [dot_mod_r(v, k64, R_BLS) for v in vecs]
-    exp_xy = [expected_point(be, ZL_BLS12_381, d) for d in dots]   # this rank's shard
-    exp_all = exp_xy                                                # all ranks together (N > 1: sum of the shard dot products mod r)
-    if world > 1:
-        is_nccl0 = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
-        mine = torch.tensor([(d >> (32 * j)) & 0xFFFFFFFF for d in dots for j in range(8)], dtype=torch.int64, device=dev if is_nccl0 else None)
-        allv = torch.empty(world * 16, dtype=torch.int64, device=mine.device)
-        dist.all_gather_into_tensor(allv, mine)
-        allv = allv.cpu().numpy().reshape(world, 2, 8)
-        tot = [sum(sum(int(allv[g, j, w]) << (32 * w) for w in range(8)) for g in range(world)) % R_BLS for j in (0, 1)]
-        exp_all = [expected_point(be, ZL_BLS12_381, d) for d in tot]
-
-    def check(xy, inf, j, what):
-        if inf or not (np.asarray(xy) == exp_xy[j]).all():
-            raise SystemExit(f"MSM self-check failed ({what}): result != (sum s_i k_i) G at full size")
-
-    from openzl_amd.sharded import fold_partials, sharded_msm, sharded_msm_batch
-
-    gather_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
-
-    def step(j=0):
-        # local Pippenger -> 1 partial sum; N > 1: all_gather over RCCL + fold on every rank (openzl_amd/sharded.py)
-        return sharded_msm(lambda: be.msm_partial_dev(h, d_vecs[j].data_ptr(), n), ZL_BLS12_381, device=gather_dev)
-
-    def local_batch(cnt):
-        # cnt MSMs as ONE pipelined batch (zl_msm_batch_partial_dev: sort of step i+2 | accumulation of step i+1 | tail of step i on three streams)
-        return be.msm_batch_partial_dev(h, [d_vecs[i % 2].data_ptr() for i in range(cnt)], n)
-
-    def steps_pipelined(cnt):
-        # every step a complete MSM with its own result; N > 1: one all_gather of the K partials per rank, K folds
-        return sharded_msm_batch(local_batch(cnt), ZL_BLS12_381, device=gather_dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    R = Run(args, torch, dist, be, dev, rank, world)
 
     leg_errors = {}
 
@@ -370,60 +737,23 @@ def main():
             leg_errors[name] = f"{type(e).__name__}: {e}"
             print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
-    # ---- correctness gate before timing: the exact configuration that is timed, at full size, both scalar vectors ----------------------
-    for j in (0, 1):
-        xy_j, inf_j = fold_partials(ZL_BLS12_381, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
-        check(xy_j, inf_j, j, "single call")
-    if world > 1:  # the folded all-rank result must be (sum over ALL shards of s_i k_i) G
-        for j in (0, 1):
-            xy_j, inf_j = step(j)
-            if inf_j or not (np.asarray(xy_j) == exp_all[j]).all():
-                raise SystemExit("MSM self-check failed (all ranks, single call): result != (sum s_i k_i) G")
-    pipelined = not args.no_pipeline and args.steps > 1
-    if pipelined:
-        # setup, untimed like the base upload: one 3-deep batch creates the side streams and grows all three buffer sets
-        for i, part in enumerate(local_batch(3)):
-            xy_i, inf_i = fold_partials(ZL_BLS12_381, part.reshape(1, -1))
-            check(xy_i, inf_i, i % 2, "pipelined batch")
-        if args.warmup:
-            steps_pipelined(args.warmup)
-    else:
-        for _ in range(args.warmup):
-            step()
-    dom_ms, tot_ms = [], []
-    barrier()
-    t0 = time.perf_counter()
-    if pipelined:
-        results = steps_pipelined(args.steps)
-        tm = be.last_timing()
-        dom_ms.append(tm.dominant_ms)   # mean accumulation-kernel duration over the K steps (HIP events on its stream)
-        tot_ms.append(tm.total_ms)      # device time per step, pipelined
-    else:
-        results = []
-        for i in range(args.steps):
-            results.append(step(i % 2))
-            tm = be.last_timing()
-            dom_ms.append(tm.dominant_ms)
-            tot_ms.append(tm.total_ms)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # ---- the headline: synthetic inputs generated per rank, resident in HBM before the timed region; gate; K timed steps ------------------
+    inp = MsmInputs(R, n, 0)
+    h, k64, vecs, d_vecs, exp_xy = inp.h, inp.k64, inp.vecs, inp.d_vecs, inp.exp_xy
+    t_generate = inp.t_generate
+    head = msm_leg(R, inp, args.steps, args.warmup, not args.no_pipeline, True, "headline")
+    elapsed, pipelined, single_ms = head["elapsed"], head["pipelined"], head["single_call_latency_ms"]
     tm = be.last_timing()
-    for i, (xy_i, inf_i) in enumerate(results):  # every timed step is checked exactly (N > 1: against the sum over all shards)
-        if inf_i or not (np.asarray(xy_i) == exp_all[i % 2]).all():
-            raise SystemExit("MSM self-check failed (timed step): result != (sum s_i k_i) G at full size")
-    # latency of one un-pipelined MSM call, for the record
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
-    single_ms = (time.perf_counter() - t1) * 1e3
-    single_dev = be.last_timing()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    def check(xy, inf, j, what):
+        if inf or not (np.asarray(xy) == exp_xy[j]).all():
+            raise SystemExit(f"MSM self-check failed ({what}): result != (sum s_i k_i) G at full size")
+
+    def local_batch(cnt):
+        return be.msm_batch_partial_dev(h, [d_vecs[i % 2].data_ptr() for i in range(cnt)], n)
+
     s_host = vecs[0]
     d_scalars = d_vecs[0]
-
     # ---- PCIe-inclusive rate (SURVEY.md §8d config 2's timed region: scalars from host memory + kernels + result; never `value`) ---------
     pcie_info = None
     def _leg_pcie_info():
@@ -658,21 +988,50 @@ def main():
     if not args.no_cpu and rank == 0 and world == 1:
         _guard("cpu", _leg_cpu)
 
+    # ---- BASELINE configs 1, 2, 4 on the N = 1 line (3 = ntt, 5 = groth16 above) -------------------------------------------------------------
+    configs = {}
+    if rank == 0 and world == 1 and not args.no_configs:
+        def _leg_c1():
+            configs["1"] = config1_leg(R, args.no_cpu)
+
+        def _leg_c2():
+            configs["2"] = config2_leg(R)
+
+        def _leg_c4():
+            # 2^26 = 8 x 2^23 through the sharded entry point with 8 virtual ranks on this one GPU: functional (exact) check of the whole
+            # config-4 data path; its multi-GPU throughput needs N > 1 (scaling.config4 on that line)
+            shard_log = 23 if args.log_n >= 24 else max(10, args.log_n - 3)
+            r4 = mctx_run(args, [local_rank] * 8, shard_log, 0, 2, 1)
+            m4 = r4["msm"]
+            configs["4"] = {"config": f"2^{shard_log + 3} BLS12-381 G1 MSM as 8 shards of 2^{shard_log} (zl_msm_sharded, 8 virtual ranks on ONE GPU)",
+                            "functional": True, "checked_exactly": True, "ms_per_msm_on_one_gpu": m4["ms_per_step"], "points_per_s_on_one_gpu": m4["points_per_s"],
+                            "multi_gpu_throughput": "not measured at N = 1 (see scaling.config4 of a --gpus N run)", "exchange": r4["exchange"]}
+
+        _guard("config1", _leg_c1)
+        _guard("config2", _leg_c2)
+        _guard("config4", _leg_c4)
+        configs["3"] = "see ntt (2^24 BLS12-381 Fr forward + inverse)"
+        configs["5"] = "see groth16 (Poseidon hash-chain circuit, 958 465 constraints)"
+
     if rank == 0:
         pts = float(n) * world * args.steps
         value = pts / elapsed
-        dom = float(np.mean(dom_ms))
+        dom = head["dom_ms"]
         achieved = 128.0 * n / (dom * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration, null otherwise
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            if args.log_n == int(pmc["log_n"]) and int(tm.window_bits) == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
-                traffic = pmc["k_msm_accumulate_traffic_bytes"]
-        except Exception:
-            traffic = None
-        cw = int(tm.window_bits)
+        traffic_src = None
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if args.log_n == int(pmc["log_n"]) and head["window_bits"] == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
+                    traffic = pmc["k_msm_accumulate_traffic_bytes"]
+                    traffic_src = cand
+                    break
+            except Exception:
+                continue
+        cw = head["window_bits"]
         line = {
             "metric": "MSM points/sec (BLS12-381 G1)",
             "value": value,
@@ -694,24 +1053,25 @@ def main():
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "steps_issued_as": "one pipelined batch (zl_msm_batch_partial_dev): sort | accumulate | tail of consecutive steps overlap on three streams; "
                                           "consecutive steps alternate between two scalar vectors" if pipelined else "separate calls",
-                       "single_call_latency_ms": single_ms, "single_call_device_ms": float(single_dev.total_ms),
+                       "single_call_latency_ms": single_ms, "single_call_device_ms": head["single_call_device_ms"],
                        "bases_generate_s": t_generate,
                        "result_check": "every timed step equals (sum s_i k_i) G exactly at full size (known discrete logs); the CPU oracle's MSM of the "
                                        "complete input equals it too (cpu_baseline.parity_full_size)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json; null for any other configuration)",
+                         "traffic": traffic, "traffic_unit": f"bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src or 'rNN_pmc_traffic.json'}; null for any other configuration)",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
-                         "int_alu": {"unit": "G Fq-mul/s", "achieved": float(tm.entries) * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
-                                     "frac": float(tm.entries) * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
+                         "int_alu": {"unit": "G Fq-mul/s", "achieved": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9, "peak": FQ_MUL_PEAK_G,
+                                     "frac": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_G,
                                      "mads_per_mixed_add": MADS_PER_MIXED_ADD, "muls_per_mixed_add": MULS_PER_MIXED_ADD,
                                      "note": "the roofline that actually binds: (point, window) pairs x 9.04 multiplication-equivalents per mixed add "
-                                             "(6M + 2S + one dual product scan with a shared Montgomery reduction = 6 x 392 + 2 x 301 + 588 = 3542 v_mad_u64_u32, counted in the kernel's ISA; "
-                                             "rounds 1 and early 2 priced a squaring as a multiplication, 9.5, which overstated this fraction by 5 %) / kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
+                                             "(6M + 2S + one dual product scan with a shared Montgomery reduction = 6 x 392 + 2 x 301 + 588 = 3542 v_mad_u64_u32, counted in the kernel's ISA) "
+                                             "/ kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier "
                                              "at the kernel's occupancy, 3 waves/SIMD (tools/fbench28_asm.hip; profiles/r02_fbench28_asm_occupancy.log)"},
-                         "kernel_ms": dom, "device_total_ms": float(np.mean(tot_ms)),
+                         "kernel_ms": dom, "device_total_ms": head["tot_ms"],
                          "note": "algorithmic bytes = 128 B/point (96 B base + 32 B scalar) x points per launch; the kernel is "
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
             "cpu_baseline": cpu,
+            "configs": configs or None,
             "pcie_inclusive": pcie_info,
             "msm_fixed_key": fixed_info,
             "msm_skewed_scalars": skew_info,
@@ -722,20 +1082,39 @@ def main():
             line["leg_errors"] = leg_errors
     else:
         line = None
-    is_nccl = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
+    inp.free()
     if world > 1:
         # Secondary legs at N > 1, last and under a watchdog: if anything stalls, the MSM line above is still printed.
         import threading
 
         def _give_up():
             if rank == 0:
-                line["secondary_legs_error"] = "timed out after 300 s"
+                line["secondary_legs_error"] = "timed out"
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        dog = threading.Timer(300.0, _give_up)
+        dog = threading.Timer(600.0, _give_up)
         dog.daemon = True
         dog.start()
+        if rank == 0:
+            line["scaling_legs"] = {"weak": scaling_entry(R, "weak", f"2^{args.log_n} points per GPU (the headline)", n, head, args.steps)}
+        if not args.no_configs:
+            # BASELINE config 4 (2^26 points over the ranks; 2^23 per GPU at N = 8) and strong scaling (2^24 points over the ranks):
+            # own inputs per leg, same gate / exact checks / barriers as the headline, plus the single-GPU reference of the same shard size
+            for name, log_total in (("config4", args.config4_log_total), ("strong", args.strong_log_total)):
+                n_loc = max(1 << 10, (1 << log_total) // world)
+                try:
+                    li = MsmInputs(R, n_loc, 40 + log_total)
+                    leg = msm_leg(R, li, args.steps, args.warmup, not args.no_pipeline, True, name)
+                    li.free()
+                    ent, err = scaling_entry(R, name, f"2^{log_total} points in total = {n_loc} per GPU", n_loc, leg, args.steps), 0.0
+                except Exception as e:  # noqa: BLE001 -- (failed self-checks are SystemExit and abort)
+                    ent, err = {"error": f"{type(e).__name__}: {e}"}, 1.0
+                    print(f"[rank {rank}] scaling leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                if R.max_over_ranks([err])[0] != 0.0 and "error" not in ent:
+                    ent = {"error": "a rank failed (see stderr)"}
+                if rank == 0:
+                    line["scaling_legs"][name] = ent
         if args.groth16_k > 0:
             # constraints/s at N GPUs: independent proofs, one per GPU (replicas: a proof does not shard), max-over-ranks time
             try:
@@ -744,13 +1123,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 n_c, t_prove, err = 0, 0.0, 1.0
                 print(f"[rank {rank}] groth16 leg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-            tt = torch.tensor([t_prove, err, float(n_c)], dtype=torch.float64, device=dev if is_nccl else None)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tt = R.max_over_ranks([t_prove, err, float(n_c)])
             if rank == 0:
-                if tt[1].item() == 0.0 and tt[0].item() > 0.0:
+                if tt[1] == 0.0 and tt[0] > 0.0:
                     line["groth16"] = {"metric": "Groth16 prove constraints/sec (BLS12-381, Poseidon arity-2 hash chain, config 5)", "n_gpus": world,
-                                       "scaling": "replicas (one independent proof per GPU)", "hashes": args.groth16_k, "constraints": int(tt[2].item()),
-                                       "prove_ms": tt[0].item() * 1e3, "constraints_per_s": world * tt[2].item() / tt[0].item(), "verified": True}
+                                       "scaling": "replicas (one independent proof per GPU)", "hashes": args.groth16_k, "constraints": int(tt[2]),
+                                       "prove_ms": tt[0] * 1e3, "constraints_per_s": world * tt[2] / tt[0], "verified": True}
                 else:
                     line["groth16"] = {"error": "a rank failed (see stderr)"}
         if is_nccl and not args.no_ntt and (world & (world - 1)) == 0 and world <= 16:
@@ -758,15 +1136,25 @@ def main():
                 dinfo = distributed_ntt_leg(be, dist, torch, dev, rank, world, args.ntt_log_n)
             except Exception as e:  # noqa: BLE001 -- reported in the JSON line, the headline number stands
                 dinfo = {"error": f"{type(e).__name__}: {e}"}
-            if rank == 0:
+            if rank == 0 and line.get("ntt") is not None:
                 line["ntt"]["distributed"] = dinfo
-        dog.cancel()
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    be.bases_free(h)
-    be.close()
-    if world > 1:
+        # all collectives are done: leave the process group; ranks != 0 exit and release their GPUs
+        R.barrier()
+        be.close()
         dist.destroy_process_group()
+        if rank != 0:
+            dog.cancel()
+            return
+        if not args.no_mctx:
+            # the C-ABI transport (one process, zl_ctx_create_multi: ncclCommInitAll inside the library) timed once, in a child process
+            devs = list(range(world)) if is_nccl else [g % torch.cuda.device_count() for g in range(world)]
+            time.sleep(1.0)
+            line["mctx"] = mctx_child(args, devs)
+        dog.cancel()
+        print(json.dumps(line), flush=True)
+        return
+    print(json.dumps(line), flush=True)
+    be.close()
 
 
 if __name__ == "__main__":

@@ -1,8 +1,18 @@
 // zl_capi.hip -- the extern "C" surface declared in include/zl_backend.h (context, bases, MSM, NTT wrappers).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
+#include <thread>
+#include <vector>
 #include "zl_ctx.h"
+#include "zl_pool.h"
+
+zl_pool& zl_pool_get() {
+    static zl_pool pool(std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u));  // + the calling thread
+    return pool;
+}
 
 extern "C" {
 
@@ -62,6 +72,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     for (auto& t : ctx->fb_table) if (t) (void)hipFree(t);
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
     if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
+    if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
     for (zl_ctx** ax : {&ctx->aux, &ctx->aux2}) {
@@ -202,14 +213,69 @@ int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars,
     const zl_bases& b = ctx->bases[bases];
     return ZL_DISPATCH(b.curve, b.group, zl_partial_to_affine, partial, out_xy, out_inf);
 }
+// Host scalars (what VariableBaseMSM::multi_scalar_mul is handed: the witness is new for every proof).  One copy followed by one MSM leaves
+// the whole transfer (32 B / point: 12.6 ms for 2^24 from pageable memory) in front of the first kernel.  Large inputs are therefore cut into
+// a few growing shards of points (2^20, 2^20, 2^21, 2^22, ...): MSM(all) = sum of the shards' MSMs, a helper thread copies shard j + 1 on its
+// own stream while the three-stream pipeline of zl_msm_batch_partial_dev works on the shards before it (each job waits for its copy's
+// event), and only the first, small copy stays exposed.  The shards use the window width of their own size, which costs a few percent
+// more additions than one full-size MSM; measured at 2^24: see bench.py pcie_inclusive.
+static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const uint64_t* scalars, size_t n, void* d_sc, uint64_t* out_xy, uint8_t* out_inf) {
+    std::vector<size_t> off, len;
+    size_t done = 0, step = (size_t)1 << 20;
+    while (done < n) {
+        size_t l = std::min(step, n - done);
+        if (n - done - l < step / 2) l = n - done;  // no tiny last shard
+        off.push_back(done);
+        len.push_back(l);
+        done += l;
+        if (off.size() >= 2) step <<= 1;
+    }
+    const size_t K = off.size();
+    if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+    std::vector<hipEvent_t> ev(K, nullptr);
+    for (size_t j = 0; j < K; j++) {
+        const hipError_t e = hipEventCreateWithFlags(&ev[j], hipEventDisableTiming);
+        if (e != hipSuccess) { for (auto x : ev) if (x) (void)hipEventDestroy(x); ctx->last_hip = (int)e; return ZL_EHIP; }
+    }
+    std::atomic<int> recorded{0};
+    const int dev = ctx->device;
+    hipStream_t sc = ctx->stream_copy;
+    std::thread copier([&]() {
+        hipError_t e = hipSetDevice(dev);
+        for (size_t j = 0; j < K && e == hipSuccess; j++) {
+            // from pageable memory this call stages through the runtime's pinned buffers and returns when the last piece is queued
+            e = hipMemcpyAsync(reinterpret_cast<unsigned char*>(d_sc) + off[j] * 32, reinterpret_cast<const unsigned char*>(scalars) + off[j] * 32, len[j] * 32,
+                               hipMemcpyHostToDevice, sc);
+            if (e == hipSuccess) e = hipEventRecord(ev[j], sc);
+            if (e == hipSuccess) recorded.store((int)j + 1, std::memory_order_release);
+        }
+        if (e != hipSuccess) recorded.store(-1, std::memory_order_release);
+    });
+    std::vector<const zl_bases*> jb(K, &b);
+    std::vector<size_t> jf(K), jn(K);
+    std::vector<const void*> js(K);
+    for (size_t j = 0; j < K; j++) { jf[j] = first + off[j]; jn[j] = len[j]; js[j] = reinterpret_cast<unsigned char*>(d_sc) + off[j] * 32; }
+    std::vector<uint64_t> parts(K * ZL_PARTIAL_WORDS);
+    int rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_jobs, ctx, jb.data(), jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded);
+    copier.join();
+    (void)hipStreamSynchronize(sc);
+    for (auto x : ev) (void)hipEventDestroy(x);
+    if (rc) return rc;
+    return zl_partials_sum((zl_curve_t)b.curve, (zl_group_t)b.group, parts.data(), K, out_xy, out_inf);
+}
+
 int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!ctx || !out_xy || (!scalars && n)) return ZL_EINVAL;
-    if (ctx->bases.find(bases) == ctx->bases.end()) return ZL_EHANDLE;
+    auto it = ctx->bases.find(bases);
+    if (it == ctx->bases.end()) return ZL_EHANDLE;
+    if (first > it->second.n || n > it->second.n - first) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     void* d_sc = nullptr;
     if (n) {
         int rc = zl_scratch_get(ctx, 7, n * 32, &d_sc);
         if (rc) return rc;
+        // the window table of a precomputed handle is built for full-size MSMs over it; shards would each pay its merged bucket set
+        if (n >= ((size_t)1 << 22) && it->second.precomp_c == 0 && !getenv("ZL_NO_HOST_CHUNKS")) return msm_host_chunked(ctx, it->second, first, scalars, n, d_sc, out_xy, out_inf);
         ZL_HIP(ctx, hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     return zl_msm_dev(ctx, bases, first, d_sc, n, out_xy, out_inf);

@@ -260,7 +260,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             const size_t jn[4] = {(size_t)nw, (size_t)nv - 1, (size_t)nv - 1, (size_t)N - 1};
             const hipEvent_t jw[4] = {nullptr, nullptr, nullptr, ev_h};
             uint64_t jp[4][ZL_PARTIAL_WORDS];
-            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0]);
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)nullptr);
             memcpy(part[3], jp[0], sizeof jp[0]);
             memcpy(part[0], jp[1], sizeof jp[1]);
             memcpy(part[1], jp[2], sizeof jp[2]);

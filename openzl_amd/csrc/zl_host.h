@@ -178,6 +178,27 @@ public:
     }
     uint32_t var_index(uint32_t key) const { return (key & kWitnessBit) ? (uint32_t)instance_.size() + (key & ~kWitnessBit) : key; }
     const std::vector<LC>& rows(int m) const { return m == 0 ? A_ : m == 1 ? B_ : C_; }
+    // 64-bit fingerprint of the constraint MATRICES (not the assignment): row / variable counts and the keys + coefficients of up to
+    // 1024 evenly spaced rows of every matrix.  A proving context records it when it learns its circuit and refuses a compiler whose
+    // fingerprint differs: two different circuits of the same shape must not silently share device matrices.  Rows are append-only, so
+    // the value is cached per (row count, variable counts): prove() pays for it once per compiler.
+    uint64_t structure_digest() const {
+        if (digest_rows_ == A_.size() && digest_inst_ == instance_.size() && digest_wit_ == witness_.size()) return digest_;
+        uint64_t h = 0xCBF29CE484222325ull;
+        auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+        mix(A_.size()); mix(instance_.size()); mix(witness_.size());
+        const size_t rows = A_.size(), step = rows > 1024 ? rows / 1024 : 1;
+        for (int m = 0; m < 3; m++) {
+            const std::vector<LC>& M = this->rows(m);
+            for (size_t i = 0; i < rows; i += step) {
+                mix(M[i].terms.size());
+                for (const auto& t : M[i].terms) { mix(t.first); for (int k = 0; k < F::N; k += 2) mix((uint64_t)t.second.l[k] | ((uint64_t)t.second.l[k + 1] << 32)); }
+            }
+        }
+        digest_ = h;
+        digest_rows_ = A_.size(); digest_inst_ = instance_.size(); digest_wit_ = witness_.size();
+        return h;
+    }
     const std::vector<F>& instance_assignment() const { return instance_; }
     const std::vector<F>& witness_assignment() const { return witness_; }
 
@@ -186,6 +207,8 @@ private:
     Mode mode_;
     std::vector<F> instance_, witness_;
     std::vector<LC> A_, B_, C_;
+    mutable uint64_t digest_ = 0;
+    mutable size_t digest_rows_ = (size_t)-1, digest_inst_ = 0, digest_wit_ = 0;
 };
 
 // ---- Poseidon (config 5) ------------------------------------------------------------------------------------------------------
@@ -362,9 +385,12 @@ struct Groth16 {
         zl_ctx* ctx = nullptr;
         uint64_t a_query = 0, b_g1_query = 0, h_query = 0, l_query = 0, b_g2_query = 0;
         // device-resident constraint matrices (static per circuit): uploaded by compile; a context decoded from bytes does not know its
-        // circuit, so the first prove() uploads them (hence mutable)
+        // circuit, so the first prove() uploads them and BINDS the context to that circuit (hence mutable: the first prove of a decoded
+        // context mutates it, so it must not race with another prove on the same context; every later prove is read-only).
+        // circuit_digest = R1CS::structure_digest() of the bound circuit: a compiler with another fingerprint is refused.
         mutable uint64_t r1cs = 0;
         mutable size_t n_constraints = 0;
+        mutable uint64_t circuit_digest = 0;
         std::vector<uint64_t> alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2;
         size_t n_instance = 0, n_witness = 0, domain_size = 0;
         Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it

@@ -247,6 +247,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         if (!exported) own.build(cs);
         rc = zl_r1cs_upload(ctx, E::curve, exported ? &exported->view : &own.view, &pc.r1cs);
         pc.n_constraints = nc;
+        pc.circuit_digest = cs.structure_digest();
     }
     lap("r1cs export + upload");
     // alpha*G1, beta*G1, delta*G1, beta*G2, delta*G2
@@ -545,7 +546,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
     if (r_out) *r_out = r;
     if (s_out) *s_out = s;
-    if (pc.r1cs && cs.constraint_count() != pc.n_constraints) return res;
+    if (pc.r1cs && (cs.constraint_count() != pc.n_constraints || cs.structure_digest() != pc.circuit_digest)) return res;  // not the bound circuit
     if (!pc.r1cs) {
         // a context decoded from bytes (Groth16::decode) does not know its circuit: the first proof uploads the matrices, after checking
         // that the compiler's evaluation domain is the one the key's h_query was generated for
@@ -558,6 +559,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
         const int rc_up = zl_r1cs_upload(pc.ctx, E::curve, &ex.view, &pc.r1cs);
         if (rc_up) { res.error = Error{rc_up}; return res; }
         pc.n_constraints = nc;
+        pc.circuit_digest = cs.structure_digest();
     }
     // only the assignment travels per proof; the matrices and the proving key are device-resident
     const auto& inst = cs.instance_assignment();

@@ -23,10 +23,13 @@
 // The result does not depend on c, on the digit signs or on the order entries land in a bucket (group law).
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #include <algorithm>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "zl_ctx.h"
+#include "zl_pool.h"
 
 // This file is compiled once per group: -DZL_G=BlsG1|BnG1|BlsG2|BnG2 (see openzl_amd/build.py)
 #ifndef ZL_G
@@ -78,16 +81,24 @@ __device__ __forceinline__ bool zl_take_one(const uint32_t* s, uint32_t i, uint3
     return one;
 }
 
+// The ABI takes canonical scalars (< r, what ark's into_repr() yields).  A scalar with bits at or above SC_BITS cannot be one; the window
+// layout (W = ceil((SC_BITS + 1) / c) windows, spread top window) silently drops or misplaces such bits, so the recoder flags them and the
+// call returns ZL_EINVAL instead of a wrong sum.
+__device__ __forceinline__ void zl_flag_wide_scalar(uint32_t top_word, int sc_bits, uint32_t* __restrict__ bad) {
+    if ((top_word >> (sc_bits - 224)) != 0u) atomicOr(bad, 1u);
+}
 // MODE 0: histogram; MODE 1: scatter (cursor initialised with the bucket offsets)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ counters, uint32_t* __restrict__ entries,
-                                                    uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
+                                                    uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
+                                                    int sc_bits, uint32_t* __restrict__ bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n && !(inf && inf[i]);
     const uint32_t* s = scalars + (size_t)(live ? i : 0) * 8;
     uint32_t sv[8];
     for (int k = 0; k < 8; k++) sv[k] = live ? s[k] : 0u;
+    if (MODE == 0) zl_flag_wide_scalar(sv[7], sc_bits, bad);
     if (MODE == 0) {
         if (zl_take_one(sv, i, ones_list, ones_count)) return;
     } else if (sv[0] == 1u && (sv[1] | sv[2] | sv[3] | sv[4] | sv[5] | sv[6] | sv[7]) == 0u) {
@@ -116,12 +127,14 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 // k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
 static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits,
-                                                             uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
+                                                             uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
+                                                             int sc_bits, uint32_t* __restrict__ bad) {
     ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
     uint4 lo = sp[0], hi = sp[1];
+    if (live) zl_flag_wide_scalar(hi.w, sc_bits, bad);
     if (!live || (inf && inf[i])) lo = hi = make_uint4(0, 0, 0, 0);  // a base at infinity contributes nothing: its scalar is dropped here
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;  // listed: contributes no digits
@@ -225,12 +238,14 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 // (low bits of the point index) << spread_t | (magnitude - 1); the reduction weights those buckets by their low spread_t bits only.
 static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint32_t gw, int spread_t,
                                                                   uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
-                                                                  uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf) {
+                                                                  uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
+                                                                  int sc_bits, uint32_t* __restrict__ bad) {
     ZL_SIDE_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)(live ? i : 0) * 8);
     uint4 lo = sp[0], hi = sp[1];
+    if (live) zl_flag_wide_scalar(hi.w, sc_bits, bad);
     if (!live || (inf && inf[i])) lo = hi = make_uint4(0, 0, 0, 0);  // a base at infinity contributes nothing
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;
@@ -656,7 +671,8 @@ static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block_sums(const uin
     }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
-static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
+static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out,
+                                                          const uint32_t* __restrict__ flag_in = nullptr /* copied to total_out[1] */) {
     ZL_SIDE_PRIO();
     // single block: exclusive scan of block_sums in place
     __shared__ uint32_t sh[1024];
@@ -680,7 +696,10 @@ static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__
         if (threadIdx.x == 1023) carry += incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (flag_in) total_out[1] = *flag_in;
+    }
 }
 static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t count, const uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
@@ -1202,7 +1221,7 @@ struct MsmJob {
     // buffers
     uint32_t *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr, *d_entries = nullptr, *d_block_sums = nullptr, *d_big_list = nullptr,
              *d_big_count = nullptr, *d_ones_count = nullptr, *d_giant_count = nullptr, *d_giant_list = nullptr, *d_ones_list = nullptr,
-             *d_bigsg_items = nullptr;
+             *d_bigsg_items = nullptr, *d_bad_scalar = nullptr;
     unsigned long long* d_bigsg_head = nullptr;
     X *d_buckets = nullptr, *d_partials = nullptr, *d_segs = nullptr, *d_stage1 = nullptr, *d_sets = nullptr, *d_ones_parts = nullptr, *d_giant_tmp = nullptr;
     const Affine<F>* d_bases = nullptr;
@@ -1210,9 +1229,9 @@ struct MsmJob {
     const uint32_t* sc = nullptr;
     // host results (pinned when pipelined)
     X* hw = nullptr;
-    uint32_t* hE = nullptr;
+    uint32_t* hE = nullptr;  // [0] = entries accumulated, [1] = non-canonical-scalar flag
     std::vector<X> hw_own;
-    uint32_t hE_own = 0;
+    uint32_t hE_own[2] = {0, 0};
 
     int plan(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_) {
         n = n_;
@@ -1271,7 +1290,7 @@ struct MsmJob {
         sc = reinterpret_cast<const uint32_t*>(d_scalars);
         hw_own.assign((size_t)SETS * roots_per_set + 1, X::inf());
         hw = hw_own.data();
-        hE = &hE_own;
+        hE = hE_own;
         return ZL_OK;
     }
     // buffer set 0, 1 or 2 (slots 0..3 / 10..13 / 14..17); the tail buffers (slot 4) and the sort temporaries (slots 5, 6) are shared: tails and sorts
@@ -1280,18 +1299,19 @@ struct MsmJob {
         void* p;
         int rc;
         const int o = set == 0 ? 0 : (set == 1 ? 10 : 14);
-        // counters (NB+1) | offsets (NB+1) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
+        // counters (NB+1) | offsets (NB+2: [NB] = total entries, [NB+1] = non-canonical-scalar flag) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
         const size_t max_bigsg = (size_t)(maxE / 1024) + 2;  // oversized sub-groups hold > cap >= 1024 entries each
-        size_t small_words = (size_t)3 * (NB + 1) + scan_blocks + 1 + max_big + max_giant + 16 + n + 2 * max_bigsg;
+        size_t small_words = (size_t)3 * (NB + 1) + 1 + scan_blocks + 1 + max_big + max_giant + 16 + n + 2 * max_bigsg;
         if ((rc = zl_scratch_get(ctx, o + 0, small_words * 4, &p))) return rc;
         d_counts = (uint32_t*)p;
         d_offsets = d_counts + (NB + 1);
-        d_cursor = d_offsets + (NB + 1);
+        d_cursor = d_offsets + (NB + 2);
         d_block_sums = d_cursor + (NB + 1);
         d_big_list = d_block_sums + scan_blocks + 1;
         d_big_count = d_big_list + max_big;
         d_ones_count = d_big_count + 1;
         d_giant_count = d_big_count + 2;
+        d_bad_scalar = d_big_count + 3;  // zeroed with the counts; set by the recoder for a scalar with bits >= SC_BITS
         d_giant_list = d_big_count + 16;
         d_ones_list = d_giant_list + max_giant;
         d_bigsg_items = d_ones_list + n;
@@ -1332,13 +1352,13 @@ struct MsmJob {
             const uint32_t P2 = Gn * 128 * fsl;
             const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
             s6 = b_lo + b_pidx + (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256 + 256;
-        } else {
+        } else if (c <= 16) {
             uint32_t nslices = (256 + W - 1) / W;
             const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
             if (nslices > max_slices) nslices = max_slices;
             if (nslices < 1) nslices = 1;
             s5 = (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256;
-        }
+        }  // plain c >= 21 (more than 255 sort groups): the global-atomics sort needs no temporaries
     }
     int sort(zl_ctx* ctx, hipStream_t st) {
         const zl_bases& bs = *bsp;
@@ -1370,10 +1390,10 @@ struct MsmJob {
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count, d_inf);
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P, (const uint32_t*)nullptr);
             hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
             hipLaunchKernelGGL(k_msm_part_scatter_st, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
                                pre ? (uint32_t)bs.n : 0u, pre ? (uint32_t)first : 0u, d_part_lo, d_part_idx);  // plain: d_bases already starts at `first`
@@ -1395,13 +1415,13 @@ struct MsmJob {
             uint32_t* d_blk2 = d_off2 + P2 + 1;
             hipLaunchKernelGGL(k_msm_sub_hist, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fsl, d_c2);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2, (const uint32_t*)nullptr);
             hipLaunchKernelGGL(k_scan_apply, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2, d_off2, d_c2);
             hipLaunchKernelGGL(k_msm_sub_scatter_st, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
                                d_idx2);
             hipLaunchKernelGGL(k_msm_fine_hist, dim3(SG), dim3(256), 0, st, d_lo2, d_off2, SG, fsl, d_off2 + P2, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
             // staged entries per block: at most 144 KiB + 1 KiB of cursors (1 block per CU); sub-groups average n*W/SG entries, so many small
             // sub-groups (plain wide windows) get a smaller stage and two blocks per CU
@@ -1424,11 +1444,11 @@ struct MsmJob {
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count, d_inf);
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
             // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
             uint32_t ranges = 1;
@@ -1438,11 +1458,11 @@ struct MsmJob {
             hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
         } else {
             // wide windows without a table: histogram / scatter with global atomics
-            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf);
+            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count, d_inf);
+            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
         }
         ZL_HIP(ctx, hipGetLastError());
         return ZL_OK;
@@ -1478,25 +1498,40 @@ struct MsmJob {
         }
         ZL_HIP(ctx, hipGetLastError());
         ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * ((size_t)SETS * roots_per_set + 1), hipMemcpyDeviceToHost, st));
-        ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 4, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 8, hipMemcpyDeviceToHost, st));
         return ZL_OK;
     }
-    X finish() const {
-        // One Horner over the bit positions of the scalar, high to low: the window sum of set w is A_w + g0 * sum_b 2^b S_(w,b), weighted by
-        // 2^(c w) (the table of a precomputed handle already carries that factor: one set, w = 0).  Position c w + lg g0 + b takes S_(w,b),
-        // position c w takes A_w; the doublings are the ones the window Horner needs anyway.
-        X total = X::inf();
-        const int top = (int)(SETS - 1) * c + (int)red_lg0 + (int)red_levels - 1;
-        for (int pos = std::max(top, 0); pos >= 0; pos--) {
-            if (pos != std::max(top, 0)) zl::dbl_inplace(total);
-            const int w = std::min<int>(pos / c, (int)SETS - 1), off = pos - w * c;
-            const X* root = hw + (size_t)w * roots_per_set;  // channels: T, A, S_0 ..
-            if (off == 0) zl::add_full(total, root[1]);
+    // The window sum of set w is V_w = A_w + g0 * sum_b 2^b S_(w,b) (the root channels T, A, S_0 .. of its reduction tree); the result is
+    // sum_w 2^(c w) V_w (the table of a precomputed handle already carries that factor: one set, w = 0) + the scalar-1 bases.
+    //   stage 1  every V_w by its own short Horner over the bit positions of the window (<= c - 2 doublings, levels + 1 additions): the
+    //            sets are independent -> zl_pool, one task per set
+    //   stage 2  one serial Horner over the sets, high to low: c doublings + one addition per set (the ~c W doublings every window
+    //            method needs)
+    // (Rounds 1-2 ran ONE Horner over all bit positions on one thread: the same ~c W doublings, but all (levels + 2) W additions
+    // serial as well: 0.40 ms for BLS12-381 G1 at c = 16 against ~0.2 ms now.)
+    X window_value(int w) const {
+        const X* root = hw + (size_t)w * roots_per_set;  // channels: T, A, S_0 ..
+        X v = X::inf();
+        const int top = (int)red_lg0 + (int)red_levels - 1;  // highest position inside the window that carries a channel
+        for (int off = std::max(top, 0); off >= 0; off--) {
+            if (off != std::max(top, 0)) zl::dbl_inplace(v);
             const int bsel = off - (int)red_lg0;
             if (bsel >= 0 && bsel < (int)red_levels) {
                 const bool skipped = spread_t >= 0 && w == (int)SETS - 1 && off >= spread_t && !pre;  // spread top window: bits from spread_t on carry no weight
-                if (!skipped) zl::add_full(total, root[2 + bsel]);
+                if (!skipped) zl::add_full(v, root[2 + bsel]);
             }
+            if (off == 0) zl::add_full(v, root[1]);
+        }
+        return v;
+    }
+    X finish(bool parallel = true) const {
+        std::vector<X> V(SETS);
+        if (parallel && SETS >= 4) zl_pool_get().parallel_for(SETS, [&](size_t w) { V[w] = window_value((int)w); });
+        else for (uint32_t w = 0; w < SETS; w++) V[w] = window_value((int)w);
+        X total = V[SETS - 1];
+        for (int w = (int)SETS - 2; w >= 0; w--) {
+            for (int k = 0; k < c; k++) zl::dbl_inplace(total);
+            zl::add_full(total, V[w]);
         }
         zl::add_full(total, hw[(size_t)SETS * roots_per_set]);
         return total;
@@ -1509,10 +1544,13 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
     X total = X::inf();
     ctx->timing = zl_timing{};
     if (n > 0) {
+        static const bool trace = getenv("ZL_HOST_TRACE") != nullptr;  // developer aid: host-side phase times of a single call on stderr
+        const auto tp0 = std::chrono::steady_clock::now();
         MsmJob<G> job;
         int rc;
         if ((rc = job.plan(ctx, bs, first, d_scalars, n))) return rc;
         if ((rc = job.alloc(ctx, 0))) return rc;
+        const auto tp1 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
         if ((rc = job.sort(ctx, st))) return rc;
@@ -1521,7 +1559,9 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         if ((rc = job.tail(ctx, st))) return rc;
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        const auto tp2 = std::chrono::steady_clock::now();
         ZL_HIP(ctx, hipStreamSynchronize(st));
+        const auto tp3 = std::chrono::steady_clock::now();
         if (ctx->timing_on) {
             ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.total_ms, ctx->ev[0], ctx->ev[3]));
             ZL_HIP(ctx, hipEventElapsedTime(&ctx->timing.dominant_ms, ctx->ev[1], ctx->ev[2]));
@@ -1529,7 +1569,14 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         ctx->timing.launches = 1;
         ctx->timing.window_bits = (uint32_t)job.c;
         ctx->timing.entries = *job.hE;
+        if (job.hE[1]) return ZL_EINVAL;  // a scalar with bits at or above SC_BITS: not a canonical scalar (the ABI's contract)
         total = job.finish();
+        if (trace) {
+            const auto tp4 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+            fprintf(stderr, "[zl_msm n=%zu c=%d] plan+alloc %.1f us  issue %.1f us  sync-wait %.1f us  timing+horner %.1f us\n", n, job.c, us(tp0, tp1), us(tp1, tp2),
+                    us(tp2, tp3), us(tp3, tp4));
+        }
     }
     static_assert(sizeof(X) <= ZL_PARTIAL_WORDS * 8, "partial too small");
     memset(out_partial, 0, ZL_PARTIAL_WORDS * 8);
@@ -1548,8 +1595,10 @@ struct MsmSpec {
     size_t n;
     hipEvent_t wait;  // optional: the scalars of this job are ready when this event (recorded on another stream) has fired
 };
+// `recorded` (optional): the wait events are recorded by ANOTHER host thread (zl_msm's copy thread); job i may only be issued once
+// *recorded > i, because hipStreamWaitEvent on a not-yet-recorded event does not wait.  Negative = that thread failed.
 template <class G>
-static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials) {
+static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded = nullptr) {
     using X = XYZZ<typename G::F>;
     ctx->timing = zl_timing{};
     if (count == 0) return ZL_OK;
@@ -1557,6 +1606,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     for (size_t i = 0; i < count; i++) any_empty = any_empty || specs[i].n == 0;
     if (any_empty || count == 1) {
         for (size_t i = 0; i < count; i++) {
+            if (recorded) { while (recorded->load(std::memory_order_acquire) >= 0 && recorded->load(std::memory_order_acquire) <= (int)i) std::this_thread::yield(); if (recorded->load() < 0) return ZL_EHIP; }
             if (specs[i].wait) ZL_HIP(ctx, hipEventSynchronize(specs[i].wait));
             int rc = msm_run_t<G>(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, out_partials + i * ZL_PARTIAL_WORDS);
             if (rc) return rc;
@@ -1634,6 +1684,10 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
     for (size_t i = 0; i < count && he == hipSuccess && rc == ZL_OK; i++) {
         if (i >= 3) he = hipStreamWaitEvent(s_sort, ev_tail[i - 3], 0);  // buffer set i % 3 is free again
+        if (recorded && specs[i].wait) {
+            while (recorded->load(std::memory_order_acquire) >= 0 && recorded->load(std::memory_order_acquire) <= (int)i) std::this_thread::yield();
+            if (recorded->load() < 0) { rc = ZL_EHIP; break; }
+        }
         if (he == hipSuccess && specs[i].wait) he = hipStreamWaitEvent(s_sort, specs[i].wait, 0);
         if (he != hipSuccess) break;
         if ((rc = jobs[i].sort(ctx, s_sort))) break;
@@ -1670,6 +1724,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     ctx->timing.launches = (uint32_t)count;
     ctx->timing.window_bits = (uint32_t)jobs[0].c;
     ctx->timing.entries = *jobs[count - 1].hE;
+    for (size_t i = 0; i < count; i++)
+        if (jobs[i].hE[1]) return ZL_EINVAL;  // non-canonical scalar (see msm_run_t)
     // host Horners (256 doublings + one addition per bit position each, ~0.5 ms): all jobs side by side
     {
         const size_t nt = std::min<size_t>(count, 16);
@@ -1677,7 +1733,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         for (size_t t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
                 for (size_t i = t; i < count; i += nt) {
-                    const X total = jobs[i].finish();
+                    const X total = jobs[i].finish(false);  // the jobs already run side by side
                     memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
                     memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
                 }
@@ -1797,10 +1853,10 @@ int ZL_GNAME(zl_msm_run_batch)(zl_ctx* ctx, const zl_bases& b, size_t first, con
 }
 // heterogeneous pipeline: job i = (bases[i], first[i], d_scalars[i], n[i]) (Groth16: the four G1 MSMs of one proof)
 int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n,
-                              const hipEvent_t* wait, size_t count, uint64_t* out_partials) {
+                              const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded) {
     std::vector<MsmSpec> specs(count);
     for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{bases[i], first[i], d_scalars[i], n[i], wait ? wait[i] : nullptr};
-    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials);
+    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials, recorded);
 }
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);

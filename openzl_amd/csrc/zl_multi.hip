@@ -15,8 +15,16 @@
 #include <string.h>
 #include <thread>
 #include <vector>
-#include <rccl/rccl.h>
 #include "zl_ctx.h"
+
+// The handful of RCCL declarations this unit needs, stated locally (ABI of rccl.h, ROCm 7: ncclResult_t / ncclDataType_t are plain int enums,
+// ncclComm_t an opaque pointer, ncclSuccess = 0, ncclUint64 = 5): the library is loaded with dlopen, so neither its header nor the
+// library itself has to exist on a box that only ever uses one device -- zl_ctx_create_multi then returns ZL_ENODEV for distinct devices.
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef struct ncclComm* ncclComm_t;
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint64 = 5;
 
 struct zl_rccl_api {
     void* lib = nullptr;
@@ -82,6 +90,24 @@ static int per_rank(zl_mctx* m, Fn fn) {
     for (int g = 0; g < m->n; g++) if (rc[g]) return rc[g];
     return ZL_OK;
 }
+
+// after a failure with work already enqueued: no rank's stream may still be touching stack-owned host buffers or another rank's memory
+static void drain_all(zl_mctx* m) {
+    for (int g = 0; g < m->n; g++) {
+        if (!m->ctx[g]) continue;
+        if (hipSetDevice(m->dev[g]) == hipSuccess) (void)hipStreamSynchronize(m->ctx[g]->stream);
+    }
+    (void)hipGetLastError();
+}
+#define ZL_MHIP(m, ctx, call)                                          \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) {                                        \
+            (ctx)->last_hip = (int)e_;                                 \
+            drain_all(m);                                              \
+            return e_ == hipErrorOutOfMemory ? ZL_ENOMEM : ZL_EHIP;    \
+        }                                                              \
+    } while (0)
 
 extern "C" {
 
@@ -165,13 +191,14 @@ int zl_msm_sharded(zl_mctx* m, const uint64_t* bases, const size_t* first, const
     std::vector<void*> buf(G);
     for (int g = 0; g < G; g++)
         if ((rc = mctx_buf(m, g, (size_t)(G + 1) * pbytes, &buf[g]))) return rc;  // [0, G): gathered, [G]: this rank's contribution
+    std::vector<uint64_t> gathered((size_t)G * ZL_PARTIAL_WORDS);  // declared before anything is enqueued: every failure below drains first
     rc = per_rank(m, [&](int g) -> int {
         unsigned char* b = reinterpret_cast<unsigned char*>(buf[g]);
         ZL_HIP(m->ctx[g], hipMemcpyAsync(b + (size_t)G * pbytes, &parts[(size_t)g * ZL_PARTIAL_WORDS], pbytes, hipMemcpyHostToDevice, m->ctx[g]->stream));
         if (m->virt) ZL_HIP(m->ctx[g], hipEventRecord(m->ev[g], m->ctx[g]->stream));
         return (int)ZL_OK;
     });
-    if (rc) return rc;
+    if (rc) { drain_all(m); return rc; }
     if (!m->virt) {
         ncclResult_t r = m->rccl.GroupStart();
         for (int g = 0; g < G && r == ncclSuccess; g++) {
@@ -180,25 +207,25 @@ int zl_msm_sharded(zl_mctx* m, const uint64_t* bases, const size_t* first, const
         }
         const ncclResult_t r2 = m->rccl.GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) { m->last_rccl = (int)r; return ZL_EHIP; }
+        if (r != ncclSuccess) { m->last_rccl = (int)r; drain_all(m); return ZL_EHIP; }
     } else {
         for (int g = 0; g < G; g++) {  // rank g pulls every rank's contribution once that rank has staged it
             hipStream_t st = m->ctx[g]->stream;
-            if (hipSetDevice(m->dev[g]) != hipSuccess) return ZL_EHIP;
+            ZL_MHIP(m, m->ctx[g], hipSetDevice(m->dev[g]));
             for (int s = 0; s < G; s++) {
-                ZL_HIP(m->ctx[g], hipStreamWaitEvent(st, m->ev[s], 0));
-                ZL_HIP(m->ctx[g], hipMemcpyAsync(reinterpret_cast<unsigned char*>(buf[g]) + (size_t)s * pbytes,
-                                                 reinterpret_cast<unsigned char*>(buf[s]) + (size_t)G * pbytes, pbytes, hipMemcpyDeviceToDevice, st));
+                ZL_MHIP(m, m->ctx[g], hipStreamWaitEvent(st, m->ev[s], 0));
+                // hipMemcpyDefault: the two buffers may live on different devices when only SOME ids repeat (unified addressing resolves them)
+                ZL_MHIP(m, m->ctx[g], hipMemcpyAsync(reinterpret_cast<unsigned char*>(buf[g]) + (size_t)s * pbytes,
+                                                     reinterpret_cast<unsigned char*>(buf[s]) + (size_t)G * pbytes, pbytes, hipMemcpyDefault, st));
             }
         }
     }
     // 3. fold rank 0's gathered copy (every rank holds the same G partials)
-    std::vector<uint64_t> gathered((size_t)G * ZL_PARTIAL_WORDS);
-    if (hipSetDevice(m->dev[0]) != hipSuccess) return ZL_EHIP;
-    ZL_HIP(m->ctx[0], hipMemcpyAsync(gathered.data(), buf[0], (size_t)G * pbytes, hipMemcpyDeviceToHost, m->ctx[0]->stream));
+    ZL_MHIP(m, m->ctx[0], hipSetDevice(m->dev[0]));
+    ZL_MHIP(m, m->ctx[0], hipMemcpyAsync(gathered.data(), buf[0], (size_t)G * pbytes, hipMemcpyDeviceToHost, m->ctx[0]->stream));
     for (int g = 0; g < G; g++) {
-        if (hipSetDevice(m->dev[g]) != hipSuccess) return ZL_EHIP;
-        ZL_HIP(m->ctx[g], hipStreamSynchronize(m->ctx[g]->stream));
+        ZL_MHIP(m, m->ctx[g], hipSetDevice(m->dev[g]));
+        ZL_MHIP(m, m->ctx[g], hipStreamSynchronize(m->ctx[g]->stream));
     }
     return zl_partials_sum((zl_curve_t)curve, (zl_group_t)group, gathered.data(), (size_t)G, out_xy, out_inf);
 }
@@ -227,7 +254,7 @@ int zl_ntt_sharded(zl_mctx* m, zl_curve_t curve, void* const* d_data, unsigned l
         if (!r && m->virt) ZL_HIP(m->ctx[g], hipEventRecord(m->ev[g], m->ctx[g]->stream));
         return r;
     });
-    if (rc) return rc;
+    if (rc) { drain_all(m); return rc; }
     // the ONE exchange: rank g's chunk j goes to rank j's slot g (all-to-all of G chunks of B elements)
     if (!m->virt) {
         ncclResult_t r = m->rccl.GroupStart();
@@ -241,21 +268,21 @@ int zl_ntt_sharded(zl_mctx* m, zl_curve_t curve, void* const* d_data, unsigned l
         }
         const ncclResult_t r2 = m->rccl.GroupEnd();
         if (r == ncclSuccess) r = r2;
-        if (r != ncclSuccess) { m->last_rccl = (int)r; return ZL_EHIP; }
+        if (r != ncclSuccess) { m->last_rccl = (int)r; drain_all(m); return ZL_EHIP; }
     } else {
         for (int g = 0; g < G; g++) {  // receiver g pulls its chunk from every sender once the sender's first leg is done
             hipStream_t st = m->ctx[g]->stream;
-            if (hipSetDevice(m->dev[g]) != hipSuccess) return ZL_EHIP;
+            ZL_MHIP(m, m->ctx[g], hipSetDevice(m->dev[g]));
             for (int s = 0; s < G; s++) {
-                ZL_HIP(m->ctx[g], hipStreamWaitEvent(st, m->ev[s], 0));
-                ZL_HIP(m->ctx[g], hipMemcpyAsync(reinterpret_cast<unsigned char*>(buf[g]) + (size_t)s * chunk,
-                                                 reinterpret_cast<const unsigned char*>(d_data[s]) + (size_t)g * chunk, chunk, hipMemcpyDeviceToDevice, st));
+                ZL_MHIP(m, m->ctx[g], hipStreamWaitEvent(st, m->ev[s], 0));
+                ZL_MHIP(m, m->ctx[g], hipMemcpyAsync(reinterpret_cast<unsigned char*>(buf[g]) + (size_t)s * chunk,
+                                                     reinterpret_cast<const unsigned char*>(d_data[s]) + (size_t)g * chunk, chunk, hipMemcpyDefault, st));
             }
         }
         // a sender's buffer is overwritten by its own second leg: every receiver must have pulled from it first
         for (int g = 0; g < G; g++) {
-            if (hipSetDevice(m->dev[g]) != hipSuccess) return ZL_EHIP;
-            ZL_HIP(m->ctx[g], hipStreamSynchronize(m->ctx[g]->stream));
+            ZL_MHIP(m, m->ctx[g], hipSetDevice(m->dev[g]));
+            ZL_MHIP(m, m->ctx[g], hipStreamSynchronize(m->ctx[g]->stream));
         }
     }
     // leg 2 on the received data, result copied back into the caller's buffer
@@ -267,6 +294,7 @@ int zl_ntt_sharded(zl_mctx* m, zl_curve_t curve, void* const* d_data, unsigned l
         ZL_HIP(m->ctx[g], hipStreamSynchronize(m->ctx[g]->stream));
         return (int)ZL_OK;
     });
+    if (rc) drain_all(m);
     return rc;
 }
 

@@ -1,0 +1,83 @@
+// zl_pool.h -- a small persistent host thread pool for the host tails of the device work (the window Horner of an MSM is a few hundred
+// group operations: worth spreading, not worth a thread spawn per call).  One pool per process (zl_pool_get, defined in zl_capi.hip).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+class zl_pool {
+public:
+    explicit zl_pool(unsigned workers) {
+        for (unsigned i = 0; i < workers; i++) th_.emplace_back([this]() { loop(); });
+    }
+    ~zl_pool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // f(0) .. f(n - 1), each exactly once, on the workers and the caller; returns when all are done
+    void parallel_for(size_t n, const std::function<void(size_t)>& f) {
+        if (n == 0) return;
+        if (n == 1 || th_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+        auto job = std::make_shared<Job>();
+        job->fn = &f;
+        job->n = n;
+        job->left.store(n, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = job;
+            gen_++;
+        }
+        cv_.notify_all();
+        work(*job);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&]() { return job->left.load(std::memory_order_acquire) == 0; });
+        if (job_ == job) job_.reset();
+    }
+
+private:
+    struct Job {  // one parallel_for; a worker that arrives late finds next >= n and leaves it alone
+        const std::function<void(size_t)>* fn = nullptr;
+        size_t n = 0;
+        std::atomic<size_t> next{0}, left{0};
+    };
+    void work(Job& j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) return;
+            (*j.fn)(i);
+            if (j.left.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m_);
+                done_.notify_all();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return stop_ || (gen_ != seen && job_); });
+                if (stop_) return;
+                seen = gen_;
+                j = job_;
+            }
+            work(*j);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::shared_ptr<Job> job_;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+zl_pool& zl_pool_get();

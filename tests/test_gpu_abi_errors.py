@@ -142,3 +142,42 @@ def test_groth16_rejects_malformed_csr(backend):
             assert e.value.code == EINVAL, mutate
     finally:
         gu.free_pk(backend, dpk)
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("n,c,table", [(1000, 0, False), (1000, 18, False), (1 << 22, 0, False), (70000, 0, True)],
+                         ids=["lds_sort", "wide_c18", "2^22_spread_top_window", "table"])
+def test_msm_rejects_scalars_wider_than_the_field(backend, curve, n, c, table):
+    """The ABI takes canonical scalars (< r).  A scalar with bits at or above MODULUS_BITS would be cut or mis-bucketed by the window layout
+    (the spread top window of the plain 17..20-bit path at n >= 2^22 ORs the point index above the digit), so every sort path flags it
+    and the call fails with ZL_EINVAL instead of returning a wrong point; the same vector with the offending scalar reduced works."""
+    import torch
+
+    if curve is po.BN254 and n > 100000:
+        pytest.skip("one large case is enough")
+    rng = np.random.Generator(np.random.PCG64(5150 + n))
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = rng.integers(1, 1 << 62, size=n, dtype=np.uint64)
+    S = ol.random_scalars(curve, n, 5151)
+    h = backend.bases_generate(curve.cid, k)
+    try:
+        if table:
+            backend.bases_precompute(h, 16)
+        backend.set_msm_window(c)
+        good = backend.msm(h, S)
+        bad = S.copy()
+        bad[n // 3, 3] |= np.uint64(1) << np.uint64(curve.fr.bits - 192)  # bit MODULUS_BITS of one scalar
+        with pytest.raises(BackendError) as e:
+            backend.msm(h, bad)
+        assert e.value.code == EINVAL
+        d_bad = torch.from_numpy(bad.view(np.int64)).cuda()
+        d_ok = torch.from_numpy(S.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        with pytest.raises(BackendError) as e:
+            backend.msm_batch_partial_dev(h, [d_ok.data_ptr(), d_bad.data_ptr(), d_ok.data_ptr()], n)
+        assert e.value.code == EINVAL
+        again = backend.msm(h, S)  # the ctx is usable afterwards and the flag does not stick
+        assert again[1] == good[1] and (again[0] == good[0]).all()
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)

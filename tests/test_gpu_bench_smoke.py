@@ -24,8 +24,14 @@ def test_bench_single_gpu_small():
     d = _line(r.stdout)
     assert d["unit"] == "points/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 3 and d["higher_is_better"] is True
     assert d["config"]["workload"] == "bls12_381_g1_msm_2^16_per_gpu" and d["config"]["precomputed_table"].startswith("none")
-    for key in ("roofline", "cpu_baseline", "pcie_inclusive", "msm_fixed_key", "msm_skewed_scalars", "ntt", "groth16"):
+    for key in ("roofline", "cpu_baseline", "pcie_inclusive", "msm_fixed_key", "msm_skewed_scalars", "ntt", "groth16", "configs"):
         assert isinstance(d[key], dict), key
+    # all five BASELINE configurations are on the line
+    c = d["configs"]
+    assert c["1"]["checked_exactly"] and c["1"]["cpu_baseline"]["parity_full_size"] is True and c["1"]["gpu_single_call_ms"] > 0
+    assert c["2"]["checked_exactly"] and c["2"]["single_call_ms"] > 0 and 0 < c["2"]["int_alu_frac_single_call"] < 1
+    assert c["4"]["functional"] is True and c["4"]["checked_exactly"] is True
+    assert isinstance(c["3"], str) and isinstance(c["5"], str)
     assert "leg_errors" not in d
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_msm_accumulate"
     assert d["cpu_baseline"]["parity_full_size"] is True and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
@@ -33,12 +39,50 @@ def test_bench_single_gpu_small():
     assert d["groth16"]["verified"] is True and d["msm_fixed_key"]["table_build_ms"] > 0
 
 
+def _check_two_rank_line(d):
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "shard2"
+    assert d["groth16"]["n_gpus"] == 2 and d["groth16"]["verified"] is True
+    assert "secondary_legs_error" not in d
+    legs = d["scaling_legs"]
+    for name in ("weak", "config4", "strong"):
+        e = legs[name]
+        assert "error" not in e, e
+        assert e["checked_exactly"] is True and e["ms_per_step"] > 0 and e["points_per_s"] > 0 and e["per_gpu_efficiency"] > 0
+    assert legs["config4"]["points_total"] == 2 ** 18 and legs["strong"]["points_total"] == 2 ** 16
+    # the one-process transport, timed by a child process; both test ranks share GPU 0, so the exchange runs on virtual ranks
+    m = d["mctx"]
+    assert "error" not in m, m
+    assert m["n_gpus"] == 2 and m["rccl_ranks"] == 0 and m["msm"]["checked_exactly"] is True and m["ntt"]["forward_ms"] > 0
+
+
+_SMALL_N2 = ["--gpus", "2", "--log-n", "16", "--ntt-log-n", "14", "--groth16-k", "4", "--steps", "2", "--warmup", "1", "--config4-log-total", "18",
+             "--strong-log-total", "16"]
+
+
 def test_bench_two_ranks_gloo_one_gpu():
     env = dict(os.environ, ZL_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "16", "--ntt-log-n", "14", "--groth16-k", "4", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        os.path.join(ROOT, "bench.py")] + _SMALL_N2, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_two_rank_line(_line(r.stdout))
+
+
+def test_bench_bare_launch_self_execs_under_torchrun():
+    """`python bench.py --gpus 2` with no torchrun environment (how a user, or a driver without the launcher line, starts it) must re-launch
+    itself one rank per GPU instead of exiting."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZL_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + _SMALL_N2, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "re-launching" in r.stderr
+    _check_two_rank_line(_line(r.stdout))
+
+
+def test_bench_mctx_transport_virtual_ranks():
+    """--transport mctx: ONE process, zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded; 4 virtual ranks on GPU 0 (RCCL needs distinct devices)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--transport", "mctx", "--gpus", "4", "--mctx-devices", "0,0,0,0", "--log-n", "14",
+                        "--ntt-log-n", "12", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "shard2"
-    assert d["groth16"]["n_gpus"] == 2 and d["groth16"]["verified"] is True
+    assert d["n_gpus"] == 4 and d["value"] > 0 and d["mctx"]["rccl_ranks"] == 0 and d["mctx"]["msm"]["checked_exactly"] is True
+    assert d["mctx"]["ntt"]["log_n"] == 14 and d["config"]["parallelism"] == "mctx4"
