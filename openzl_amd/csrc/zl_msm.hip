@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 // ---- LDS counting sort (c <= 16): no global atomics -------------------------------------------------------------
 // k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
-static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint16_t* __restrict__ digits,
+static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, int spread_t, uint16_t* __restrict__ digits,
                                                              uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
                                                              int sc_bits, uint32_t* __restrict__ bad) {
     ZL_SIDE_PRIO();
@@ -154,7 +154,11 @@ static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __res
         uint32_t neg = 0;
         carry = 0;
         if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
-        digits[(size_t)w * n + i] = d == 0 ? (uint16_t)0xFFFF : (uint16_t)((neg << 15) | (d - 1));
+        uint32_t b = d - 1;
+        // a narrow top window (spread_t + 1 bits) is spread over its whole bucket set like in k_msm_recode_wide; its digits are never
+        // negative (magnitudes <= 2^spread_t <= H), so the code 0xFFFF stays free
+        if (spread_t >= 0 && w == W - 1) b |= (i & ((1u << (c - 1 - spread_t)) - 1u)) << spread_t;
+        digits[(size_t)w * n + i] = d == 0 ? (uint16_t)0xFFFF : (uint16_t)((neg << 15) | b);
     }
 }
 // block (slice, w): private LDS histogram of window w over a slice of the scalars -> counts[slice][w*H + bin]
@@ -1258,9 +1262,10 @@ struct MsmJob {
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
-        // bucket reduction (k_msm_reduce_level0 + k_msm_reduce_tree): blocks of 8 buckets (4 for small inputs: more lanes, shorter chains)
+        // bucket reduction (k_msm_reduce_level0 + k_msm_reduce_tree): blocks of 8 buckets (4 / 2 for smaller inputs: more lanes, shorter chains)
         {
-            uint32_t g0 = NB >= (1u << 17) ? 8u : 4u;
+            // measured (gpurun sweep of ZL_TUNE_SEG, round 3): 2 up to 2^16 points, 4 at 2^18 - 2^20, 8 from 2^22 on
+            uint32_t g0 = NB >= (1u << 20) ? 8u : (NB >= (1u << 17) ? 4u : 2u);
             g0 = (uint32_t)std::max(2, zl_tune("ZL_TUNE_SEG", (int)g0));
             while (g0 & (g0 - 1)) g0 &= g0 - 1;
             if (g0 > H) g0 = H;
@@ -1268,7 +1273,7 @@ struct MsmJob {
             // low spread_t bits of the bucket index: all of level 0's bits must be on one side of that boundary (a very narrow top
             // window, 0 < spread_t < log2 g0, shortens the level-0 blocks to 2^spread_t)
             spread_t = -1;
-            if (wide && !pre) {
+            if ((wide || c <= 16) && !pre) {  // (the global-atomics sort of plain c >= 21 keeps its crowded top window)
                 const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
                 if (top_bits - 1 < c - 1) {
                     spread_t = top_bits - 1;
@@ -1444,7 +1449,7 @@ struct MsmJob {
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_digits, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, spread_t, d_digits, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);

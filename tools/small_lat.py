@@ -17,7 +17,8 @@ what = sys.argv[1:] or ["msm", "g16"]
 be = Backend(0)
 be.enable_timing(True)
 if "msm" in what:
-    for curve, name, logs in ((ZL_BN254, "bn254", (16,)), (ZL_BLS12_381, "bls12_381", (16, 18, 20, 22))):
+    sizes = tuple(int(x) for x in os.environ.get("SIZES", "16,18,20,22").split(","))
+    for curve, name, logs in ((ZL_BN254, "bn254", (16,)), (ZL_BLS12_381, "bls12_381", sizes)):
         nmax = 1 << max(logs)
         rng = np.random.Generator(np.random.PCG64(1))
         k = np.zeros((nmax, 4), dtype=np.uint64)
