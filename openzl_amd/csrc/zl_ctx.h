@@ -27,6 +27,9 @@ struct BlsG1 {
     static constexpr int SC_BITS = 255;
     static constexpr int FQ64 = 6;     // u64 limbs per Fq element in the ABI layouts
     static constexpr int COORDS = 1;   // Fq elements per coordinate
+    static constexpr bool GLV = true;  // plain MSMs split every scalar with the endomorphism (x, y) -> (beta x, y) = [lambda](x, y)
+    using GLVP = BLS12_381_GLV;
+    ZL_HD static F glv_beta() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = GLVP::beta(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F gen_x() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gx(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F gen_y() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gy(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F coeff_b() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::b(i); return FieldIO<F>::load_mont32(w); }
@@ -40,6 +43,7 @@ struct BnG1 {
     static constexpr int SC_BITS = 254;
     static constexpr int FQ64 = 4;
     static constexpr int COORDS = 1;
+    static constexpr bool GLV = false;
     ZL_HD static F gen_x() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gx(i); return r; }
     ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
     ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
@@ -53,6 +57,7 @@ struct G2Cfg {
     static constexpr int SC_BITS = SCB;
     static constexpr int FQ64 = FQ64_;
     static constexpr int COORDS = 2;
+    static constexpr bool GLV = false;
     ZL_HD static F mk(uint32_t (*f0)(int), uint32_t (*f1)(int)) {  // two components as arkworks' Montgomery words
         uint32_t w[2 * FqP::N];
         for (int i = 0; i < FqP::N; i++) { w[i] = f0(i); w[FqP::N + i] = f1(i); }
@@ -105,7 +110,7 @@ struct zl_ctx {
     std::map<uint64_t, zl_bases> bases;
     std::map<uint64_t, zl_r1cs_dev> r1cs;
     uint64_t next_handle = 1;
-    zl_scratch scratch[20];  // 0..9: first buffer set + shared; 10..13: second MSM buffer set (pipelined batches)
+    zl_scratch scratch[24];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV)
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
     hipStream_t stream_sort = nullptr, stream_tail = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_copy = nullptr;  // zl_msm with host scalars: chunked H2D copies that run under the MSMs of the earlier chunks

@@ -85,7 +85,15 @@ __device__ __forceinline__ bool zl_take_one(const uint32_t* s, uint32_t i, uint3
 // layout (W = ceil((SC_BITS + 1) / c) windows, spread top window) silently drops or misplaces such bits, so the recoder flags them and the
 // call returns ZL_EINVAL instead of a wrong sum.
 __device__ __forceinline__ void zl_flag_wide_scalar(uint32_t top_word, int sc_bits, uint32_t* __restrict__ bad) {
-    if ((top_word >> (sc_bits - 224)) != 0u) atomicOr(bad, 1u);
+    if (bad && (top_word >> (sc_bits - 224)) != 0u) atomicOr(bad, 1u);
+}
+// GLV half-scalars (k_glv_split): a 127-bit magnitude in words 0..3 and the sign in bit 31 of word 7.  The recoders strip the sign off
+// the record and fold it into the sign of every digit.
+__device__ __forceinline__ uint32_t zl_take_sign(uint32_t& top_word, int glv) {
+    if (!glv) return 0u;
+    const uint32_t sg = top_word >> 31;
+    top_word &= 0x7FFFFFFFu;
+    return sg;
 }
 // MODE 0: histogram; MODE 1: scatter (cursor initialised with the bucket offsets)
 template <int MODE>
@@ -98,7 +106,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
     const uint32_t* s = scalars + (size_t)(live ? i : 0) * 8;
     uint32_t sv[8];
     for (int k = 0; k < 8; k++) sv[k] = live ? s[k] : 0u;
-    if (MODE == 0) zl_flag_wide_scalar(sv[7], sc_bits, bad);
+    if (MODE == 0) zl_flag_wide_scalar(sv[7], sc_bits, bad);  // (this path never runs on GLV half-scalars: MsmJob::plan)
     if (MODE == 0) {
         if (zl_take_one(sv, i, ones_list, ones_count)) return;
     } else if (sv[0] == 1u && (sv[1] | sv[2] | sv[3] | sv[4] | sv[5] | sv[6] | sv[7]) == 0u) {
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
 // ---- LDS counting sort (c <= 16): no global atomics -------------------------------------------------------------
 // k_msm_recode: one lane per scalar, all W signed digits, coalesced u16 stores digits[w][i]:
 //   0xFFFF = zero digit, else (neg << 15) | (magnitude - 1)      (negative magnitudes are <= H-1, so 0xFFFF is free)
-static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, int spread_t, uint16_t* __restrict__ digits,
+static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, int spread_t, int glv, uint16_t* __restrict__ digits,
                                                              uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
                                                              int sc_bits, uint32_t* __restrict__ bad) {
     ZL_SIDE_PRIO();
@@ -137,8 +145,9 @@ static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __res
     if (live) zl_flag_wide_scalar(hi.w, sc_bits, bad);
     if (!live || (inf && inf[i])) lo = hi = make_uint4(0, 0, 0, 0);  // a base at infinity contributes nothing: its scalar is dropped here
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;  // listed: contributes no digits
+    if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;  // listed: contributes no digits (a negative half-scalar has its sign bit set: never listed)
     if (!live) return;
+    const uint32_t sg = zl_take_sign(s[7], glv);
     const uint32_t H = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -158,7 +167,9 @@ static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __res
         // a narrow top window (spread_t + 1 bits) is spread over its whole bucket set like in k_msm_recode_wide; its digits are never
         // negative (magnitudes <= 2^spread_t <= H), so the code 0xFFFF stays free
         if (spread_t >= 0 && w == W - 1) b |= (i & ((1u << (c - 1 - spread_t)) - 1u)) << spread_t;
-        digits[(size_t)w * n + i] = d == 0 ? (uint16_t)0xFFFF : (uint16_t)((neg << 15) | b);
+        // sign of a GLV half-scalar: folded into the digit's sign.  A flipped digit of magnitude H (bucket H - 1, sign set) would be the code
+        // 0xFFFF = "zero digit" when c = 16; MsmJob::plan sends GLV jobs with c = 16 through the wide sort, whose zero marker lives in hi8
+        digits[(size_t)w * n + i] = d == 0 ? (uint16_t)0xFFFF : (uint16_t)(((neg ^ sg) << 15) | b);
     }
 }
 // block (slice, w): private LDS histogram of window w over a slice of the scalars -> counts[slice][w*H + bin]
@@ -240,7 +251,7 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_
 // spread_t >= 0 (plain wide windows only): the top window holds just spread_t + 1 bits, so its 2^spread_t magnitudes would crowd n entries
 // into 2^spread_t buckets (one sort group) while its bucket set has 2^(c-1).  It is spread over the whole set instead: bucket =
 // (low bits of the point index) << spread_t | (magnitude - 1); the reduction weights those buckets by their low spread_t bits only.
-static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint32_t gw, int spread_t,
+static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W, uint32_t gw, int spread_t, int glv,
                                                                   uint16_t* __restrict__ lo16, uint8_t* __restrict__ hi8,
                                                                   uint32_t* __restrict__ ones_list, uint32_t* __restrict__ ones_count, const uint8_t* __restrict__ inf,
                                                                   int sc_bits, uint32_t* __restrict__ bad) {
@@ -254,6 +265,7 @@ static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* 
     uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (zl_take_one(s, i, ones_list, ones_count)) s[0] = 0;
     if (!live) return;
+    const uint32_t sg = zl_take_sign(s[7], glv);
     const uint32_t H = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -271,7 +283,7 @@ static __global__ void __launch_bounds__(256) k_msm_recode_wide(const uint32_t* 
         if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
         uint32_t b = d - 1;  // bucket (d != 0)
         if (spread_t >= 0 && w == W - 1) b |= (i & ((1u << (c - 1 - spread_t)) - 1u)) << spread_t;
-        lo16[(size_t)w * n + i] = (uint16_t)((b & 0x7FFFu) | (neg << 15));
+        lo16[(size_t)w * n + i] = (uint16_t)((b & 0x7FFFu) | ((neg ^ sg) << 15));
         hi8[(size_t)w * n + i] = d == 0 ? (uint8_t)0xFF : (uint8_t)((uint32_t)w * gw + (b >> 15));  // gw = groups per window (0: merged set)
     }
 }
@@ -657,6 +669,130 @@ static __global__ void __launch_bounds__(1024) k_msm_fine_sort_big(const uint16_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ GLV front end
+// BLS12-381 G1 has the endomorphism phi(x, y) = (beta x, y) = [lambda](x, y) with lambda = z^2 - 1 and r = lambda^2 + lambda + 1.  A plain
+// MSM over n points and 255-bit scalars becomes one over 2n points (P_i and phi(P_i)) and signed 127-bit half-scalars:
+//     k = k1 + k2 lambda,  k2 = floor(k / lambda), k1 = k mod lambda,  then balanced into |k1|, |k2| <= lambda / 2 + 1 < 2^127
+//     (k1 > lambda / 2: k1 -= lambda, k2 += 1;   k2 > lambda / 2: k2 -= lambda + 1, k1 -= 1   -- lambda^2 = -lambda - 1 mod r)
+// The number of (point, window) additions is unchanged (2n half-scalars x half as many windows), but there are half as many bucket
+// sets to merge and reduce and half as many windows in the host Horner -- the parts that dominate small and mid-size MSMs.  The group
+// law makes the result identical.  arkworks 0.3 does not use the endomorphism in VariableBaseMSM; results do not depend on it.
+struct zl_u128 { uint64_t lo, hi; };
+__device__ __forceinline__ bool zl_gt(zl_u128 a, zl_u128 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
+__device__ __forceinline__ bool zl_ge(zl_u128 a, zl_u128 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
+__device__ __forceinline__ zl_u128 zl_sub(zl_u128 a, zl_u128 b) { return zl_u128{a.lo - b.lo, a.hi - b.hi - (a.lo < b.lo ? 1u : 0u)}; }
+__device__ __forceinline__ zl_u128 zl_inc(zl_u128 a) { return zl_u128{a.lo + 1, a.hi + (a.lo + 1 == 0 ? 1u : 0u)}; }
+__device__ __forceinline__ zl_u128 zl_dec(zl_u128 a) { return zl_u128{a.lo - 1, a.hi - (a.lo == 0 ? 1u : 0u)}; }
+// out: 2n records of 8 words -- record i = k1 of scalar i, record n + i = k2 of scalar i; magnitude in words 0..3, sign in bit 31 of word 7.
+// Scalars of bases at infinity give two zero records; a scalar with bits at or above sc_bits sets *bad (not canonical).
+template <class P>
+__global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ scalars, uint32_t n, const uint8_t* __restrict__ inf, uint32_t* __restrict__ out,
+                                                    int sc_bits, uint32_t* __restrict__ bad) {
+    ZL_SIDE_PRIO();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 lo4 = sp[0], hi4 = sp[1];
+    zl_flag_wide_scalar(hi4.w, sc_bits, bad);
+    if (inf && inf[i]) lo4 = hi4 = make_uint4(0, 0, 0, 0);
+    const uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    // q = floor(k m / 2^383), m = floor(2^383 / lambda): the quotient or one less
+    uint32_t pw[16];
+    {
+        uint64_t acc = 0;
+        uint32_t top = 0;
+#pragma unroll
+        for (int col = 0; col < 15; col++) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const int b = col - a;
+                if (b < 0 || b > 7) continue;
+                const uint64_t pr = (uint64_t)k[a] * P::barrett(b);
+                acc += pr;
+                top += acc < pr ? 1u : 0u;
+            }
+            pw[col] = (uint32_t)acc;
+            acc = (acc >> 32) | ((uint64_t)top << 32);
+            top = 0;
+        }
+        pw[15] = (uint32_t)acc;
+    }
+    zl_u128 q{((uint64_t)(pw[11] >> 31) | ((uint64_t)pw[12] << 1) | ((uint64_t)pw[13] << 33)), ((uint64_t)(pw[13] >> 31) | ((uint64_t)pw[14] << 1) | ((uint64_t)pw[15] << 33))};
+    const uint32_t qw[4] = {(uint32_t)q.lo, (uint32_t)(q.lo >> 32), (uint32_t)q.hi, (uint32_t)(q.hi >> 32)};
+    // k1 = k - q lambda (mod 2^160; the true value is below 2 lambda < 2^129)
+    uint32_t t[5];
+    {
+        uint64_t acc = 0;
+        uint32_t top = 0;
+#pragma unroll
+        for (int col = 0; col < 5; col++) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int b = col - a;
+                if (b < 0 || b > 3) continue;
+                const uint64_t pr = (uint64_t)qw[a] * P::lambda(b);
+                acc += pr;
+                top += acc < pr ? 1u : 0u;
+            }
+            t[col] = (uint32_t)acc;
+            acc = (acc >> 32) | ((uint64_t)top << 32);
+            top = 0;
+        }
+    }
+    uint32_t d[5];
+    {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+            const uint64_t x = (uint64_t)k[w] - t[w] - borrow;
+            d[w] = (uint32_t)x;
+            borrow = (uint32_t)(x >> 63);
+        }
+    }
+    const zl_u128 LAM{(uint64_t)P::lambda(0) | ((uint64_t)P::lambda(1) << 32), (uint64_t)P::lambda(2) | ((uint64_t)P::lambda(3) << 32)};
+    const zl_u128 HALF{(LAM.lo >> 1) | (LAM.hi << 63), LAM.hi >> 1};
+    zl_u128 k1{(uint64_t)d[0] | ((uint64_t)d[1] << 32), (uint64_t)d[2] | ((uint64_t)d[3] << 32)};
+    uint32_t k1top = d[4];
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        if (k1top != 0u || zl_ge(k1, LAM)) {
+            const bool br = zl_gt(LAM, k1);
+            k1 = zl_sub(k1, LAM);
+            k1top -= br ? 1u : 0u;
+            q = zl_inc(q);
+        }
+    }
+    zl_u128 k2 = q;
+    uint32_t neg1 = 0, neg2 = 0;
+    if (zl_gt(k1, HALF)) { k1 = zl_sub(LAM, k1); neg1 = 1; k2 = zl_inc(k2); }
+    if (zl_gt(k2, HALF)) {
+        k2 = zl_sub(zl_inc(LAM), k2);
+        neg2 = 1;
+        if (neg1) k1 = zl_inc(k1);
+        else if ((k1.lo | k1.hi) == 0) { k1.lo = 1; neg1 = 1; }
+        else k1 = zl_dec(k1);
+    }
+    if ((k1.lo | k1.hi) == 0) neg1 = 0;
+    if ((k2.lo | k2.hi) == 0) neg2 = 0;
+    uint4* o1 = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    uint4* o2 = reinterpret_cast<uint4*>(out + ((size_t)n + i) * 8);
+    o1[0] = make_uint4((uint32_t)k1.lo, (uint32_t)(k1.lo >> 32), (uint32_t)k1.hi, (uint32_t)(k1.hi >> 32));
+    o1[1] = make_uint4(0, 0, 0, neg1 << 31);
+    o2[0] = make_uint4((uint32_t)k2.lo, (uint32_t)(k2.lo >> 32), (uint32_t)k2.hi, (uint32_t)(k2.hi >> 32));
+    o2[1] = make_uint4(0, 0, 0, neg2 << 31);
+}
+// phib[i] = phi(P_i) = (beta x_i, y_i); the point at infinity (all-zero) stays itself
+template <class G>
+__global__ void __launch_bounds__(128) k_glv_phi(const Affine<typename G::F>* __restrict__ bases, uint32_t n, Affine<typename G::F>* __restrict__ phib) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = bases[i];
+    if (!p.is_inf()) p.x = zl::canon(zl::mul(p.x, G::glv_beta()));
+    phib[i] = p;
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan of `count` u32 values, 3 launches; out[count] = total
 #define SCAN_ITEMS 16
@@ -749,10 +885,12 @@ template <class G>
 __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases_,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums_,
-                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK) {
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
     using F = typename HotField<typename G::F>::type;  // same layout as G::F; Fq2 on 28-bit limbs: the inlining flavour (zl_curve.h)
     static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
     const Affine<F>* __restrict__ bases = reinterpret_cast<const Affine<F>*>(bases_);
+    const Affine<F>* __restrict__ phib = reinterpret_cast<const Affine<F>*>(phib_) - n_real;  // GLV: virtual point n_real + i = phi(P_i); else n_real = 2^32 - 1 (never selected)
     XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
     XYZZ<F>* __restrict__ partials = reinterpret_cast<XYZZ<F>*>(partials_);
     const uint32_t E = offsets[NB];
@@ -778,7 +916,8 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
             b_end = offsets[b + 1];
         }
         const uint32_t ent = entries[e];
-        const Affine<F> P = bases[ent & 0x7fffffffu];
+        const uint32_t idx = ent & 0x7fffffffu;
+        const Affine<F> P = (G::GLV && idx >= n_real ? phib : bases)[idx];
         if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
     }
     // last segment [max(b_start,start), end) of bucket b
@@ -787,14 +926,24 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
     else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
 }
 
+// The merge / level-0 / tree kernels of an Fq2 group can compute in the inlining flavour of the field like the accumulation kernel
+// (-DZL_HOT_TAILS): their out-of-line Fq2 product routines take 56 scalar arguments, 24 of which travel on the stack (236 - 1260 B of
+// scratch per lane in round 2's G2 tails).
+#ifdef ZL_HOT_TAILS
+template <class F> using TailF = typename HotField<F>::type;
+#else
+template <class F> using TailF = F;
+#endif
 // one lane per bucket: empty -> infinity; cut into <= ZL_BIG_SPAN chunks -> fold partials; else defer to a block
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
-                                                   const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
+__global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                   const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
                                                    uint32_t ZL_CHUNK, uint32_t big_span) {
     ZL_SIDE_PRIO();
-    using F = typename G::F;
+    using F = TailF<typename G::F>;
+    XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
+    const XYZZ<F>* __restrict__ partials = reinterpret_cast<const XYZZ<F>*>(partials_);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
     const uint32_t s = offsets[b], e = offsets[b + 1];
@@ -897,7 +1046,8 @@ __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __
 
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __restrict__ ones_list, const uint32_t* __restrict__ ones_count,
-                                                   const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out) {
+                                                   const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out,
+                                                   const Affine<typename G::F>* __restrict__ phib, uint32_t n_real) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -905,7 +1055,8 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
     const uint32_t cnt = *ones_count;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
-        const Affine<F> P = bases[ones_list[j]];
+        const uint32_t idx = ones_list[j];
+        const Affine<F> P = (G::GLV && idx >= n_real) ? phib[idx - n_real] : bases[idx];  // GLV: a half-scalar k2 = 1 names phi(P)
         if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, false);
     }
     zl_block_tree<G>(sh, acc);
@@ -927,11 +1078,13 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 // flat_set: the spread top window (k_msm_recode_wide): its buckets are weighted by their low spread_t bits only; level 0 is weightless
 // for it when spread_t == 0, and the host skips its S_b from bit spread_t on.
 template <class G>
-__global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
+__global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets_, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
-                                                           XYZZ<typename G::F>* __restrict__ out /* [set][block][2]: T, A */) {
+                                                           XYZZ<typename G::F>* __restrict__ out_ /* [set][block][2]: T, A */) {
     ZL_SIDE_PRIO();
-    using X = XYZZ<typename G::F>;
+    using X = XYZZ<TailF<typename G::F>>;
+    const X* __restrict__ buckets = reinterpret_cast<const X*>(buckets_);
+    X* __restrict__ out = reinterpret_cast<X*>(out_);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_blocks) return;
     const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
@@ -950,10 +1103,12 @@ __global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_redu
 // one tree level: nodes of `level` (1-based) from the nodes of level - 1.  Node layout: [set][node][channel], ch_in = level + 1 channels
 // in (T, A, S_0 .. S_(level-2)), ch_out = level + 2 out.  One lane per (set, node, out channel).
 template <class G>
-__global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F>* __restrict__ in, XYZZ<typename G::F>* __restrict__ out, uint32_t level,
+__global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F>* __restrict__ in_, XYZZ<typename G::F>* __restrict__ out_, uint32_t level,
                                                          uint32_t nodes_out_per_set, uint32_t total_lanes) {
     ZL_SIDE_PRIO();
-    using X = XYZZ<typename G::F>;
+    using X = XYZZ<TailF<typename G::F>>;
+    const X* __restrict__ in = reinterpret_cast<const X*>(in_);
+    X* __restrict__ out = reinterpret_cast<X*>(out_);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_lanes) return;
     const uint32_t ch_out = level + 2, ch_in = level + 1;
@@ -1170,7 +1325,7 @@ static int zl_tune(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int zl_pick_window(size_t n, int sc_bits) {
+static int zl_pick_window(size_t n, int sc_bits, bool wide16 = false /* c = 16 also runs the three-level sort (GLV jobs) */) {
     // cost in accumulated entries: n per window (+10 % for c <= 16: the one-level LDS counting sort streams every window's digits once per
     // bucket range and is the slower sort at large n) + ~5.7 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
     // single-call times at 2^20 .. 2^24, both curves (profiles/r02_msm_sweep_plain.log, r02_msm_sweep_bn254.log): picks 16 up to 2^21,
@@ -1181,7 +1336,8 @@ static int zl_pick_window(size_t n, int sc_bits) {
     for (int c = 2; c <= 20; c++) {
         int W = (sc_bits + 1 + c - 1) / c;
         if (c > 16 && (((uint64_t)W << (c - 1)) >> 15) > 255) continue;
-        double cost = (double)n * W * (c <= 16 ? 1.10 : 1.0) + per_bucket * W * (double)(1u << (c - 1));
+        const bool lds_sort = c < 16 || (c == 16 && !wide16);
+        double cost = (double)n * W * (lds_sort ? 1.10 : 1.0) + per_bucket * W * (double)(1u << (c - 1));
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
@@ -1216,6 +1372,12 @@ struct MsmJob {
     int c = 0, W = 0;
     int spread_t = -1;  // >= 0: the top window's entries are spread over its bucket set, weights = low spread_t bits + 1
     bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
+    bool glv = false;   // the job runs on 2 n_real half-scalars of 127 bits over the points P_i and phi(P_i) (k_glv_split / k_glv_phi)
+    bool phi_owner = false;  // this job computes the phi image of its bases in its sort phase (else it borrows d_phi from an earlier job of the call)
+    int sc_bits = 0, phi_slot = -1;
+    size_t n_real = 0;
+    uint32_t* d_vs = nullptr;            // the half-scalars (inside the sort temporaries)
+    const Affine<F>* d_phi = nullptr;    // phi(P_i), i < n_real
     uint32_t H = 0, SETS = 0, NB = 0, ZL_CHUNK = 0, nchunks = 0, scan_blocks = 0, max_big = 0, max_giant = 0, Gn = 0, big_span = ZL_BIG_SPAN;
     uint32_t red_g0 = 0, red_lg0 = 0, red_blocks = 0, red_levels = 0;  // bucket reduction: block length of level 0, blocks per set, tree levels
     uint32_t roots_per_set = 0;                                         // channels of a set's root node: T, A, S_0 .. S_(levels-1)
@@ -1237,15 +1399,37 @@ struct MsmJob {
     std::vector<X> hw_own;
     uint32_t hE_own[2] = {0, 0};
 
-    int plan(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_) {
-        n = n_;
+    // phi_slot_: scratch slot for the endomorphism image of the bases when this job computes it (GLV); -1 = never use the endomorphism
+    int plan(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_, int phi_slot_ = -1) {
+        static const bool no_glv = getenv("ZL_NO_GLV") != nullptr;  // developer A/B switch
+        bool try_glv = false;
+        // Measured (round 3, profiles/r03_glv_ab.log): halving the bucket sets wins where the merge / reduction tails and the host Horner dominate
+        // (2^16: 1.07 -> 1.00 ms, 2^18: 1.67 -> 1.63 ms, Groth16 k = 64: 3.8 -> 3.6 ms); from 2^20 on the split, the phi image of the bases
+        // (read + write of every point) and the three-level sort of 2 n records cost what the tail saves (2^20: 3.73 = 3.73 ms; 2^24 single
+        // call 39.2 -> 39.7 ms, pipelined 36.7 = 36.7), so large inputs keep the plain 255-bit windows.
+        static const size_t glv_max = (size_t)1 << zl_tune("ZL_TUNE_GLV_MAX_LOG", 19);
+        if constexpr (G::GLV) try_glv = phi_slot_ >= 0 && bs.precomp_c == 0 && !no_glv && n_ >= 1 && n_ <= glv_max && n_ < (1ull << 30);
+        int rc = plan_as(ctx, bs, first_, d_scalars, n_, try_glv);
+        // (c <= 3: the top window of a 127-bit half-scalar can reach magnitude H + carry; not worth a special case)
+        if (!rc && glv && c <= 3) rc = plan_as(ctx, bs, first_, d_scalars, n_, false);
+        // the global-atomics sort (forced plain c >= 21 beyond 255 sort groups) does not take half-scalars: plan again without them
+        if (!rc && glv && !wide && c > 16) rc = plan_as(ctx, bs, first_, d_scalars, n_, false);
+        phi_slot = glv ? phi_slot_ : -1;
+        phi_owner = glv;
+        return rc;
+    }
+    int plan_as(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_, bool glv_) {
+        glv = glv_;
+        n_real = n_;
+        n = glv ? 2 * n_ : n_;
+        sc_bits = glv ? 127 : (int)G::SC_BITS;
         first = first_;
         bsp = &bs;
         pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
-        c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, G::SC_BITS));
+        c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, sc_bits, glv));
         if (c < 2) c = 2;
         if (c > 24) c = 24;
-        W = (G::SC_BITS + 1 + c - 1) / c;
+        W = (sc_bits + 1 + c - 1) / c;
         H = 1u << (c - 1);
         SETS = pre ? 1u : (uint32_t)W;  // bucket sets
         const uint64_t NB64 = (uint64_t)SETS * H;
@@ -1255,7 +1439,9 @@ struct MsmJob {
         NB = (uint32_t)NB64;
         Gn = NB >> 15;  // sort groups of 32768 (window, bucket) ids; the group id travels in a byte, 0xFF = zero digit
         if (pre && (c < 16 || Gn < 1 || Gn > 255)) return ZL_EINVAL;
-        wide = pre || (c > 16 && Gn <= 255);  // plain windows beyond that (c >= 21) fall back to the global-atomics sort
+        // plain windows beyond that (c >= 21) fall back to the global-atomics sort.  Half-scalars at c = 16 take the wide sort too: its
+        // zero-digit marker lives in hi8, while the 16-bit code of the LDS sort has no room for a digit of magnitude H with the sign set
+        wide = pre || ((c > 16 || (glv && c == 16)) && Gn >= 1 && Gn <= 255);
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         // (128 once there are >= 2^20 lanes of that length: half as many cut buckets to merge; 32.8 -> 32.2 ms per pipelined 2^24 MSM)
         ZL_CHUNK = (maxE >> 7) >= (1u << 20) ? 128u : (uint32_t)ZL_CHUNK_MAX;
@@ -1274,7 +1460,7 @@ struct MsmJob {
             // window, 0 < spread_t < log2 g0, shortens the level-0 blocks to 2^spread_t)
             spread_t = -1;
             if ((wide || c <= 16) && !pre) {  // (the global-atomics sort of plain c >= 21 keeps its crowded top window)
-                const int top_bits = G::SC_BITS + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
+                const int top_bits = sc_bits + 1 - (W - 1) * c;  // bits of the top window incl. the carry: magnitudes <= 2^(top_bits - 1)
                 if (top_bits - 1 < c - 1) {
                     spread_t = top_bits - 1;
                     if (spread_t > 0 && (1u << spread_t) < g0) g0 = 1u << spread_t;
@@ -1336,11 +1522,20 @@ struct MsmJob {
         d_sets = d_stage1 + lvl1_elems;    // the root channels of every set, then the sum of the scalar-1 bases
         d_ones_parts = d_sets + root_elems + 1;
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
+        if (glv && phi_owner) {
+            if ((rc = zl_scratch_get(ctx, phi_slot, n_real * sizeof(Affine<F>), &p))) return rc;
+            d_phi = reinterpret_cast<const Affine<F>*>(p);
+        }
         return ZL_OK;
     }
     // sizes of the sort temporaries (slots 5 and 6), as sort() requests them: a heterogeneous pipeline grows the slots to the
     // largest job before anything is in flight (a growing zl_scratch_get frees the old block)
+    size_t vs_bytes() const { return glv ? (((size_t)n * 32 + 255) / 256) * 256 : 0; }  // the half-scalars live behind the slot-5 temporaries
     void sort_tmp_sizes(size_t& s5, size_t& s6) const {
+        sort_tmp_sizes_(s5, s6);
+        if (glv) s5 = ((s5 + 255) / 256) * 256 + vs_bytes();
+    }
+    void sort_tmp_sizes_(size_t& s5, size_t& s6) const {
         s5 = s6 = 0;
         if (wide) {
             uint32_t nslices = 64;
@@ -1371,6 +1566,26 @@ struct MsmJob {
         ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 32, st));  // big, ones, giant counts; [4..5]: oversized sub-group queue head (u64)
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
+        // GLV front end: half-scalars behind the slot-5 temporaries, phi image of the bases (once per call for a batch over one key)
+        const uint32_t* sc_eff = sc;
+        const uint8_t* inf_eff = d_inf;
+        uint32_t* bad_eff = d_bad_scalar;
+        if (glv) {
+            size_t s5tot, s6tot;
+            sort_tmp_sizes(s5tot, s6tot);
+            void* p5;
+            if ((rc = zl_scratch_get(ctx, 5, s5tot, &p5))) return rc;
+            d_vs = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p5) + (s5tot - vs_bytes()));
+            if constexpr (G::GLV) {
+                hipLaunchKernelGGL((k_glv_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
+                if (phi_owner)
+                    hipLaunchKernelGGL((k_glv_phi<G>), dim3((uint32_t)((n_real + 127) / 128)), dim3(128), 0, st, d_bases, (uint32_t)n_real, const_cast<Affine<F>*>(d_phi));
+            }
+            sc_eff = d_vs;
+            inf_eff = nullptr;  // the split already dropped the scalars of bases at infinity
+            bad_eff = nullptr;  // ... and checked the scalars' width
+        }
+        const int glv_i = glv ? 1 : 0;
         // per call, not once per process: the attribute is per device and a process may own several contexts
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -1395,7 +1610,7 @@ struct MsmJob {
             uint32_t* d_pcounts = (uint32_t*)q;
             uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
             uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, d_lo16, d_hi8, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
+            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, glv_i, d_lo16, d_hi8, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
             hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P, (const uint32_t*)nullptr);
@@ -1449,7 +1664,7 @@ struct MsmJob {
             if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, spread_t, d_digits, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
+            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
@@ -1473,7 +1688,8 @@ struct MsmJob {
         return ZL_OK;
     }
     int accumulate(zl_ctx* ctx, hipStream_t st) {
-        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK);
+        hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+                           glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         ZL_HIP(ctx, hipGetLastError());
         return ZL_OK;
     }
@@ -1486,7 +1702,7 @@ struct MsmJob {
         hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count);
         // scalar-1 bases: window-0 table entries are the bases themselves
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
-                           pre ? d_bases + first : d_bases, d_ones_parts);
+                           pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
                            (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set);
         {
@@ -1553,7 +1769,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         const auto tp0 = std::chrono::steady_clock::now();
         MsmJob<G> job;
         int rc;
-        if ((rc = job.plan(ctx, bs, first, d_scalars, n))) return rc;
+        if ((rc = job.plan(ctx, bs, first, d_scalars, n, 18))) return rc;
         if ((rc = job.alloc(ctx, 0))) return rc;
         const auto tp1 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
@@ -1629,8 +1845,14 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     std::vector<MsmJob<G>> jobs(count);
     size_t t5 = 0, t6 = 0;
     uint32_t max_sets = 0;
+    // GLV jobs need phi(P_i) of their bases: a batch over ONE key computes it once (job 0, slot 18; the later jobs borrow the pointer --
+    // their sorts run behind job 0's on the sort stream), a heterogeneous batch once per job in the slot of its buffer set (20 + i % 3: free
+    // again when the tail of job i - 3 has finished, like the rest of the set)
+    bool one_key = true;
+    for (size_t i = 1; i < count; i++) one_key = one_key && specs[i].bs == specs[0].bs && specs[i].first == specs[0].first && specs[i].n == specs[0].n;
     for (size_t i = 0; i < count; i++) {
-        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n))) return rc;
+        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, one_key ? 18 : 20 + (int)(i % 3)))) return rc;
+        if (one_key && i > 0) jobs[i].phi_owner = false;
         size_t a5, a6;
         jobs[i].sort_tmp_sizes(a5, a6);
         t5 = std::max(t5, a5);
@@ -1646,6 +1868,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     for (int pass = 0; pass < 2; pass++) {
         for (size_t i = 0; i < count; i++) {
             if ((rc = jobs[i].alloc(ctx, (int)(i % 3)))) return rc;
+            if (one_key && i > 0 && jobs[i].glv) jobs[i].d_phi = jobs[0].d_phi;
         }
     }
     const size_t per = sizeof(X) * (max_sets + 1) + 16;

@@ -1,0 +1,329 @@
+//! Groth16 [`ProofSystem`] for OpenZL with the prover's hot path (5 MSMs + 7 NTTs behind `ark_groth16::create_random_proof`,
+//! reached from `plugins/arkworks/src/groth16.rs:454`) on an AMD MI355X through `libzl_backend.so`.
+//!
+//! **SOURCE ONLY -- never compiled or tested**: the build image of this repository has no `cargo` / `rustc`.  What *is*
+//! tested is the C ABI this file binds (`include/zl_backend.h`, driven through ctypes by `tests/test_gpu_*.py`), and `src/ffi.rs` is
+//! generated from that header (`tools/gen_rust_ffi.py`; `tests/test_abi.py::test_rust_ffi_matches_header` keeps them in step).
+//!
+//! Same trait surface as the reference's `Groth16<E>` (`plugins/arkworks/src/groth16.rs:405-467`):
+//! `Compiler = R1CS<E::Fr>`, `PublicParameters = ()`, `Input = Vec<E::Fr>`, `Proof = Proof<E>`, `VerifyingContext<E>`, opaque `Error`,
+//! so the ECLAIR / gadget stack above it is unchanged.  Only `ProvingContext` differs: it also owns the device-resident copy of the key.
+//!
+//! * `compile`: arkworks' own circuit-specific setup on the CPU (one-time), then the proving key goes to the device in the reference's
+//!   own wire format (`ProvingKey::serialize_unchecked`, what `ProvingContext: codec::Encode` writes, groth16.rs:166-179) through
+//!   `zl_groth16_keys_from_bytes`.
+//! * `prove`: the constraint matrices are uploaded once per context (`zl_r1cs_upload`), every proof ships only the assignment in
+//!   arkworks' in-memory Montgomery limbs (`zl_groth16_prove_resident`, `ZL_MONT`) and the two blinding scalars sampled here with
+//!   `E::Fr::rand`, exactly as `create_random_proof` samples them.
+//! * `verify`: arkworks' own (`verify_with_processed_vk`), unchanged.
+#![allow(clippy::missing_safety_doc)]
+
+pub mod ffi;
+
+use ark_ec::{AffineCurve, PairingEngine};
+use ark_ff::{BigInteger, Field, FromBytes, PrimeField, UniformRand, Zero};
+use ark_groth16::{Groth16 as ArkGroth16, Proof as ArkProof, ProvingKey};
+use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystem, OptimizationGoal, SynthesisMode};
+use ark_serialize::CanonicalSerialize;
+use ark_snark::SNARK;
+use core::{cell::Cell, marker::PhantomData, ptr};
+use openzl_crypto::constraint::ProofSystem;
+use openzl_plugin_arkworks::{
+    constraint::R1CS,
+    groth16::{Error, Proof, VerifyingContext},
+};
+use openzl_util::rand::{CryptoRng, RngCore, SizedRng};
+
+/// The two pairing engines the backend is built for (include/zl_backend.h: `zl_curve_t`).
+pub trait Mi355xEngine: PairingEngine {
+    /// `ZL_BLS12_381` or `ZL_BN254`
+    const CURVE: i32;
+    /// u64 limbs per base-field element in the ABI layouts (6 / 4)
+    const FQ_LIMBS: usize;
+}
+impl Mi355xEngine for ark_bls12_381::Bls12_381 {
+    const CURVE: i32 = ffi::ZL_BLS12_381;
+    const FQ_LIMBS: usize = 6;
+}
+impl Mi355xEngine for ark_bn254::Bn254 {
+    const CURVE: i32 = ffi::ZL_BN254;
+    const FQ_LIMBS: usize = 4;
+}
+
+std::thread_local! {
+    /// One `zl_ctx` per thread: a ctx is bound to one GPU / stream and used from one thread at a time (zl_backend.h, "Conventions");
+    /// the reference's compiler is `!Send` (`ConstraintSystemRef` is an `Rc`), so `prove` is single-threaded per call anyway.
+    static CTX: Cell<*mut ffi::zl_ctx> = Cell::new(ptr::null_mut());
+}
+
+/// The calling thread's context on device `ZL_DEVICE` (default 0), created on first use.
+fn ctx() -> Result<*mut ffi::zl_ctx, Error> {
+    CTX.with(|c| {
+        if c.get().is_null() {
+            let device = std::env::var("ZL_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0);
+            let mut p = ptr::null_mut();
+            // every failure collapses into the plugin's opaque Error, like `.map_err(|_| Error)` at groth16.rs:438-465
+            if unsafe { ffi::zl_ctx_create(&mut p, device) } != ffi::ZL_OK {
+                return Err(Error);
+            }
+            c.set(p);
+        }
+        Ok(c.get())
+    })
+}
+
+/// Proving context: the arkworks proving key (kept for `Encode` / inspection) and its device-resident twin.
+pub struct ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    /// The key as arkworks holds it (`ProvingContext<E>(pub ProvingKey<E>)`, groth16.rs:127-140)
+    pub key: ProvingKey<E>,
+    keys: *mut ffi::zl_g16_keys,
+    /// `zl_r1cs_upload` handle of the circuit this key was compiled for (0 until the first proof)
+    r1cs: Cell<u64>,
+}
+
+impl<E> Drop for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn drop(&mut self) {
+        // keys hold bases handles of the ctx they were created on: free them before that ctx (zl_backend.h: zl_groth16_keys_free)
+        unsafe {
+            if let Ok(c) = ctx() {
+                if self.r1cs.get() != 0 {
+                    ffi::zl_r1cs_free(c, self.r1cs.get());
+                }
+            }
+            ffi::zl_groth16_keys_free(self.keys);
+        }
+    }
+}
+
+/// Groth16 on the MI355X backend
+#[derive(Clone, Copy, Debug, Default)]
+pub struct Groth16Mi355x<E>(PhantomData<E>)
+where
+    E: Mi355xEngine;
+
+/// `[u64]` limbs (canonical, little-endian) -> a base-field element
+fn fq_from_limbs<F: PrimeField>(limbs: &[u64]) -> F {
+    let mut bytes = Vec::with_capacity(limbs.len() * 8);
+    for l in limbs {
+        bytes.extend_from_slice(&l.to_le_bytes());
+    }
+    F::from_repr(<F::BigInt as FromBytes>::read(&bytes[..]).expect("limb count matches the field")).expect("the backend returns canonical residues")
+}
+
+impl<E> Groth16Mi355x<E>
+where
+    E: Mi355xEngine,
+    E::Fq: PrimeField,
+{
+    fn g1(xy: &[u64], inf: u8) -> E::G1Affine
+    where
+        E::G1Affine: From<(E::Fq, E::Fq)>,
+    {
+        if inf != 0 {
+            return E::G1Affine::zero();
+        }
+        let n = E::FQ_LIMBS;
+        (fq_from_limbs::<E::Fq>(&xy[..n]), fq_from_limbs::<E::Fq>(&xy[n..2 * n])).into()
+    }
+}
+
+impl<E> ProofSystem for Groth16Mi355x<E>
+where
+    E: Mi355xEngine,
+    E::Fq: PrimeField,
+    E::G1Affine: From<(E::Fq, E::Fq)>,
+    E::G2Affine: From<([E::Fq; 2], [E::Fq; 2])>,
+{
+    type Compiler = R1CS<E::Fr>;
+    type PublicParameters = ();
+    type ProvingContext = ProvingContext<E>;
+    type VerifyingContext = VerifyingContext<E>;
+    type Input = Vec<E::Fr>;
+    type Proof = Proof<E>;
+    type Error = Error;
+
+    #[inline]
+    fn context_compiler() -> Self::Compiler {
+        Self::Compiler::for_contexts()
+    }
+
+    #[inline]
+    fn proof_compiler() -> Self::Compiler {
+        Self::Compiler::for_proofs()
+    }
+
+    fn compile<R>(
+        public_parameters: &Self::PublicParameters,
+        compiler: Self::Compiler,
+        rng: &mut R,
+    ) -> Result<(Self::ProvingContext, Self::VerifyingContext), Self::Error>
+    where
+        R: CryptoRng + RngCore + ?Sized,
+    {
+        let _ = public_parameters;
+        // the trusted setup stays arkworks' (one-time per circuit; groth16.rs:438)
+        let (key, verifying_key) = ArkGroth16::<E>::circuit_specific_setup(compiler, &mut SizedRng(rng)).map_err(|_| Error)?;
+        // ... and travels to the device in the reference's own wire format (ProvingKey::serialize_unchecked)
+        let mut bytes = Vec::new();
+        key.serialize_unchecked(&mut bytes).map_err(|_| Error)?;
+        let mut keys = ptr::null_mut();
+        let rc = unsafe { ffi::zl_groth16_keys_from_bytes(ctx()?, E::CURVE, bytes.as_ptr(), bytes.len(), 0, &mut keys) };
+        if rc != ffi::ZL_OK {
+            return Err(Error);
+        }
+        Ok((
+            ProvingContext { key, keys, r1cs: Cell::new(0) },
+            VerifyingContext(ArkGroth16::<E>::process_vk(&verifying_key).map_err(|_| Error)?),
+        ))
+    }
+
+    fn prove<R>(context: &Self::ProvingContext, compiler: Self::Compiler, rng: &mut R) -> Result<Self::Proof, Self::Error>
+    where
+        R: CryptoRng + RngCore + ?Sized,
+    {
+        let c = ctx()?;
+        // what ark_groth16::create_proof_with_reduction does first: move the finished constraint system into a prove-mode one
+        let cs = ConstraintSystem::<E::Fr>::new_ref();
+        cs.set_optimization_goal(OptimizationGoal::Constraints);
+        cs.set_mode(SynthesisMode::Prove { construct_matrices: true });
+        compiler.generate_constraints(cs.clone()).map_err(|_| Error)?;
+        cs.finalize();
+        // the matrices are static per circuit: uploaded with the first proof, device-resident afterwards
+        if context.r1cs.get() == 0 {
+            let m = cs.to_matrices().ok_or(Error)?;
+            let csr = |rows: &Vec<Vec<(E::Fr, usize)>>| {
+                let (mut ptr_, mut col, mut val) = (vec![0u32], Vec::new(), Vec::<u64>::new());
+                for row in rows {
+                    for (coeff, index) in row {
+                        col.push(*index as u32);
+                        val.extend_from_slice(coeff.into_repr().as_ref()); // canonical integers (zl_r1cs: "coefficients ... canonical")
+                    }
+                    ptr_.push(col.len() as u32);
+                }
+                (ptr_, col, val)
+            };
+            let (a, b, cc) = (csr(&m.a), csr(&m.b), csr(&m.c));
+            let view = ffi::zl_r1cs {
+                n_constraints: m.num_constraints as u32,
+                n_instance: m.num_instance_variables as u32,
+                n_witness: m.num_witness_variables as u32,
+                row_ptr: [a.0.as_ptr(), b.0.as_ptr(), cc.0.as_ptr()],
+                col: [a.1.as_ptr(), b.1.as_ptr(), cc.1.as_ptr()],
+                val: [a.2.as_ptr(), b.2.as_ptr(), cc.2.as_ptr()],
+            };
+            let mut handle = 0u64;
+            if unsafe { ffi::zl_r1cs_upload(c, E::CURVE, &view, &mut handle) } != ffi::ZL_OK {
+                return Err(Error);
+            }
+            context.r1cs.set(handle);
+        }
+        // assignment = instance block (ONE, public inputs) then witnesses, as arkworks' in-memory Montgomery limbs: E::Fr is a
+        // single-field tuple struct over BigInteger256, itself a single-field tuple struct over [u64; 4]; ark-ff 0.3 declares no
+        // #[repr] on either, so this relies on the layout rustc gives single-field structs today (checked by the size assertion)
+        assert_eq!(core::mem::size_of::<E::Fr>(), 32);
+        let (instance, witness) = {
+            let inner = cs.borrow().ok_or(Error)?;
+            (inner.instance_assignment.clone(), inner.witness_assignment.clone())
+        };
+        let mut assignment = Vec::<E::Fr>::with_capacity(instance.len() + witness.len());
+        assignment.extend_from_slice(&instance);
+        assignment.extend_from_slice(&witness);
+        // the blinding scalars, sampled exactly where create_random_proof samples them (r then s)
+        let mut sized = SizedRng(rng);
+        let r = E::Fr::rand(&mut sized).into_repr();
+        let s = E::Fr::rand(&mut sized).into_repr();
+        let mut pk = core::mem::MaybeUninit::<ffi::zl_g16_pk>::zeroed();
+        let mut out = core::mem::MaybeUninit::<ffi::zl_g16_proof>::zeroed();
+        let rc = unsafe {
+            if ffi::zl_groth16_keys_pk(context.keys, pk.as_mut_ptr()) != ffi::ZL_OK {
+                return Err(Error);
+            }
+            ffi::zl_groth16_prove_resident(
+                c,
+                pk.as_ptr(),
+                context.r1cs.get(),
+                assignment.as_ptr() as *const u64,
+                ffi::ZL_MONT,
+                r.as_ref().as_ptr(),
+                s.as_ref().as_ptr(),
+                out.as_mut_ptr(),
+            )
+        };
+        if rc != ffi::ZL_OK {
+            return Err(Error); // .map_err(|_| Error) groth16.rs:456
+        }
+        let p = unsafe { out.assume_init() };
+        let n = E::FQ_LIMBS;
+        let b = if p.b_inf != 0 {
+            E::G2Affine::zero()
+        } else {
+            // G2: x.c0 || x.c1 || y.c0 || y.c1 (zl_backend.h)
+            let f = |k: usize| fq_from_limbs::<E::Fq>(&p.b[k * n..(k + 1) * n]);
+            ([f(0), f(1)], [f(2), f(3)]).into()
+        };
+        Ok(Proof(ArkProof { a: Self::g1(&p.a, p.a_inf), b, c: Self::g1(&p.c, p.c_inf) }))
+    }
+
+    #[inline]
+    fn verify(context: &Self::VerifyingContext, input: &Self::Input, proof: &Self::Proof) -> Result<bool, Self::Error> {
+        ArkGroth16::<E>::verify_with_processed_vk(&context.0, input, &proof.0).map_err(|_| Error)
+    }
+}
+
+/// Drop-in for `ark_ec::msm::VariableBaseMSM::multi_scalar_mul::<G>(bases, scalars)` against bases uploaded once with
+/// [`upload_g1_bases`]: `scalars` are `into_repr()` canonical integers, passed as they lie in memory.
+pub fn msm_g1<E>(bases: u64, scalars: &[<E::Fr as PrimeField>::BigInt]) -> Result<E::G1Affine, Error>
+where
+    E: Mi355xEngine,
+    E::Fq: PrimeField,
+    E::G1Affine: From<(E::Fq, E::Fq)>,
+{
+    assert_eq!(core::mem::size_of::<<E::Fr as PrimeField>::BigInt>(), 32);
+    let (mut xy, mut inf) = ([0u64; 12], 0u8);
+    let rc = unsafe { ffi::zl_msm(ctx()?, bases, 0, scalars.as_ptr() as *const u64, scalars.len(), xy.as_mut_ptr(), &mut inf) };
+    if rc != ffi::ZL_OK {
+        return Err(Error);
+    }
+    Ok(Groth16Mi355x::<E>::g1(&xy, inf))
+}
+
+/// Uploads `bases` (arkworks' in-memory `GroupAffine { x, y, infinity }` records, Montgomery coordinates) once; the handle names them in
+/// [`msm_g1`].  `infinity_offset` = byte offset of the `infinity: bool` field inside one record (`memoffset::offset_of!`).
+pub fn upload_g1_bases<E>(bases: &[E::G1Affine], infinity_offset: usize) -> Result<u64, Error>
+where
+    E: Mi355xEngine,
+{
+    let mut handle = 0u64;
+    let rc = unsafe {
+        ffi::zl_bases_upload(
+            ctx()?,
+            E::CURVE,
+            ffi::ZL_G1,
+            bases.as_ptr() as *const core::ffi::c_void,
+            bases.len(),
+            core::mem::size_of::<E::G1Affine>(),
+            infinity_offset as core::ffi::c_long,
+            ffi::ZL_MONT,
+            &mut handle,
+        )
+    };
+    if rc == ffi::ZL_OK { Ok(handle) } else { Err(Error) }
+}
+
+/// Drop-in for `Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place(&mut values)`: Montgomery limbs in place,
+/// `values.len()` a power of two.
+pub fn ntt_in_place<E>(values: &mut [E::Fr], inverse: bool, coset: bool) -> Result<(), Error>
+where
+    E: Mi355xEngine,
+{
+    assert!(values.len().is_power_of_two() && core::mem::size_of::<E::Fr>() == 32);
+    let flags = ffi::ZL_MONT | if inverse { ffi::ZL_INVERSE } else { 0 } | if coset { ffi::ZL_COSET } else { 0 };
+    let rc = unsafe { ffi::zl_ntt(ctx()?, E::CURVE, values.as_mut_ptr() as *mut u64, values.len().trailing_zeros(), flags) };
+    if rc == ffi::ZL_OK { Ok(()) } else { Err(Error) }
+}

@@ -88,3 +88,30 @@ def test_headers_are_plain_c99(tmp_path):
     libdir = os.path.join(ROOT, "openzl_amd")
     subprocess.check_call(["gcc", str(tmp_path / "hdr.o"), "-L", libdir, "-l:libzl_backend.so", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined",
                            "-o", str(tmp_path / "hdr")])
+
+
+def test_rust_ffi_matches_header():
+    """plugins/arkworks-mi355x/src/ffi.rs (the source-only Rust shim's extern "C" block) is generated from include/zl_backend.h by
+    tools/gen_rust_ffi.py: the committed file must be what the generator produces now, name every exported symbol exactly once and give
+    every function the arity of its C declaration.  (The Rust cannot be compiled here: no cargo / rustc; this keeps it from drifting.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "plugins", "arkworks-mi355x", "src", "ffi.rs")).read()
+    assert committed == gen.generate(), "stale ffi.rs: run python tools/gen_rust_ffi.py"
+    rust_fns = dict(re.findall(r"pub fn (zl_[a-z0-9_]+)\(([^)]*)\)", committed))
+    assert set(rust_fns) == set(ABI_SYMBOLS)
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "zl_backend.h")).read(), flags=re.S)
+    for name, args in rust_fns.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;{}]*?)\)\s*;", hdr, flags=re.S)
+        assert m, name
+        c_args = " ".join(m.group(1).split())
+        n_c = 0 if c_args in ("", "void") else c_args.count(",") + 1
+        n_rust = 0 if not args.strip() else args.count(",") + 1
+        assert n_c == n_rust, (name, c_args, args)
+    # the hand-written part of the shim only calls functions the generated block declares
+    lib = open(os.path.join(ROOT, "plugins", "arkworks-mi355x", "src", "lib.rs")).read()
+    for called in set(re.findall(r"ffi::(zl_[a-z0-9_]+)\(", lib)):
+        assert called in rust_fns, called

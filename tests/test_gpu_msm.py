@@ -397,3 +397,49 @@ def test_msm_pipelined_batch_equals_single_calls(backend, curve, table):
     got, inf = backend.partials_sum(curve.cid, batch[0:1])
     backend.bases_free(h)
     assert inf == einf and (got == exp).all()
+
+
+def test_msm_glv_edge_scalars(backend):
+    """BLS12-381 G1 plain MSMs split every scalar with the endomorphism (k = k1 + k2 lambda, both halves balanced to 127 bits; csrc/zl_msm.hip
+    k_glv_split).  Scalars that sit on the decision boundaries of the split -- multiples of lambda, lambda / 2 and its neighbours, 0, 1, r - 1 --
+    beside random ones, every sort path (LDS c <= 15, the wide sort at c = 16 and c = 18), single call and pipelined batch, against the oracle."""
+    import torch
+
+    curve = po.BLS12_381
+    r = curve.fr.p
+    z = 0xD201000000010000
+    lam = z * z - 1
+    assert lam * lam + lam + 1 == r
+    half = lam >> 1
+    edge = [0, 1, 2, lam - 1, lam, lam + 1, half, half + 1, half - 1, half * lam, (half + 1) * lam, (half + 1) * lam + half + 1, (half + 1) * lam + half,
+            half * lam + half, half * lam + half + 1, r - 1, r - 2, r - lam, r - lam - 1, (lam + 1) * lam % r, (half + 2) * lam - 1, 3 * lam, lam * lam % r]
+    n = 3000
+    S = ol.random_scalars(curve, n, 777)
+    S[: len(edge)] = ol.ints_to_limbs([e % r for e in edge], 4)
+    S[100:140] = ol.ints_to_limbs([(j * lam + (half if j & 1 else 0)) % r for j in range(40)], 4)
+    k, B = _bases(curve, n, 778)
+    h = backend.bases_upload(curve.cid, B)
+    exp, einf = ol.oracle_msm_g1(curve, B, S, algo=0, threads=4)
+    d_s = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    try:
+        for c in (0, 7, 12, 15, 16, 18):
+            backend.set_msm_window(c)
+            got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+            assert inf == einf and (got == exp).all(), c
+        backend.set_msm_window(0)
+        parts = backend.msm_batch_partial_dev(h, [d_s.data_ptr()] * 4, n)
+        for j in range(4):
+            xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1])
+            assert pinf == einf and (xy == exp).all(), j
+        # every edge scalar alone (n = 1): the split's sign / carry cases one by one (window forced: tiny inputs would otherwise pick c <= 3,
+        # where the endomorphism is not used)
+        backend.set_msm_window(8)
+        for e in edge:
+            s1 = ol.ints_to_limbs([e % r], 4)
+            got, inf = backend.msm(h, s1)
+            e1, i1 = ol.oracle_msm_g1(curve, B[:1], s1)
+            assert inf == i1 and (got == e1).all(), hex(e)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)

@@ -2,12 +2,12 @@
 """Per-launch timeline of the LAST burst of kernels in a rocprofv3 (rocpd sqlite) kernel trace: start offset, duration and the idle gap
 in front of every launch (us).  A burst = launches separated by less than `gap_us` of idle time; the last burst of the trace is usually
 the last call of the driving script.
-    python tools/timeline.py gpurun_out/prof/x_results.db [gap_us=300] [burst_index_from_end=1]"""
+    python tools/timeline.py gpurun_out/prof/x_results.db [gap_us=300] [burst_index_from_end=1] [only launches of at least min_us]"""
 import sqlite3
 import sys
 
 
-def main(path, gap_us=300.0, which=1):
+def main(path, gap_us=300.0, which=1, min_us=0.0):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.cursor().execute("pragma table_info(kernels)").fetchall()]
     q = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else "0")
@@ -33,7 +33,8 @@ def main(path, gap_us=300.0, which=1):
         nm = name.split("(")[0].replace("void ", "")
         nm = nm.replace("G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2LT<Fp28<BLS12_381_Fq28, BLS12_381_Fq>, false>, 255, 6, 2>", "BlsG2")
         gap = (s - prev_end) / 1e3
-        print(f"{nm[:52]:<52} {q:>3} {(s - t0) / 1e3:>10.1f} {(e - s) / 1e3:>9.1f} {gap:>8.1f} {grid:>9} {wg:>5}")
+        if (e - s) / 1e3 >= min_us:
+            print(f"{nm[:52]:<52} {q:>3} {(s - t0) / 1e3:>10.1f} {(e - s) / 1e3:>9.1f} {gap:>8.1f} {grid:>9} {wg:>5}")
         busy += (e - s) / 1e3
         prev_end = max(prev_end, e)
     print(f"# sum of kernel durations {busy:.1f} us")
@@ -41,4 +42,4 @@ def main(path, gap_us=300.0, which=1):
 
 if __name__ == "__main__":
     a = sys.argv
-    main(a[1], float(a[2]) if len(a) > 2 else 300.0, int(a[3]) if len(a) > 3 else 1)
+    main(a[1], float(a[2]) if len(a) > 2 else 300.0, int(a[3]) if len(a) > 3 else 1, float(a[4]) if len(a) > 4 else 0.0)
