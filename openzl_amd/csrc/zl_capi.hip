@@ -45,6 +45,7 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
         delete ctx;
         return ZL_ENODEV;
     }
+    if (e == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {

@@ -90,6 +90,7 @@ struct zl_twiddles {
     void* d_lo = nullptr;  // w^i, i < 2^lo_bits
     void* d_hi = nullptr;  // w^(i << lo_bits)
     void* d_small = nullptr;  // per-radix tables
+    void* d_last = nullptr;   // combined inter-factor twiddles of the last pass, one per element (multi-pass sizes, built on first use)
     unsigned lo_bits = 0;
 };
 struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Montgomery form)
@@ -100,6 +101,7 @@ struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Mon
 };
 struct zl_ctx {
     int device = 0;
+    int cu_count = 0;                  // compute units of the device (grid of the persistent accumulation kernel)
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // created by the ctx
     int last_hip = 0;

@@ -179,6 +179,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         zl_ctx* a = new (std::nothrow) zl_ctx();
         if (!a) return ZL_ENOMEM;
         a->device = ctx->device;
+        a->cu_count = ctx->cu_count;
         // aux (G2 MSM): default priority, like the G1 accumulation stream (the short sort / tail kernels of both run on highest-priority
         // streams, so nothing waits behind the long G2 accumulate any more; lowest priority measured 1 ms slower); aux2 (witness map):
         // highest, h gates the last MSM

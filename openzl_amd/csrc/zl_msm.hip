@@ -881,20 +881,14 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
 #ifndef ZL_ACC_BLOCK
 #define ZL_ACC_BLOCK 64
 #endif
+// one lane, one chunk: entries [t * ZL_CHUNK, (t + 1) * ZL_CHUNK) of the bucket-sorted list
 template <class G>
-__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
-                                                        const Affine<typename G::F>* __restrict__ bases_,
-                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
-                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
-                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+__device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, uint32_t E, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ bases,
+                                                    XYZZ<typename HotField<typename G::F>::type>* __restrict__ bucket_sums,
+                                                    XYZZ<typename HotField<typename G::F>::type>* __restrict__ partials, uint32_t ZL_CHUNK,
+                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ phib, uint32_t n_real) {
     using F = typename HotField<typename G::F>::type;  // same layout as G::F; Fq2 on 28-bit limbs: the inlining flavour (zl_curve.h)
-    static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
-    const Affine<F>* __restrict__ bases = reinterpret_cast<const Affine<F>*>(bases_);
-    const Affine<F>* __restrict__ phib = reinterpret_cast<const Affine<F>*>(phib_) - n_real;  // GLV: virtual point n_real + i = phi(P_i); else n_real = 2^32 - 1 (never selected)
-    XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
-    XYZZ<F>* __restrict__ partials = reinterpret_cast<XYZZ<F>*>(partials_);
-    const uint32_t E = offsets[NB];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
     if (start64 >= E) return;
     const uint32_t start = (uint32_t)start64;
@@ -924,6 +918,39 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
     const bool complete = (b_start >= start) && (b_end <= end);
     if (complete) bucket_sums[b] = acc;
     else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+    using F = typename HotField<typename G::F>::type;
+    static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
+    // GLV: virtual point n_real + i = phi(P_i); else n_real = 2^32 - 1 (never selected)
+    zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+                           reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
+                           reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+}
+// The same chunks on a grid that does NOT fill the register file (pipelined batches): k_msm_accumulate at three waves per SIMD holds 498 of
+// the 512 registers of every SIMD for as long as it runs, so the sort of the next MSM and the tail of the previous one only get onto the
+// machine when it ends (rocprofv3 of a batch, profiles/r03_glv_ab.log: 3.5 ms between consecutive accumulations in which those two run alone).
+// Here `wg_per_cu` workgroups of 256 lanes per CU (2: two waves per SIMD, 332 registers) loop over the chunks, which leaves a wave slot of
+// ~180 registers per SIMD and all of the LDS to the side streams for the whole accumulation.  Measured and NOT used by default (see
+// msm_run_jobs_t): the overlap happens, but both co-resident field-arithmetic kernels slow down far more than the gap was worth.
+#define ZL_ACC_PERSIST_BLOCK 256
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accumulate_persist(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, uint32_t nchunks) {
+    using F = typename HotField<typename G::F>::type;
+    const uint32_t E = offsets[NB];
+    // lanes of one wave take consecutive chunks (neighbouring entries), the grid strides over the list
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += gridDim.x * blockDim.x)
+        zl_accumulate_chunk<G>(t, E, entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_), reinterpret_cast<XYZZ<F>*>(bucket_sums_),
+                               reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK, reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
 }
 
 // The merge / level-0 / tree kernels of an Fq2 group can compute in the inlining flavour of the field like the accumulation kernel
@@ -1687,7 +1714,13 @@ struct MsmJob {
         ZL_HIP(ctx, hipGetLastError());
         return ZL_OK;
     }
-    int accumulate(zl_ctx* ctx, hipStream_t st) {
+    // wg_per_cu > 0: the persistent form (pipelined batches) on wg_per_cu x CUs workgroups
+    int accumulate(zl_ctx* ctx, hipStream_t st, int wg_per_cu = 0) {
+        const uint32_t lanes_persist = (uint32_t)wg_per_cu * (uint32_t)ctx->cu_count * ZL_ACC_PERSIST_BLOCK;
+        if (wg_per_cu > 0 && ctx->cu_count > 0 && nchunks >= 8 * (uint64_t)lanes_persist)  // >= 8 chunks per lane: the last, partial round costs little
+            hipLaunchKernelGGL((k_msm_accumulate_persist<G>), dim3((uint32_t)wg_per_cu * (uint32_t)ctx->cu_count), dim3(ZL_ACC_PERSIST_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases,
+                               d_buckets, d_partials, ZL_CHUNK, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, nchunks);
+        else
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                            glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         ZL_HIP(ctx, hipGetLastError());
@@ -1885,6 +1918,11 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (max_sets + 1));
     }
     hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
+    // k_msm_accumulate_persist (room for the side streams) is OFF: measured at 2^24 (profiles/r03_persist_accumulate.log) the sort and the
+    // tail do move under the accumulation and the gap between accumulations closes, but the accumulation itself goes from 33.4 to 38.9 ms
+    // beside the sort and to ~50 ms beside the level-0 / tree kernels (two instruction streams of 40-60 KB each share one 64-KB instruction
+    // cache per CU pair, and the tail kernels' own additions take 6-10 ms instead of 1.6): 49.9 ms per MSM against 37.6.  ZL_TUNE_ACC_WG_PER_CU=2 enables it.
+    const int acc_wg_per_cu = sizeof(X) > 256 ? 0 : zl_tune("ZL_TUNE_ACC_WG_PER_CU", 0);
     std::vector<hipEvent_t> ev_sorted(count), ev_acc(count), ev_tail(count), ev_acc0(ctx->timing_on ? count : 0);
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     auto cleanup = [&]() {
@@ -1923,7 +1961,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         if (he == hipSuccess) he = hipStreamWaitEvent(s_acc, ev_sorted[i], 0);
         if (he == hipSuccess && ctx->timing_on) he = hipEventRecord(ev_acc0[i], s_acc);
         if (he != hipSuccess) break;
-        if ((rc = jobs[i].accumulate(ctx, s_acc))) break;
+        if ((rc = jobs[i].accumulate(ctx, s_acc, acc_wg_per_cu))) break;
         he = hipEventRecord(ev_acc[i], s_acc);
         if (he == hipSuccess) he = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
         if (he != hipSuccess) break;

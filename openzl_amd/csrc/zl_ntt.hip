@@ -38,6 +38,7 @@ struct NttArgs {
     const void *t_lo, *t_hi;  // w^lo, w^(hi << L)
     const void* w_small;      // w_(2^s)^i, i < 2^(s-1)
     const void *g_lo, *g_hi;  // coset powers (hi table carries n^-1 for the inverse)
+    const void* last_tw;      // last pass of a multi-pass transform: the complete inter-factor twiddle of every element, in load order (or null)
     uint32_t ninv[8];
 };
 
@@ -145,6 +146,8 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_pass(const Fp<FrP>* __re
             if (a.pre_coset) x = zl::mul(x, twiddle2(reinterpret_cast<const F*>(a.g_lo), reinterpret_cast<const F*>(a.g_hi), a.L, m));
         } else if (!LAST) {
             x = zl::mul(x, sh_row[r]);
+        } else if (a.last_tw) {
+            x = zl::mul(x, reinterpret_cast<const F*>(a.last_tw)[m]);  // one multiplication: the factor was combined once per key (k_ntt_last_table)
         } else {
             x = zl::mul(x, twiddle2(t_lo, t_hi, a.L, (uint64_t)r * (K0 + col)));
         }
@@ -274,6 +277,29 @@ __global__ void __launch_bounds__(256) k_ntt_pow_table(Fp<FrP>* __restrict__ tab
         e >>= 1;
     }
     table[i] = acc;
+}
+
+// The last pass multiplies element (row r, digit-reversed column index K) by w_N^(r K): 2^n distinct factors, so any split into small
+// tables costs a second multiplication per element to combine them (15 instead of 14 multiplications per element at 2^24, and the passes
+// are bound by exactly that count: 0.68 / 0.85 / 1.00 ms for 4 / 5 / 6 multiplications per element).  HBM is the resource with slack
+// (0.43 of 8 TB/s), so the combined factors are tabulated once per (size, direction) in the order the last pass loads its input and
+// streamed beside it: +32 B of reads per element for one multiplication less.  table[m] = scale * w^(r (k1 + Krest)) with
+// m = ((k1 << rest_log) + rest) << s | r, exactly the addressing of k_ntt_pass<LAST>.
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_last_table(Fp<FrP>* __restrict__ table, NttArgs a) {
+    using F = Fp<FrP>;
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >> a.n_log) return;
+    const uint32_t s = a.s, s1 = a.sizes[0], rest_log = a.S_prev - s1;
+    const uint64_t r = m & ((1ull << s) - 1), rest = (m >> s) & ((1ull << rest_log) - 1), k1 = m >> (s + rest_log);
+    uint64_t rem = rest, Krest = 0;
+    uint32_t Sq = a.S_prev;
+    for (int q = (int)a.P - 2; q >= 1; q--) {
+        Sq -= a.sizes[q];
+        Krest += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+        rem >>= a.sizes[q];
+    }
+    table[m] = twiddle2(reinterpret_cast<const F*>(a.t_lo), reinterpret_cast<const F*>(a.t_hi), a.L, r * (k1 + Krest));
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -416,6 +442,21 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
             a.post_scale = 0;
         }
         for (int k = 0; k < 8; k++) a.ninv[k] = ninv.l[k];
+        // the combined twiddles of the last pass, tabulated once per (size, direction): forward (plain and coset share it: the coset scaling
+        // rides on pass 1) and the scaled inverse; the coset inverse (its 1/n lives in the coset table) combines on the fly
+        if (last && pl.P > 1 && !(inverse && coset) && n <= 26 && !getenv("ZL_NTT_NO_LAST_TABLE")) {
+            if (!tw->d_last) {
+                void* t = nullptr;
+                if (hipMalloc(&t, N * sizeof(F)) == hipSuccess) {
+                    a.last_tw = nullptr;
+                    hipLaunchKernelGGL((k_ntt_last_table<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
+                    tw->d_last = t;
+                } else {
+                    (void)hipGetLastError();  // no room: keep combining on the fly
+                }
+            }
+            a.last_tw = tw->d_last;
+        }
         // columns per tile
         uint32_t cols_avail_log;
         if (pl.P == 1) cols_avail_log = 0;
@@ -598,6 +639,9 @@ int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned fl
     return ZL_EINVAL;
 }
 void zl_ntt_free(zl_ctx* ctx) {
-    for (auto& kv : ctx->twiddles) if (kv.second.d_lo) (void)hipFree(kv.second.d_lo);
+    for (auto& kv : ctx->twiddles) {
+        if (kv.second.d_lo) (void)hipFree(kv.second.d_lo);
+        if (kv.second.d_last) (void)hipFree(kv.second.d_last);
+    }
     ctx->twiddles.clear();
 }
