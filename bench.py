@@ -876,13 +876,15 @@ def main():
                 raise SystemExit("full-size parity check failed: the CPU oracle's NTT differs from the GPU result")
             ntt_cpu["parity_full_size"] = True
             del X_cpu, X_gpu
-        ntt_traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_ntt.json")))
-            if ln == int(pmc["log_n"]):
-                ntt_traffic = pmc["traffic_bytes_per_transform"]
-        except Exception:
-            ntt_traffic = None
+        ntt_traffic, ntt_traffic_src = None, None
+        for cand in ("r03_pmc_traffic_ntt.json", "r02_pmc_traffic_ntt.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if ln == int(pmc["log_n"]):
+                    ntt_traffic, ntt_traffic_src = pmc["traffic_bytes_per_transform"], cand
+                    break
+            except Exception:
+                continue
         f_ms, i_ms = float(np.mean(fwd)), float(np.mean(inv))
         if world > 1:
             cpu_dev = dev if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else None
@@ -898,8 +900,9 @@ def main():
             "fwd_plus_inv_elems_per_s": tot / ((f_ms + i_ms) * 1e-3),
             "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
-                         "traffic_unit": "bytes per transform, all passes (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic_ntt.json; null for other sizes)",
-                         "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform, all butterfly passes of one transform together"},
+                         "traffic_unit": f"bytes per transform, all passes (FETCH_SIZE + WRITE_SIZE, profiles/{ntt_traffic_src or 'rNN_pmc_traffic_ntt.json'}; null for other sizes)",
+                         "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform, all butterfly passes of one transform together; "
+                                 "the last pass also streams its combined twiddles (+32 B/element read, one multiplication less)"},
             "cpu_baseline": ntt_cpu,
         }
         del dx
