@@ -643,7 +643,9 @@ def mctx_child(args, devices, timeout_s=240):
 
     env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_ENV}
     cmd = [sys.executable, os.path.abspath(__file__), "--transport", "mctx", "--gpus", str(len(devices)), "--mctx-devices", ",".join(str(d) for d in devices),
-           "--log-n", str(args.log_n), "--ntt-log-n", str(args.ntt_log_n), "--steps", str(max(2, min(args.steps, 6))), "--warmup", "1"]
+           "--log-n", str(min(args.log_n, 22)), "--ntt-log-n", str(min(args.ntt_log_n, 22)), "--steps", str(max(2, min(args.steps, 6))), "--warmup", "1"]
+    # (2^22 points / elements per device: the child generates every device's inputs itself, one after the other; the point of this leg is the
+    #  library's own RCCL exchange, whose cost does not depend on the shard size)
     if args.no_ntt:
         cmd.append("--no-ntt")
     try:

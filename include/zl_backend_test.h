@@ -37,6 +37,11 @@ int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t*
  *     5 neg_inplace(p)  6 to_affine(p) (x, y in the first two coordinates) */
 int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint32_t* in, size_t n, uint32_t* out);
 
+/* Turns `c` into a different circuit of the SAME shape (the first coefficient of row 0 of A is doubled; the assignment no longer satisfies
+ * it).  A proving context compiled for / bound to the original circuit must refuse the tweaked one (its matrices are device-resident and are
+ * not re-uploaded per proof): zl_groth16_prove_circuit returns ZL_EINVAL instead of proving against the wrong matrices. */
+int zl_test_circuit_tweak(zl_circuit* c);
+
 #ifdef __cplusplus
 }
 #endif

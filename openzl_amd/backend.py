@@ -146,6 +146,7 @@ def load_library(path: Optional[str] = None):
     L.zl_test_poseidon_permute_dev.argtypes = [vp, C.c_int, u64p]
     L.zl_test_fp28_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_circuit_tweak.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -395,7 +396,7 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak"]
 
 
 def _p32(a: np.ndarray):

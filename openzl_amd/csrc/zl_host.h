@@ -199,6 +199,11 @@ public:
         digest_rows_ = A_.size(); digest_inst_ = instance_.size(); digest_wit_ = witness_.size();
         return h;
     }
+    // TEST ONLY (zl_test_circuit_tweak): doubles the first coefficient of row 0 of A -- a different circuit of the same shape
+    void tweak_for_tests() {
+        if (!A_.empty() && !A_[0].terms.empty()) A_[0].terms[0].second = zl::add(A_[0].terms[0].second, A_[0].terms[0].second);
+        digest_rows_ = (size_t)-1;
+    }
     const std::vector<F>& instance_assignment() const { return instance_; }
     const std::vector<F>& witness_assignment() const { return witness_; }
 

@@ -653,6 +653,14 @@ struct zl_circuit {
     R1csExport<BLS12_381_Fr> ex_bls;
     R1csExport<BN254_Fr> ex_bn;
 };
+// include/zl_backend_test.h: turn the circuit into a DIFFERENT circuit of the same shape (first coefficient of A's row 0 doubled); its
+// cached CSR export is dropped.  A proving context bound to the original circuit must refuse it (R1CS::structure_digest).
+extern "C" int zl_test_circuit_tweak(zl_circuit* c) {
+    if (!c) return ZL_EINVAL;
+    if (c->bls) { c->bls->tweak_for_tests(); c->ex_bls = R1csExport<BLS12_381_Fr>(); c->ex_bls.build(*c->bls); }
+    if (c->bn) { c->bn->tweak_for_tests(); c->ex_bn = R1csExport<BN254_Fr>(); c->ex_bn.build(*c->bn); }
+    return ZL_OK;
+}
 struct zl_g16_keys {
     zl_curve_t curve;
     Groth16<Bls12_381>::ProvingContext pc_bls;

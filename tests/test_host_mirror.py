@@ -73,3 +73,44 @@ def test_groth16_compile_and_prove_end_to_end(backend, curve, k):
     finally:
         keys.close()
         circ.close()
+
+
+@pytest.mark.gpu
+def test_proving_context_refuses_a_different_circuit_of_the_same_shape(backend):
+    """The constraint matrices are device-resident per proving context and only the assignment travels per proof, so the context is bound to
+    its circuit by a fingerprint of the matrices (R1CS::structure_digest): the same circuit with another witness proves, a circuit of the same
+    shape with one coefficient changed (test hook zl_test_circuit_tweak) is refused -- for compiled keys and for keys decoded from bytes, which
+    bind at their first proof (a decoded key silently kept the first circuit's matrices)."""
+    from openzl_amd import BackendError, Circuit, Groth16Keys
+
+    curve = po.BLS12_381
+    c1 = Circuit(curve.cid, 2)
+    keys = Groth16Keys(backend, c1, seed=11)
+    c2 = Circuit(curve.cid, 2, x0=5, x1=9)      # same circuit, other witness
+    c3 = Circuit(curve.cid, 2)
+    assert c3.L.zl_test_circuit_tweak(c3._c) == 0  # same shape, different matrices
+    try:
+        p1, _, _ = keys.prove(seed=3)
+        assert keys.verify(p1, c1.arrays()["assignment"][1:2])
+        old = keys.circuit
+        keys.circuit = c2
+        p2, _, _ = keys.prove(seed=3)
+        assert keys.verify(p2, c2.arrays()["assignment"][1:2])
+        keys.circuit = c3
+        with pytest.raises(BackendError) as e:
+            keys.prove(seed=3)
+        assert e.value.code == -1
+        keys.circuit = old
+        # a decoded key binds to the first circuit it proves
+        dec = Groth16Keys.from_bytes(backend, c1, keys.to_bytes())
+        try:
+            dec.prove(seed=4)
+            dec.circuit = c3
+            with pytest.raises(BackendError):
+                dec.prove(seed=4)
+        finally:
+            dec.close()
+    finally:
+        keys.close()
+        for c in (c1, c2, c3):
+            c.close()
