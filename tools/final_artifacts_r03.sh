@@ -35,6 +35,7 @@ rocprofv3 --kernel-trace --stats -d $O/p4 -o t -- python tools/ntt_one.py 24 5 >
 python tools/prof_summary.py $(dbof $O/p4) k_ntt_pass > $O/r03_kernel_stats_ntt_2_24.txt
 rocprofv3 --kernel-trace --stats -d $O/p5 -o t -- python tools/g16_one.py > $O/g16_one.log 2>&1
 python tools/prof_summary.py $(dbof $O/p5) > $O/r03_kernel_stats_groth16.txt
+python tools/timeline.py $(dbof $O/p5) 1500 1 200 > $O/r03_g16_timeline.txt 2>&1   # last proof: launches >= 200 us with their queues
 rocprofv3 --kernel-trace --stats -d $O/p6 -o t -- python tools/msm_sweep.py --g2 20 > $O/g2_sweep.log 2>&1
 python tools/prof_summary.py $(dbof $O/p6) > $O/r03_kernel_stats_g2_2_20.txt
 # ---- bench lines and sweeps --------------------------------------------------------------------------------------------------------
