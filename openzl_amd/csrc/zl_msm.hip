@@ -1590,7 +1590,9 @@ struct MsmJob {
     int sort(zl_ctx* ctx, hipStream_t st) {
         const zl_bases& bs = *bsp;
         int rc;
-        ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
+        // the bucket counters are written in full by the LDS path (k_msm_slice_prefix) and by the wide path (k_msm_fine_hist); only the
+        // global-atomics sort counts into them
+        if (!wide && c > 16) ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
         ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 32, st));  // big, ones, giant counts; [4..5]: oversized sub-group queue head (u64)
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
         // GLV front end: half-scalars behind the slot-5 temporaries, phi image of the bases (once per call for a batch over one key)
@@ -1804,6 +1806,19 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
         int rc;
         if ((rc = job.plan(ctx, bs, first, d_scalars, n, 18))) return rc;
         if ((rc = job.alloc(ctx, 0))) return rc;
+        {   // results land in pinned host memory: the two D2H copies are then plain queue entries behind the last kernel (from pageable
+            // memory each cost a staging round trip: ~25 us of idle device in front of either copy)
+            const size_t need = sizeof(X) * ((size_t)job.SETS * job.roots_per_set + 1) + 16;
+            if (ctx->pinned_cap < need) {
+                if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+                ctx->pinned = nullptr;
+                ctx->pinned_cap = 0;
+                ZL_HIP(ctx, hipHostMalloc(&ctx->pinned, need + 4096, hipHostMallocDefault));
+                ctx->pinned_cap = need + 4096;
+            }
+            job.hw = reinterpret_cast<X*>(ctx->pinned);
+            job.hE = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(ctx->pinned) + sizeof(X) * ((size_t)job.SETS * job.roots_per_set + 1));
+        }
         const auto tp1 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
         if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
