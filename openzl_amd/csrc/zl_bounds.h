@@ -121,6 +121,14 @@ constexpr bool formulas_hold() {
         jac_dbl_inplace(j);
         ok = ok && hi(j.x) <= COORD_MAX && hi(j.y) <= COORD_MAX && hi(j.z) <= COORD_MAX;
     }
+    {   // runs of doublings through Jacobian coordinates (host Horner over the windows): both the short XYZZ form and the round trip
+        XYZZ<F> s3 = worst<F>();
+        dbl_n(s3, 3);
+        ok = ok && closed(s3);
+        XYZZ<F> s5 = worst<F>();
+        dbl_n(s5, 5);
+        ok = ok && closed(s5);
+    }
     {   // negation, normalisation
         XYZZ<F> p = worst<F>();
         neg_inplace(p);

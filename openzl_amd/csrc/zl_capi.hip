@@ -72,7 +72,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
     for (auto& t : ctx->fb_table) if (t) (void)hipFree(t);
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
-    if (ctx->stream_tail) (void)hipStreamDestroy(ctx->stream_tail);
+    for (auto& t : ctx->stream_tail) if (t) (void)hipStreamDestroy(t);
     if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
@@ -82,7 +82,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
         (void)hipStreamSynchronize(a->stream);
         for (auto& sc : a->scratch) if (sc.p) (void)hipFree(sc.p);
         if (a->stream_sort) (void)hipStreamDestroy(a->stream_sort);
-        if (a->stream_tail) (void)hipStreamDestroy(a->stream_tail);
+        for (auto& t : a->stream_tail) if (t) (void)hipStreamDestroy(t);
         if (a->pinned) (void)hipHostFree(a->pinned);
         zl_ntt_free(a);
         for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);
@@ -257,7 +257,7 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
     std::vector<const void*> js(K);
     for (size_t j = 0; j < K; j++) { jf[j] = first + off[j]; jn[j] = len[j]; js[j] = reinterpret_cast<unsigned char*>(d_sc) + off[j] * 32; }
     std::vector<uint64_t> parts(K * ZL_PARTIAL_WORDS);
-    int rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_jobs, ctx, jb.data(), jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded);
+    int rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_jobs, ctx, jb.data(), jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded, (const std::function<void(size_t)>*)nullptr);
     copier.join();
     (void)hipStreamSynchronize(sc);
     for (auto x : ev) (void)hipEventDestroy(x);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <vector>
 #include "../../include/zl_backend.h"
@@ -112,9 +113,10 @@ struct zl_ctx {
     std::map<uint64_t, zl_bases> bases;
     std::map<uint64_t, zl_r1cs_dev> r1cs;
     uint64_t next_handle = 1;
-    zl_scratch scratch[24];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV)
+    zl_scratch scratch[26];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV); 4, 19, 23: tail buffers of the three sets
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
-    hipStream_t stream_sort = nullptr, stream_tail = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
+    hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
+    hipStream_t stream_tail[3] = {nullptr, nullptr, nullptr};  // one tail stream per buffer set: the tails of consecutive small jobs run side by side
     hipStream_t stream_copy = nullptr;  // zl_msm with host scalars: chunked H2D copies that run under the MSMs of the earlier chunks
     void* pinned = nullptr;  // pinned host staging for pipelined results
     size_t pinned_cap = 0;
@@ -149,7 +151,7 @@ inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
 #define ZL_DECL_GROUP(G)                                                                                                   \
     int zl_msm_run_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial); \
     int zl_msm_run_batch_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials); \
-    int zl_msm_run_jobs_##G(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded); \
+    int zl_msm_run_jobs_##G(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded, const std::function<void(size_t)>* on_done); \
     int zl_partial_to_affine_##G(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf);                              \
     int zl_partials_fold_##G(const uint64_t* partials, size_t count, uint64_t* out_partial);                                \
     int zl_partial_from_affine_##G(const uint64_t* xy, uint64_t* out_partial);                                \

@@ -269,6 +269,22 @@ ZL_HD constexpr void jac_dbl_inplace(Jac<F>& p) {
     p.x = x3;
     p.z = z3;
 }
+// p = 2^n p.  A run of doublings is cheaper in Jacobian coordinates (dbl-2009-l: 2M + 5S against 6M + 3S + a dual scan for the XYZZ doubling);
+// XYZZ -> Jacobian with Z = zzz is (X zz^2, Y zzz^2, zzz) (x = X / zz, zz^3 = zzz^2), back is (X, Y, Z^2, Z^3): six multiplications for the
+// round trip, so runs of at least four doublings take it.  Used by the host Horner over the windows of an MSM (c doublings per window).
+// Bounds: XYZZ coordinates <= 8q in -> products of (8, 2) -> Jacobian coordinates < 2q; jac_dbl_inplace keeps them < 8q; out x < 4q, y, zz, zzz < 2q.
+template <class F>
+ZL_HD constexpr void dbl_n(XYZZ<F>& p, int n) {
+    if (p.is_inf() || n <= 0) return;
+    if (n < 4) {
+        for (int k = 0; k < n; k++) dbl_inplace(p);
+        return;
+    }
+    Jac<F> j{mul(p.x, sqr(p.zz)), mul(p.y, sqr(p.zzz)), p.zzz};
+    for (int k = 0; k < n; k++) jac_dbl_inplace(j);
+    const F zz = sqr(j.z);
+    p = XYZZ<F>{j.x, j.y, zz, mul(zz, j.z)};
+}
 // p = -p
 template <class F>
 ZL_HD constexpr void neg_inplace(XYZZ<F>& p) {

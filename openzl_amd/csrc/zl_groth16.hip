@@ -13,6 +13,9 @@
 #include <string.h>
 #include <thread>
 #include <vector>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include "zl_ctx.h"
 
 template <class FrP>
@@ -143,6 +146,12 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     if (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw) return ZL_EINVAL;
 
     hipStream_t st = ctx->stream;
+    static const bool trace = getenv("ZL_HOST_TRACE") != nullptr;  // developer aid: host-side phase times on stderr
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto lap_us = [&](const char* what) {
+        if (trace) fprintf(stderr, "[zl_groth16 nc=%u] %-28s at %8.1f us\n", (unsigned)nc, what,
+                           (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tp0).count() / 1e3);
+    };
     ctx->g16_h = nullptr;  // the quotient of an earlier proof may live in a scratch block this call re-allocates
     ctx->g16_h_n = 0;
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
@@ -226,6 +235,22 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         const hipError_t e_z = hipStreamSynchronize(st);  // z is complete before the other streams / threads read it
         if (e_z != hipSuccess) { ctx->last_hip = (int)e_z; return wm_fail(ZL_EHIP); }
     }
+    // first points of the a / b queries (index 0 pairs with z[0] = 1); fetched here, before the MSM streams are busy (the download uses the
+    // ctx's own stream and sort scratch)
+    uint64_t a0_xy[12], b0_xy[12], b20_xy[24];
+    {
+        // static per key: fetched from the device on the first proof only
+        const struct { const zl_bases* b; int group; uint64_t* out; size_t words; } firsts[3] = {
+            {bs[0], ZL_G1, a0_xy, 12}, {bs[1], ZL_G1, b0_xy, 12}, {bs[4], ZL_G2, b20_xy, 24}};
+        for (const auto& f : firsts) {
+            if (f.b->first_xy.empty()) {
+                uint64_t tmp[24] = {0};
+                if ((rc = ZL_DISPATCH(pk->curve, f.group, zl_bases_download, ctx, *f.b, 0, 1, tmp))) return wm_fail(rc);
+                f.b->first_xy.assign(tmp, tmp + f.words);
+            }
+            memcpy(f.out, f.b->first_xy.data(), f.words * 8);
+        }
+    }
     // host work that does not depend on the MSMs (r*delta1, s*delta1, r*s*delta1, s*delta2: ~1300 group operations) runs on a third
     // thread while the device is busy
     uint32_t rw[8], sw[8];
@@ -242,7 +267,10 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         zl::neg_inplace(rs_delta);
         s_delta2 = zl::mul_scalar(delta2, sw);
     });
+    lap_us("z on device, host pre started");
     int rc_g2 = ZL_OK;
+    XYZZ<F1> g_a = XYZZ<F1>::inf(), g1_b = XYZZ<F1>::inf(), g_c = XYZZ<F1>::inf();
+    bool have_c = false;
     {
         zl_ctx* aux = ctx->aux;
         const zl_bases* b2 = bs[4];
@@ -261,34 +289,41 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             const size_t jn[4] = {(size_t)nw, (size_t)nv - 1, (size_t)nv - 1, (size_t)N - 1};
             const hipEvent_t jw[4] = {nullptr, nullptr, nullptr, ev_h};
             uint64_t jp[4][ZL_PARTIAL_WORDS];
-            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)nullptr);
+            // A and B1 are complete once the a and b1 MSMs (jobs 1, 2) are: their double-scalar product s A + r B1 (255 doublings + ~190
+            // additions on the host, ~0.4 ms) runs on the pipeline's completion thread while the h MSM and the G2 MSM are still on the device
+            const std::function<void(size_t)> on_done = [&](size_t i) {
+                if (i != 2) return;
+                pre.join();
+                g_a = r_delta1;
+                zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
+                zl::add_full(g_a, from_partial<F1>(jp[1]));
+                zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
+                g1_b = s_delta1;
+                zl::add_full(g1_b, affine_from_canon<G1>(b0_xy));
+                zl::add_full(g1_b, from_partial<F1>(jp[2]));
+                zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
+                lap_us("a, b1 in: s A + r B1 starts");
+                g_c = zl::mul_scalar2(g_a, sw, g1_b, rw);
+                zl::add_full(g_c, rs_delta);
+                have_c = true;
+                lap_us("s A + r B1 done");
+            };
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)nullptr, &on_done);
             memcpy(part[3], jp[0], sizeof jp[0]);
             memcpy(part[0], jp[1], sizeof jp[1]);
             memcpy(part[1], jp[2], sizeof jp[2]);
             memcpy(part[2], jp[3], sizeof jp[3]);
         }
+        lap_us("G1 pipeline returned");
         (void)hipStreamSynchronize(s_wm);  // also on the error path: nothing of this proof may still be running
         g2.join();
+        lap_us("G2 joined");
     }
-    pre.join();
+    if (pre.joinable()) pre.join();
     if (!rc) rc = rc_g2;
+    if (!rc && !have_c) rc = ZL_EHIP;  // (the completion callback did not run: cannot happen after a successful pipeline)
     ctx->timing_on = timing_saved;
     if (rc) return rc;
-    // first points of the a / b queries (index 0 pairs with z[0] = 1)
-    uint64_t a0_xy[12], b0_xy[12], b20_xy[24];
-    {
-        // static per key: fetched from the device on the first proof only
-        const struct { const zl_bases* b; int group; uint64_t* out; size_t words; } firsts[3] = {
-            {bs[0], ZL_G1, a0_xy, 12}, {bs[1], ZL_G1, b0_xy, 12}, {bs[4], ZL_G2, b20_xy, 24}};
-        for (const auto& f : firsts) {
-            if (f.b->first_xy.empty()) {
-                uint64_t tmp[24] = {0};
-                if ((rc = ZL_DISPATCH(pk->curve, f.group, zl_bases_download, ctx, *f.b, 0, 1, tmp))) return rc;
-                f.b->first_xy.assign(tmp, tmp + f.words);
-            }
-            memcpy(f.out, f.b->first_xy.data(), f.words * 8);
-        }
-    }
     if (ctx->timing_on) {
         ZL_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         ZL_HIP(ctx, hipStreamSynchronize(st));
@@ -298,27 +333,19 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     }
     ctx->g16_h = d_h;
     ctx->g16_h_n = N;
-    // ---- host assembly: four additions per element + one double-scalar multiplication s*A + r*B1 (Shamir) -----------------------
-    XYZZ<F1> g_a = r_delta1;
-    zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
-    zl::add_full(g_a, from_partial<F1>(part[0]));
-    zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
-    XYZZ<F1> g1_b = s_delta1;
-    zl::add_full(g1_b, affine_from_canon<G1>(b0_xy));
-    zl::add_full(g1_b, from_partial<F1>(part[1]));
-    zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
+    // ---- host assembly: A, B1 and s A + r B1 - r s delta1 were formed by the completion callback above; what is left needs the last MSMs
     XYZZ<F2> g2_b = s_delta2;
     zl::add_full(g2_b, affine_from_canon<G2>(b20_xy));
     zl::add_full(g2_b, from_partial<F2>(part[4]));
     zl::add_full(g2_b, affine_from_canon<G2>(pk->beta_g2));
-    XYZZ<F1> g_c = zl::mul_scalar2(g_a, sw, g1_b, rw);
-    zl::add_full(g_c, rs_delta);
     zl::add_full(g_c, from_partial<F1>(part[3]));
     zl::add_full(g_c, from_partial<F1>(part[2]));
+    lap_us("assembly");
     memset(out, 0, sizeof *out);
     store_canon<G1>(out->a, &out->a_inf, g_a);
     store_canon<G2>(out->b, &out->b_inf, g2_b);
     store_canon<G1>(out->c, &out->c_inf, g_c);
+    lap_us("proof normalised");
     return ZL_OK;
 }
 

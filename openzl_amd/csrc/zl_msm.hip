@@ -1511,8 +1511,8 @@ struct MsmJob {
         hE = hE_own;
         return ZL_OK;
     }
-    // buffer set 0, 1 or 2 (slots 0..3 / 10..13 / 14..17); the tail buffers (slot 4) and the sort temporaries (slots 5, 6) are shared: tails and sorts
-    // of consecutive jobs run in order on their own streams
+    // buffer set 0, 1 or 2 (slots 0..3 + 4 / 10..13 + 19 / 14..17 + 23); the sort temporaries (slots 5, 6) are shared: the sorts of consecutive
+    // jobs run in order on the sort stream
     int alloc(zl_ctx* ctx, int set) {
         void* p;
         int rc;
@@ -1543,7 +1543,8 @@ struct MsmJob {
         // ping-pong node buffers of the reduction tree: leaves = 2 channels x blocks, level 1 = 3 channels x blocks / 2 (the largest)
         const size_t leaf_elems = (size_t)2 * SETS * red_blocks, lvl1_elems = (size_t)3 * SETS * (red_blocks / 2 + 1);
         const size_t root_elems = (size_t)SETS * roots_per_set;
-        if ((rc = zl_scratch_get(ctx, 4, (leaf_elems + lvl1_elems + root_elems + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
+        const int tail_slot = set == 0 ? 4 : (set == 1 ? 19 : 23);  // per set: the tails of consecutive jobs may overlap (small jobs)
+        if ((rc = zl_scratch_get(ctx, tail_slot, (leaf_elems + lvl1_elems + root_elems + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
         d_segs = (X*)p;                    // tree nodes, even levels (level 0 = leaves)
         d_stage1 = d_segs + leaf_elems;    // tree nodes, odd levels
         d_sets = d_stage1 + lvl1_elems;    // the root channels of every set, then the sum of the scalar-1 bases
@@ -1786,7 +1787,7 @@ struct MsmJob {
         else for (uint32_t w = 0; w < SETS; w++) V[w] = window_value((int)w);
         X total = V[SETS - 1];
         for (int w = (int)SETS - 2; w >= 0; w--) {
-            for (int k = 0; k < c; k++) zl::dbl_inplace(total);
+            zl::dbl_n(total, c);  // c doublings in Jacobian coordinates
             zl::add_full(total, V[w]);
         }
         zl::add_full(total, hw[(size_t)SETS * roots_per_set]);
@@ -1867,7 +1868,10 @@ struct MsmSpec {
 // `recorded` (optional): the wait events are recorded by ANOTHER host thread (zl_msm's copy thread); job i may only be issued once
 // *recorded > i, because hipStreamWaitEvent on a not-yet-recorded event does not wait.  Negative = that thread failed.
 template <class G>
-static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded = nullptr) {
+// `on_done` (optional): called with i from a helper thread as soon as job i's result is in out_partials (jobs complete in order), while the
+// later jobs are still running on the device: a caller with host work that depends on the first results starts it early (Groth16: s A + r B1).
+static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded = nullptr,
+                          const std::function<void(size_t)>* on_done = nullptr) {
     using X = XYZZ<typename G::F>;
     ctx->timing = zl_timing{};
     if (count == 0) return ZL_OK;
@@ -1879,6 +1883,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
             if (specs[i].wait) ZL_HIP(ctx, hipEventSynchronize(specs[i].wait));
             int rc = msm_run_t<G>(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, out_partials + i * ZL_PARTIAL_WORDS);
             if (rc) return rc;
+            if (on_done) (*on_done)(i);
         }
         return ZL_OK;
     }
@@ -1888,7 +1893,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, prio_hi));
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_tail, hipStreamNonBlocking, prio_hi));
+        for (auto& t : ctx->stream_tail) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prio_hi));
     }
     std::vector<MsmJob<G>> jobs(count);
     size_t t5 = 0, t6 = 0;
@@ -1932,7 +1937,11 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         jobs[i].hw = reinterpret_cast<X*>(base);
         jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (max_sets + 1));
     }
-    hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream, s_tail = ctx->stream_tail;
+    hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream;
+    // The tail of job i runs on the tail stream of its buffer set: consecutive tails are independent (own buckets, partials, tree nodes), and
+    // for small jobs -- a chain of ~25 dependent group operations at a few lanes each -- they are what the pipeline's latency consists of:
+    // four 237-point MSMs of a small proof finished their tails one after the other in 2.1 ms, now side by side.
+    hipStream_t s_tails[3] = {ctx->stream_tail[0], ctx->stream_tail[1], ctx->stream_tail[2]};
     // k_msm_accumulate_persist (room for the side streams) is OFF: measured at 2^24 (profiles/r03_persist_accumulate.log) the sort and the
     // tail do move under the accumulation and the gap between accumulations closes, but the accumulation itself goes from 33.4 to 38.9 ms
     // beside the sort and to ~50 ms beside the level-0 / tree kernels (two instruction streams of 40-60 KB each share one 64-KB instruction
@@ -1978,17 +1987,46 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         if (he != hipSuccess) break;
         if ((rc = jobs[i].accumulate(ctx, s_acc, acc_wg_per_cu))) break;
         he = hipEventRecord(ev_acc[i], s_acc);
+        hipStream_t s_tail = s_tails[i % 3];
         if (he == hipSuccess) he = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
         if (he != hipSuccess) break;
         if ((rc = jobs[i].tail(ctx, s_tail))) break;
         he = hipEventRecord(ev_tail[i], s_tail);
     }
-    if (he == hipSuccess) he = hipEventRecord(ev_end, s_tail);
+    // ev_end: after the last tail of every tail stream
+    for (size_t back = 1; back <= 2 && back < count && he == hipSuccess && rc == ZL_OK; back++) he = hipStreamWaitEvent(s_tails[(count - 1) % 3], ev_tail[count - 1 - back], 0);
+    if (he == hipSuccess && rc == ZL_OK) he = hipEventRecord(ev_end, s_tails[(count - 1) % 3]);
+    // Host tails: this thread waits for the jobs' tail events in order (a job's root channels are then in pinned memory) and hands every
+    // finished job to a helper thread that runs its window Horner and delivers the result -- while the device works on the later jobs.  Small
+    // jobs, which the device finishes faster than the host, get their Horners side by side; `on_done` is delivered in job order.  (The helpers
+    // make no HIP calls: a fresh thread's first HIP call costs ~0.1 ms of per-thread runtime setup, per proof.)
+    std::atomic<int> frc{ZL_OK};
+    std::atomic<size_t> delivered{0};
+    std::vector<std::thread> finishers;
+    if (he == hipSuccess && rc == ZL_OK) {
+        for (size_t i = 0; i < count; i++) {
+            bool ok = frc.load() == ZL_OK;
+            if (ok && hipEventSynchronize(ev_tail[i]) != hipSuccess) { frc.store(ZL_EHIP); ok = false; }
+            if (ok && jobs[i].hE[1]) { frc.store(ZL_EINVAL); ok = false; }  // non-canonical scalar (see msm_run_t)
+            finishers.emplace_back([&, i, ok]() {
+                if (ok) {
+                    const X total = jobs[i].finish(count <= 2);  // several jobs: they already run side by side
+                    memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
+                    memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
+                }
+                while (delivered.load(std::memory_order_acquire) != i) std::this_thread::yield();
+                if (ok && on_done && frc.load() == ZL_OK) (*on_done)(i);
+                delivered.store(i + 1, std::memory_order_release);
+            });
+        }
+    }
     // drain all three streams whatever happened, then report
     (void)hipStreamSynchronize(s_sort);
     (void)hipStreamSynchronize(s_acc);
-    const hipError_t hs = hipStreamSynchronize(s_tail);
-    if (he == hipSuccess) he = hs;
+    for (hipStream_t t : s_tails) {
+        const hipError_t hs = hipStreamSynchronize(t);
+        if (he == hipSuccess) he = hs;
+    }
     if (he == hipSuccess && rc == ZL_OK && ctx->timing_on) {
         float tot = 0.f, acc_sum = 0.f, t = 0.f;
         he = hipEventElapsedTime(&tot, ev_begin, ev_end);
@@ -1999,28 +2037,14 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         ctx->timing.total_ms = tot / (float)count;          // per MSM, pipelined
         ctx->timing.dominant_ms = acc_sum / (float)count;   // mean accumulation kernel
     }
+    for (auto& t : finishers) t.join();  // (their events fired before the streams drained)
     cleanup();
     if (he != hipSuccess) { ctx->last_hip = (int)he; return ZL_EHIP; }
     if (rc) return rc;
+    if (frc.load()) return frc.load();
     ctx->timing.launches = (uint32_t)count;
     ctx->timing.window_bits = (uint32_t)jobs[0].c;
     ctx->timing.entries = *jobs[count - 1].hE;
-    for (size_t i = 0; i < count; i++)
-        if (jobs[i].hE[1]) return ZL_EINVAL;  // non-canonical scalar (see msm_run_t)
-    // host Horners (256 doublings + one addition per bit position each, ~0.5 ms): all jobs side by side
-    {
-        const size_t nt = std::min<size_t>(count, 16);
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
-                for (size_t i = t; i < count; i += nt) {
-                    const X total = jobs[i].finish(false);  // the jobs already run side by side
-                    memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
-                    memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
-                }
-            });
-        for (auto& x : th) x.join();
-    }
     return ZL_OK;
 }
 
@@ -2134,10 +2158,11 @@ int ZL_GNAME(zl_msm_run_batch)(zl_ctx* ctx, const zl_bases& b, size_t first, con
 }
 // heterogeneous pipeline: job i = (bases[i], first[i], d_scalars[i], n[i]) (Groth16: the four G1 MSMs of one proof)
 int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n,
-                              const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded) {
+                              const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded,
+                              const std::function<void(size_t)>* on_done) {
     std::vector<MsmSpec> specs(count);
     for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{bases[i], first[i], d_scalars[i], n[i], wait ? wait[i] : nullptr};
-    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials, recorded);
+    return msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, out_partials, recorded, on_done);
 }
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);
