@@ -113,9 +113,10 @@ struct zl_ctx {
     std::map<uint64_t, zl_bases> bases;
     std::map<uint64_t, zl_r1cs_dev> r1cs;
     uint64_t next_handle = 1;
-    zl_scratch scratch[26];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV); 4, 19, 23: tail buffers of the three sets
+    zl_scratch scratch[40];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV); 4, 19, 23: tail buffers of the three sets
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
+    hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
     hipStream_t stream_tail[3] = {nullptr, nullptr, nullptr};  // one tail stream per buffer set: the tails of consecutive small jobs run side by side
     hipStream_t stream_copy = nullptr;  // zl_msm with host scalars: chunked H2D copies that run under the MSMs of the earlier chunks
     void* pinned = nullptr;  // pinned host staging for pipelined results

@@ -1402,6 +1402,7 @@ struct MsmJob {
     bool glv = false;   // the job runs on 2 n_real half-scalars of 127 bits over the points P_i and phi(P_i) (k_glv_split / k_glv_phi)
     bool phi_owner = false;  // this job computes the phi image of its bases in its sort phase (else it borrows d_phi from an earlier job of the call)
     int sc_bits = 0, phi_slot = -1;
+    int slotA = 5, slotB = 6;  // scratch slots of the sort temporaries (shared by the jobs of a pipelined batch; per buffer set when small jobs run side by side)
     size_t n_real = 0;
     uint32_t* d_vs = nullptr;            // the half-scalars (inside the sort temporaries)
     const Affine<F>* d_phi = nullptr;    // phi(P_i), i < n_real
@@ -1513,10 +1514,20 @@ struct MsmJob {
     }
     // buffer set 0, 1 or 2 (slots 0..3 + 4 / 10..13 + 19 / 14..17 + 23); the sort temporaries (slots 5, 6) are shared: the sorts of consecutive
     // jobs run in order on the sort stream
-    int alloc(zl_ctx* ctx, int set) {
+    static int phi_slot_of(int set) { return set == 3 ? 35 : 20 + set; }
+    int alloc(zl_ctx* ctx, int set, bool own_sort = false) {
         void* p;
         int rc;
-        const int o = set == 0 ? 0 : (set == 1 ? 10 : 14);
+        const int o = set == 0 ? 0 : (set == 1 ? 10 : (set == 2 ? 14 : 28));
+        if (own_sort) {  // the job's sort runs beside the other sets' sorts: its temporaries are its own, sized here (nothing is in flight yet)
+            static const int A[4] = {5, 24, 26, 33}, B[4] = {6, 25, 27, 34};
+            slotA = A[set];
+            slotB = B[set];
+            size_t a5, a6;
+            sort_tmp_sizes(a5, a6);
+            if (a5 && (rc = zl_scratch_get(ctx, slotA, a5, &p))) return rc;
+            if (a6 && (rc = zl_scratch_get(ctx, slotB, a6, &p))) return rc;
+        }
         // counters (NB+1) | offsets (NB+2: [NB] = total entries, [NB+1] = non-canonical-scalar flag) | cursor (NB+1) | block sums | big list | counts | giant list | scalar-1 list
         const size_t max_bigsg = (size_t)(maxE / 1024) + 2;  // oversized sub-groups hold > cap >= 1024 entries each
         size_t small_words = (size_t)3 * (NB + 1) + 1 + scan_blocks + 1 + max_big + max_giant + 16 + n + 2 * max_bigsg;
@@ -1543,7 +1554,7 @@ struct MsmJob {
         // ping-pong node buffers of the reduction tree: leaves = 2 channels x blocks, level 1 = 3 channels x blocks / 2 (the largest)
         const size_t leaf_elems = (size_t)2 * SETS * red_blocks, lvl1_elems = (size_t)3 * SETS * (red_blocks / 2 + 1);
         const size_t root_elems = (size_t)SETS * roots_per_set;
-        const int tail_slot = set == 0 ? 4 : (set == 1 ? 19 : 23);  // per set: the tails of consecutive jobs may overlap (small jobs)
+        const int tail_slot = set == 0 ? 4 : (set == 1 ? 19 : (set == 2 ? 23 : 32));  // per set: the tails of consecutive jobs may overlap (small jobs)
         if ((rc = zl_scratch_get(ctx, tail_slot, (leaf_elems + lvl1_elems + root_elems + 2 + ZL_ONES_BLOCKS + (size_t)max_giant * ZL_GIANT_PARTS) * sizeof(X), &p))) return rc;
         d_segs = (X*)p;                    // tree nodes, even levels (level 0 = leaves)
         d_stage1 = d_segs + leaf_elems;    // tree nodes, odd levels
@@ -1604,7 +1615,7 @@ struct MsmJob {
             size_t s5tot, s6tot;
             sort_tmp_sizes(s5tot, s6tot);
             void* p5;
-            if ((rc = zl_scratch_get(ctx, 5, s5tot, &p5))) return rc;
+            if ((rc = zl_scratch_get(ctx, slotA, s5tot, &p5))) return rc;
             d_vs = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p5) + (s5tot - vs_bytes()));
             if constexpr (G::GLV) {
                 hipLaunchKernelGGL((k_glv_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
@@ -1631,7 +1642,7 @@ struct MsmJob {
             const size_t b_plo = b_lo, b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
             const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256;
             void* pd;
-            if ((rc = zl_scratch_get(ctx, 5, b_lo + b_hi + b_plo + b_pidx + b_pc + 256, &pd))) return rc;
+            if ((rc = zl_scratch_get(ctx, slotA, b_lo + b_hi + b_plo + b_pidx + b_pc + 256, &pd))) return rc;
             unsigned char* q = (unsigned char*)pd;
             uint16_t* d_lo16 = (uint16_t*)q; q += b_lo;
             uint8_t* d_hi8 = (uint8_t*)q; q += b_hi;
@@ -1656,7 +1667,7 @@ struct MsmJob {
             const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
             void* pd2;
             const size_t b2_lo = b_plo, b2_idx = b_pidx, b2_c = (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256;
-            if ((rc = zl_scratch_get(ctx, 6, b2_lo + b2_idx + b2_c + 256, &pd2))) return rc;  // slot 6 is otherwise the NTT's scratch vector
+            if ((rc = zl_scratch_get(ctx, slotB, b2_lo + b2_idx + b2_c + 256, &pd2))) return rc;  // slot 6 is otherwise the NTT's scratch vector
             unsigned char* q2 = (unsigned char*)pd2;
             uint16_t* d_lo2 = (uint16_t*)q2; q2 += b2_lo;
             uint32_t* d_idx2 = (uint32_t*)q2; q2 += b2_idx;
@@ -1691,7 +1702,7 @@ struct MsmJob {
             if (nslices < 1) nslices = 1;
             const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
             void* pd;
-            if ((rc = zl_scratch_get(ctx, 5, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
+            if ((rc = zl_scratch_get(ctx, slotA, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
             uint16_t* d_digits = (uint16_t*)pd;
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
             hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
@@ -1903,25 +1914,37 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // again when the tail of job i - 3 has finished, like the rest of the set)
     bool one_key = true;
     for (size_t i = 1; i < count; i++) one_key = one_key && specs[i].bs == specs[0].bs && specs[i].first == specs[0].first && specs[i].n == specs[0].n;
+    // SMALL jobs (at most 2^22 bucket entries each) are chains of short, latency-bound kernels: three phases on three shared streams would
+    // run their sorts one after the other, then their accumulations, then their tails (four 237-point MSMs of a small proof: 2.1 ms).  They
+    // run side by side instead: job i does sort, accumulation and tail on the stream of buffer set i % NS, with its own sort temporaries.
+    uint64_t biggest = 0;
+    for (size_t i = 0; i < count; i++) biggest = std::max<uint64_t>(biggest, (uint64_t)specs[i].n);
+    const bool side = biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 17));
+    const size_t NS = side ? std::min<size_t>(count, 4) : 3;
     for (size_t i = 0; i < count; i++) {
-        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, one_key ? 18 : 20 + (int)(i % 3)))) return rc;
-        if (one_key && i > 0) jobs[i].phi_owner = false;
+        // (side by side every job computes its own phi image: there is no common stream that would order a borrower behind the owner)
+        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, (one_key && !side) ? 18 : MsmJob<G>::phi_slot_of((int)(i % NS))))) return rc;
+        if (one_key && !side && i > 0) jobs[i].phi_owner = false;
         size_t a5, a6;
         jobs[i].sort_tmp_sizes(a5, a6);
         t5 = std::max(t5, a5);
         t6 = std::max(t6, a6);
         max_sets = std::max<uint32_t>(max_sets, jobs[i].SETS * jobs[i].roots_per_set);
     }
+    if (side) {
+        for (size_t k = 0; k < NS; k++)
+            if (!ctx->stream_lane[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_lane[k], hipStreamNonBlocking));
+    }
     // all buffers up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i: the first pass
     // grows every slot to its largest user, the second binds the final pointers.  Three sets: the tail of job i runs beside the
     // accumulation of job i+1 and is slow there, so the sort of job i+2 must not have to wait for it.
     void* dummy;
-    if (t5 && (rc = zl_scratch_get(ctx, 5, t5, &dummy))) return rc;
-    if (t6 && (rc = zl_scratch_get(ctx, 6, t6, &dummy))) return rc;
+    if (!side && t5 && (rc = zl_scratch_get(ctx, 5, t5, &dummy))) return rc;
+    if (!side && t6 && (rc = zl_scratch_get(ctx, 6, t6, &dummy))) return rc;
     for (int pass = 0; pass < 2; pass++) {
         for (size_t i = 0; i < count; i++) {
-            if ((rc = jobs[i].alloc(ctx, (int)(i % 3)))) return rc;
-            if (one_key && i > 0 && jobs[i].glv) jobs[i].d_phi = jobs[0].d_phi;
+            if ((rc = jobs[i].alloc(ctx, (int)(i % NS), side))) return rc;
+            if (one_key && !side && i > 0 && jobs[i].glv) jobs[i].d_phi = jobs[0].d_phi;
         }
     }
     const size_t per = sizeof(X) * (max_sets + 1) + 16;
@@ -1972,30 +1995,41 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // everything already queued on the caller's stream (e.g. the kernels that produced the scalars) comes first
     he = hipEventRecord(ev_begin, s_acc);
     if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
+    if (side)
+        for (size_t k = 0; k < NS && he == hipSuccess; k++) he = hipStreamWaitEvent(ctx->stream_lane[k], ev_begin, 0);
+    hipStream_t last_tail = nullptr;
+    static const bool jtrace = getenv("ZL_HOST_TRACE") != nullptr;
+    const auto jt0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < count && he == hipSuccess && rc == ZL_OK; i++) {
-        if (i >= 3) he = hipStreamWaitEvent(s_sort, ev_tail[i - 3], 0);  // buffer set i % 3 is free again
+        // pipelined: three phases on three streams; side by side: the whole job on the stream of its buffer set (the waits below are then
+        // between operations of one stream, i.e. no-ops)
+        hipStream_t js_sort = side ? ctx->stream_lane[i % NS] : s_sort, js_acc = side ? ctx->stream_lane[i % NS] : s_acc;
+        hipStream_t s_tail = side ? ctx->stream_lane[i % NS] : s_tails[i % 3];
+        if (i >= NS) he = hipStreamWaitEvent(js_sort, ev_tail[i - NS], 0);  // buffer set i % NS is free again
         if (recorded && specs[i].wait) {
             while (recorded->load(std::memory_order_acquire) >= 0 && recorded->load(std::memory_order_acquire) <= (int)i) std::this_thread::yield();
             if (recorded->load() < 0) { rc = ZL_EHIP; break; }
         }
-        if (he == hipSuccess && specs[i].wait) he = hipStreamWaitEvent(s_sort, specs[i].wait, 0);
+        if (he == hipSuccess && specs[i].wait) he = hipStreamWaitEvent(js_sort, specs[i].wait, 0);
         if (he != hipSuccess) break;
-        if ((rc = jobs[i].sort(ctx, s_sort))) break;
-        he = hipEventRecord(ev_sorted[i], s_sort);
-        if (he == hipSuccess) he = hipStreamWaitEvent(s_acc, ev_sorted[i], 0);
-        if (he == hipSuccess && ctx->timing_on) he = hipEventRecord(ev_acc0[i], s_acc);
+        if ((rc = jobs[i].sort(ctx, js_sort))) break;
+        he = hipEventRecord(ev_sorted[i], js_sort);
+        if (he == hipSuccess) he = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
+        if (he == hipSuccess && ctx->timing_on) he = hipEventRecord(ev_acc0[i], js_acc);
         if (he != hipSuccess) break;
-        if ((rc = jobs[i].accumulate(ctx, s_acc, acc_wg_per_cu))) break;
-        he = hipEventRecord(ev_acc[i], s_acc);
-        hipStream_t s_tail = s_tails[i % 3];
+        if ((rc = jobs[i].accumulate(ctx, js_acc, acc_wg_per_cu))) break;
+        he = hipEventRecord(ev_acc[i], js_acc);
         if (he == hipSuccess) he = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
         if (he != hipSuccess) break;
         if ((rc = jobs[i].tail(ctx, s_tail))) break;
         he = hipEventRecord(ev_tail[i], s_tail);
+        last_tail = s_tail;
+        if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu (n=%zu c=%d%s) issued at %.1f us\n", i, jobs[i].n_real, jobs[i].c, side ? ", side by side" : "",
+                            (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
     }
-    // ev_end: after the last tail of every tail stream
-    for (size_t back = 1; back <= 2 && back < count && he == hipSuccess && rc == ZL_OK; back++) he = hipStreamWaitEvent(s_tails[(count - 1) % 3], ev_tail[count - 1 - back], 0);
-    if (he == hipSuccess && rc == ZL_OK) he = hipEventRecord(ev_end, s_tails[(count - 1) % 3]);
+    // ev_end: after the last tail of every stream that ran tails
+    for (size_t back = 1; back < NS && back < count && he == hipSuccess && rc == ZL_OK; back++) he = hipStreamWaitEvent(last_tail, ev_tail[count - 1 - back], 0);
+    if (he == hipSuccess && rc == ZL_OK) he = hipEventRecord(ev_end, last_tail);
     // Host tails: this thread waits for the jobs' tail events in order (a job's root channels are then in pinned memory) and hands every
     // finished job to a helper thread that runs its window Horner and delivers the result -- while the device works on the later jobs.  Small
     // jobs, which the device finishes faster than the host, get their Horners side by side; `on_done` is delivered in job order.  (The helpers
@@ -2007,6 +2041,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         for (size_t i = 0; i < count; i++) {
             bool ok = frc.load() == ZL_OK;
             if (ok && hipEventSynchronize(ev_tail[i]) != hipSuccess) { frc.store(ZL_EHIP); ok = false; }
+            if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu on the host at %.1f us\n", i,
+                                (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
             if (ok && jobs[i].hE[1]) { frc.store(ZL_EINVAL); ok = false; }  // non-canonical scalar (see msm_run_t)
             finishers.emplace_back([&, i, ok]() {
                 if (ok) {
@@ -2027,6 +2063,11 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         const hipError_t hs = hipStreamSynchronize(t);
         if (he == hipSuccess) he = hs;
     }
+    if (side)
+        for (size_t k = 0; k < NS; k++) {
+            const hipError_t hs = hipStreamSynchronize(ctx->stream_lane[k]);
+            if (he == hipSuccess) he = hs;
+        }
     if (he == hipSuccess && rc == ZL_OK && ctx->timing_on) {
         float tot = 0.f, acc_sum = 0.f, t = 0.f;
         he = hipEventElapsedTime(&tot, ev_begin, ev_end);
