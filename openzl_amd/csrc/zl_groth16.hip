@@ -308,7 +308,13 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
                 zl::add_full(g1_b, from_partial<F1>(jp[2]));
                 zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
                 lap_us("a, b1 in: s A + r B1 starts");
-                g_c = zl::mul_scalar2(g_a, sw, g1_b, rw);
+                {   // s A + r B1 as two single-scalar products side by side (0.3 ms) instead of one interleaved double-scalar product (0.45 ms)
+                    XYZZ<F1> rb = XYZZ<F1>::inf();
+                    std::thread t_rb([&]() { rb = zl::mul_scalar(g1_b, rw); });
+                    g_c = zl::mul_scalar(g_a, sw);
+                    t_rb.join();
+                    zl::add_full(g_c, rb);
+                }
                 zl::add_full(g_c, rs_delta);
                 store_canon<G1>(a_words, &a_inf, g_a);  // A is final: its normalisation (one inversion) leaves the critical path too
                 have_c = true;

@@ -2046,7 +2046,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
             if (ok && jobs[i].hE[1]) { frc.store(ZL_EINVAL); ok = false; }  // non-canonical scalar (see msm_run_t)
             finishers.emplace_back([&, i, ok]() {
                 if (ok) {
-                    const X total = jobs[i].finish(count <= 2);  // several jobs: they already run side by side
+                    const X total = jobs[i].finish(true);  // (concurrent callers of the host pool each take part in their own loop)
                     memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
                     memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
                 }
