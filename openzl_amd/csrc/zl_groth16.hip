@@ -120,8 +120,10 @@ static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
 }
 
 template <class G1, class G2>
+// `witness` (optional): the assignment arrives in two pieces, `assignment` = the instance block and `witness` = the witness block, as the
+// compiler holds them (openzl::Groth16::prove): two copies to the device instead of a host-side concatenation of tens of megabytes per proof
 static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* cs, const uint64_t* assignment, unsigned flags, const uint64_t* r,
-                           const uint64_t* s, zl_g16_proof* out) {
+                           const uint64_t* s, zl_g16_proof* out, const uint64_t* witness = nullptr) {
     using FrP = typename G1::FrP;
     using Fr = Fp<FrP>;
     using F1 = typename G1::F;
@@ -170,11 +172,17 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     const size_t* off_val = cs->off_val;
     Fr* d_zc = (Fr*)(d + off_zc);
     Fr* d_zm = (Fr*)(d + off_zm);
+    auto h2d = [&](Fr* dst) -> hipError_t {
+        if (!witness) return hipMemcpyAsync(dst, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(dst, assignment, (size_t)ni * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nw) e = hipMemcpyAsync(dst + ni, witness, (size_t)nw * 32, hipMemcpyHostToDevice, st);
+        return e;
+    };
     if (flags & ZL_MONT) {  // arkworks' in-memory assignment: Montgomery limbs; the canonical copy (MSM scalars) is made on the device
-        ZL_HIP(ctx, hipMemcpyAsync(d_zm, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
+        ZL_HIP(ctx, h2d(d_zm));
         hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, d_zc, nv);
     } else {
-        ZL_HIP(ctx, hipMemcpyAsync(d_zc, assignment, (size_t)nv * 32, hipMemcpyHostToDevice, st));
+        ZL_HIP(ctx, h2d(d_zc));
         ZL_HIP(ctx, hipMemcpyAsync(d_zm, d_zc, (size_t)nv * 32, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, nv);
     }
@@ -287,25 +295,26 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         // the four G1 MSMs as one pipeline (sort | accumulate | tail of consecutive MSMs overlap, zl_msm.hip): l, a, b1 need only z;
         // the h job waits for the witness map's event
         {
-            const zl_bases* jb[4] = {bs[3], bs[0], bs[1], bs[2]};
-            const size_t jf[4] = {0, 1, 1, 0};
-            const void* js[4] = {zc + (size_t)ni * 32, zc + 32, zc + 32, d_h};
-            const size_t jn[4] = {(size_t)nw, (size_t)nv - 1, (size_t)nv - 1, (size_t)N - 1};
+            // order a, b1, l, h: A and B1 are complete after the first two jobs (their product s A + r B1 then runs under the other two)
+            const zl_bases* jb[4] = {bs[0], bs[1], bs[3], bs[2]};
+            const size_t jf[4] = {1, 1, 0, 0};
+            const void* js[4] = {zc + 32, zc + 32, zc + (size_t)ni * 32, d_h};
+            const size_t jn[4] = {(size_t)nv - 1, (size_t)nv - 1, (size_t)nw, (size_t)N - 1};
             const hipEvent_t jw[4] = {nullptr, nullptr, nullptr, ev_h};
             uint64_t jp[4][ZL_PARTIAL_WORDS];
-            // A and B1 are complete once the a and b1 MSMs (jobs 1, 2) are: their double-scalar product s A + r B1 (255 doublings + ~190
+            // A and B1 are complete once the a and b1 MSMs (jobs 0, 1) are: their double-scalar product s A + r B1 (255 doublings + ~190
             // additions on the host, ~0.4 ms) runs on the pipeline's completion thread while the h MSM and the G2 MSM are still on the device
             const std::function<void(size_t)> on_done = [&](size_t i) {
-                if (i != 2) return;
+                if (i != 1) return;
                 pre.join();
                 pre_b.join();
                 g_a = r_delta1;
                 zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
-                zl::add_full(g_a, from_partial<F1>(jp[1]));
+                zl::add_full(g_a, from_partial<F1>(jp[0]));
                 zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
                 g1_b = s_delta1;
                 zl::add_full(g1_b, affine_from_canon<G1>(b0_xy));
-                zl::add_full(g1_b, from_partial<F1>(jp[2]));
+                zl::add_full(g1_b, from_partial<F1>(jp[1]));
                 zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
                 lap_us("a, b1 in: s A + r B1 starts");
                 {   // s A + r B1 as two single-scalar products side by side (0.3 ms) instead of one interleaved double-scalar product (0.45 ms)
@@ -321,9 +330,9 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
                 lap_us("s A + r B1 done");
             };
             rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)nullptr, &on_done);
-            memcpy(part[3], jp[0], sizeof jp[0]);
-            memcpy(part[0], jp[1], sizeof jp[1]);
-            memcpy(part[1], jp[2], sizeof jp[2]);
+            memcpy(part[0], jp[0], sizeof jp[0]);
+            memcpy(part[1], jp[1], sizeof jp[1]);
+            memcpy(part[3], jp[2], sizeof jp[2]);
             memcpy(part[2], jp[3], sizeof jp[3]);
         }
         lap_us("G1 pipeline returned");
@@ -416,6 +425,19 @@ extern "C" int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint6
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
     if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
+    return ZL_EINVAL;
+}
+// internal (zl_host.hip): the assignment as the compiler holds it -- instance block and witness block, Montgomery limbs
+int zl_groth16_prove_split(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* instance, const uint64_t* witness, const uint64_t* r,
+                           const uint64_t* s, zl_g16_proof* out) {
+    if (!ctx || !pk || !instance || !r || !s || !out) return ZL_EINVAL;
+    auto it = ctx->r1cs.find(r1cs_handle);
+    if (it == ctx->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
+    if (it->second.n_witness && !witness) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    static const uint64_t none[4] = {0, 0, 0, 0};
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, instance, ZL_MONT, r, s, out, witness ? witness : none);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, instance, ZL_MONT, r, s, out, witness ? witness : none);
     return ZL_EINVAL;
 }
 extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,

@@ -11,6 +11,10 @@
 #include "zl_host.h"
 #include "zl_serialize.h"
 
+// zl_groth16.hip: the prover with the assignment in the compiler's two pieces (instance block, witness block; Montgomery limbs)
+int zl_groth16_prove_split(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* instance, const uint64_t* witness, const uint64_t* r,
+                           const uint64_t* s, zl_g16_proof* out);  // zl_groth16.hip
+
 namespace openzl {
 
 template <class FrP>
@@ -561,12 +565,10 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
         pc.n_constraints = nc;
         pc.circuit_digest = cs.structure_digest();
     }
-    // only the assignment travels per proof; the matrices and the proving key are device-resident
+    // only the assignment travels per proof; the matrices and the proving key are device-resident.  It goes to the device straight from the
+    // compiler's two vectors (Montgomery limbs as held): no host-side concatenation
     const auto& inst = cs.instance_assignment();
     const auto& wit = cs.witness_assignment();
-    std::vector<uint64_t> assignment((inst.size() + wit.size()) * 4);  // Montgomery limbs as held by the compiler (ZL_MONT)
-    memcpy(assignment.data(), inst.data(), inst.size() * 32);
-    memcpy(assignment.data() + 4 * inst.size(), wit.data(), wit.size() * 32);
     zl_g16_pk pk{};
     pk.curve = E::curve;
     pk.a_query = pc.a_query; pk.b_g1_query = pc.b_g1_query; pk.h_query = pc.h_query; pk.l_query = pc.l_query; pk.b_g2_query = pc.b_g2_query;
@@ -575,7 +577,8 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     uint64_t rw[4], sw[4];
     memcpy(rw, r.l, 32);
     memcpy(sw, s.l, 32);
-    const int rc = zl_groth16_prove_resident(pc.ctx, &pk, pc.r1cs, assignment.data(), ZL_MONT, rw, sw, &res.value);
+    const int rc = zl_groth16_prove_split(pc.ctx, &pk, pc.r1cs, reinterpret_cast<const uint64_t*>(inst.data()),
+                                          wit.empty() ? nullptr : reinterpret_cast<const uint64_t*>(wit.data()), rw, sw, &res.value);
     if (rc) { res.error = Error{rc}; return res; }  // .map_err(|_| Error) groth16.rs:456
     res.ok = true;
     return res;
