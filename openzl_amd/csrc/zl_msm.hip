@@ -1914,12 +1914,14 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // again when the tail of job i - 3 has finished, like the rest of the set)
     bool one_key = true;
     for (size_t i = 1; i < count; i++) one_key = one_key && specs[i].bs == specs[0].bs && specs[i].first == specs[0].first && specs[i].n == specs[0].n;
-    // SMALL jobs (at most 2^22 bucket entries each) are chains of short, latency-bound kernels: three phases on three shared streams would
+    // SMALL jobs (at most 2^20 points each) are chains of short, latency-bound kernels: three phases on three shared streams would
     // run their sorts one after the other, then their accumulations, then their tails (four 237-point MSMs of a small proof: 2.1 ms).  They
     // run side by side instead: job i does sort, accumulation and tail on the stream of buffer set i % NS, with its own sort temporaries.
     uint64_t biggest = 0;
     for (size_t i = 0; i < count; i++) biggest = std::max<uint64_t>(biggest, (uint64_t)specs[i].n);
-    const bool side = biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 17));
+    // measured (round 3, batches of 6): 2^16 0.69 -> 0.50 ms per MSM, 2^20 3.31 -> 3.10; equal at 2^18 - 2^19; from 2^21 on the three-phase pipeline
+    // wins (2^24: 36.3 against 37.3 ms)
+    const bool side = biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
     const size_t NS = side ? std::min<size_t>(count, 4) : 3;
     for (size_t i = 0; i < count; i++) {
         // (side by side every job computes its own phi image: there is no common stream that would order a borrower behind the owner)
