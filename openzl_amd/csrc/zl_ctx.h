@@ -29,6 +29,7 @@ struct BlsG1 {
     static constexpr int FQ64 = 6;     // u64 limbs per Fq element in the ABI layouts
     static constexpr int COORDS = 1;   // Fq elements per coordinate
     static constexpr bool GLV = true;  // plain MSMs split every scalar with the endomorphism (x, y) -> (beta x, y) = [lambda](x, y)
+    static constexpr int ENDO_K = 2;   // ... into two 127-bit halves
     using GLVP = BLS12_381_GLV;
     ZL_HD static F glv_beta() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = GLVP::beta(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F gen_x() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gx(i); return FieldIO<F>::load_mont32(w); }
@@ -45,6 +46,7 @@ struct BnG1 {
     static constexpr int FQ64 = 4;
     static constexpr int COORDS = 1;
     static constexpr bool GLV = false;
+    static constexpr int ENDO_K = 1;
     ZL_HD static F gen_x() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gx(i); return r; }
     ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
     ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
@@ -58,7 +60,13 @@ struct G2Cfg {
     static constexpr int SC_BITS = SCB;
     static constexpr int FQ64 = FQ64_;
     static constexpr int COORDS = 2;
-    static constexpr bool GLV = false;
+    // BLS12-381 G2 (ID 2): the untwist-Frobenius-twist endomorphism psi acts as [z] = [-|z|], r < |z|^4: a scalar is four base-|z| digits of 64 bits
+    // over P, psi(P), psi^2(P), psi^3(P) with alternating signs (GLS).  BN254 G2 keeps plain 254-bit windows.
+    static constexpr bool GLV = ID_ == 2;
+    static constexpr int ENDO_K = ID_ == 2 ? 4 : 1;
+    using GLVP = BLS12_381_GLS;
+    ZL_HD static F psi_x() { return mk(GLVP::psi_x0, GLVP::psi_x1); }
+    ZL_HD static F psi_y() { return mk(GLVP::psi_y0, GLVP::psi_y1); }
     ZL_HD static F mk(uint32_t (*f0)(int), uint32_t (*f1)(int)) {  // two components as arkworks' Montgomery words
         uint32_t w[2 * FqP::N];
         for (int i = 0; i < FqP::N; i++) { w[i] = f0(i); w[FqP::N + i] = f1(i); }

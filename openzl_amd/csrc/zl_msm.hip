@@ -793,6 +793,112 @@ __global__ void __launch_bounds__(128) k_glv_phi(const Affine<typename G::F>* __
     phib[i] = p;
 }
 
+// ---- GLS for BLS12-381 G2: k = k0 + k1 |z| + k2 |z|^2 + k3 |z|^3 (digits below |z| < 2^64), k P = k0 P - k1 psi(P) + k2 psi^2(P) - k3 psi^3(P) ----------
+// out: 4n records of 8 words -- record j n + i = digit j of scalar i in words 0..1, its sign (odd j: negative) in bit 31 of word 7.
+// q = floor(x / |z|) for x < 2^256: Barrett with m = floor(2^320 / |z|) = 2^256 + mlow: ((x mlow >> 256) + x) >> 64, at most one short.
+template <class P>
+__device__ __forceinline__ uint64_t zl_divmod_z(uint32_t x[8]) {
+    uint32_t pw[16];
+    {
+        uint64_t acc = 0;
+        uint32_t top = 0;
+#pragma unroll
+        for (int col = 0; col < 15; col++) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const int b = col - a;
+                if (b < 0 || b > 7) continue;
+                const uint64_t pr = (uint64_t)x[a] * P::barrett(b);
+                acc += pr;
+                top += acc < pr ? 1u : 0u;
+            }
+            pw[col] = (uint32_t)acc;
+            acc = (acc >> 32) | ((uint64_t)top << 32);
+            top = 0;
+        }
+        pw[15] = (uint32_t)acc;
+    }
+    uint32_t t[9];  // (x mlow >> 256) + x
+    {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            carry += (uint64_t)pw[8 + w] + x[w];
+            t[w] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        t[8] = (uint32_t)carry;
+    }
+    uint32_t q[8];
+#pragma unroll
+    for (int w = 0; w < 7; w++) q[w] = t[w + 2];
+    q[7] = 0;
+    // rem = x - q |z| (mod 2^128; the true value is below 2 |z| < 2^65)
+    const uint64_t Z = (uint64_t)P::z(0) | ((uint64_t)P::z(1) << 32);
+    const uint64_t q01 = (uint64_t)q[0] | ((uint64_t)q[1] << 32), q23 = (uint64_t)q[2] | ((uint64_t)q[3] << 32);
+    const uint64_t lo = q01 * Z, hi = __umul64hi(q01, Z) + q23 * Z;
+    const uint64_t x01 = (uint64_t)x[0] | ((uint64_t)x[1] << 32), x23 = (uint64_t)x[2] | ((uint64_t)x[3] << 32);
+    uint64_t rlo = x01 - lo, rhi = x23 - hi - (x01 < lo ? 1u : 0u);
+    if (rhi != 0 || rlo >= Z) {
+        rhi -= rlo < Z ? 1u : 0u;
+        rlo -= Z;
+        uint32_t carry = 1;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const uint32_t v = q[w] + carry;
+            carry = (v < carry) ? 1u : 0u;
+            q[w] = v;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) x[w] = q[w];
+    return rlo;
+}
+template <class P>
+__global__ void __launch_bounds__(256) k_gls_split(const uint32_t* __restrict__ scalars, uint32_t n, const uint8_t* __restrict__ inf, uint32_t* __restrict__ out,
+                                                    int sc_bits, uint32_t* __restrict__ bad) {
+    ZL_SIDE_PRIO();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 lo4 = sp[0], hi4 = sp[1];
+    zl_flag_wide_scalar(hi4.w, sc_bits, bad);
+    if (inf && inf[i]) lo4 = hi4 = make_uint4(0, 0, 0, 0);
+    uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint64_t d[4];
+    d[0] = zl_divmod_z<P>(k);
+    d[1] = zl_divmod_z<P>(k);
+    d[2] = zl_divmod_z<P>(k);
+    d[3] = (uint64_t)k[0] | ((uint64_t)k[1] << 32);  // k < r < |z|^4: the last quotient is a digit
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint4* o = reinterpret_cast<uint4*>(out + ((size_t)j * n + i) * 8);
+        o[0] = make_uint4((uint32_t)d[j], (uint32_t)(d[j] >> 32), 0, 0);
+        o[1] = make_uint4(0, 0, 0, (d[j] != 0 && (j & 1)) ? 0x80000000u : 0u);
+    }
+}
+// phib[(j - 1) n + i] = psi^j(P_i), j = 1..3; psi(x, y) = (conj(x) gx, conj(y) gy); infinity (all-zero) stays itself
+template <class G>
+__global__ void __launch_bounds__(64) k_gls_psi(const Affine<typename G::F>* __restrict__ bases, uint32_t n, Affine<typename G::F>* __restrict__ phib) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = bases[i];
+    const bool inf = p.is_inf();
+    const F gx = G::psi_x(), gy = G::psi_y();
+    for (int j = 0; j < 3; j++) {
+        if (!inf) {
+            F cx = p.x, cy = p.y;
+            cx.c1 = zl::canon(zl::neg(cx.c1));  // conj: (c0, -c1); canonical again before it enters a product
+            cy.c1 = zl::canon(zl::neg(cy.c1));
+            p.x = zl::canon(zl::mul(cx, gx));
+            p.y = zl::canon(zl::mul(cy, gy));
+        }
+        phib[(size_t)j * n + i] = p;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan of `count` u32 values, 3 launches; out[count] = total
 #define SCAN_ITEMS 16
@@ -1401,7 +1507,7 @@ struct MsmJob {
     bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
     bool glv = false;   // the job runs on 2 n_real half-scalars of 127 bits over the points P_i and phi(P_i) (k_glv_split / k_glv_phi)
     bool phi_owner = false;  // this job computes the phi image of its bases in its sort phase (else it borrows d_phi from an earlier job of the call)
-    int sc_bits = 0, phi_slot = -1;
+    int sc_bits = 0, phi_slot = -1, endo_k = 1;  // endo_k: half-scalars per scalar (2: GLV on G1, 4: GLS on BLS12-381 G2)
     int slotA = 5, slotB = 6;  // scratch slots of the sort temporaries (shared by the jobs of a pipelined batch; per buffer set when small jobs run side by side)
     size_t n_real = 0;
     uint32_t* d_vs = nullptr;            // the half-scalars (inside the sort temporaries)
@@ -1436,7 +1542,7 @@ struct MsmJob {
         // (read + write of every point) and the three-level sort of 2 n records cost what the tail saves (2^20: 3.73 = 3.73 ms; 2^24 single
         // call 39.2 -> 39.7 ms, pipelined 36.7 = 36.7), so large inputs keep the plain 255-bit windows.
         static const size_t glv_max = (size_t)1 << zl_tune("ZL_TUNE_GLV_MAX_LOG", 19);
-        if constexpr (G::GLV) try_glv = phi_slot_ >= 0 && bs.precomp_c == 0 && !no_glv && n_ >= 1 && n_ <= glv_max && n_ < (1ull << 30);
+        if constexpr (G::GLV) try_glv = phi_slot_ >= 0 && bs.precomp_c == 0 && !no_glv && n_ >= 1 && n_ <= glv_max && (uint64_t)n_ * G::ENDO_K < (1ull << 31);
         int rc = plan_as(ctx, bs, first_, d_scalars, n_, try_glv);
         // (c <= 3: the top window of a 127-bit half-scalar can reach magnitude H + carry; not worth a special case)
         if (!rc && glv && c <= 3) rc = plan_as(ctx, bs, first_, d_scalars, n_, false);
@@ -1449,8 +1555,9 @@ struct MsmJob {
     int plan_as(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_, bool glv_) {
         glv = glv_;
         n_real = n_;
-        n = glv ? 2 * n_ : n_;
-        sc_bits = glv ? 127 : (int)G::SC_BITS;
+        endo_k = glv ? (int)G::ENDO_K : 1;
+        n = (size_t)endo_k * n_;
+        sc_bits = !glv ? (int)G::SC_BITS : (G::ENDO_K == 2 ? 127 : 64);
         first = first_;
         bsp = &bs;
         pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
@@ -1562,7 +1669,7 @@ struct MsmJob {
         d_ones_parts = d_sets + root_elems + 1;
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
         if (glv && phi_owner) {
-            if ((rc = zl_scratch_get(ctx, phi_slot, n_real * sizeof(Affine<F>), &p))) return rc;
+            if ((rc = zl_scratch_get(ctx, phi_slot, (size_t)(endo_k - 1) * n_real * sizeof(Affine<F>), &p))) return rc;
             d_phi = reinterpret_cast<const Affine<F>*>(p);
         }
         return ZL_OK;
@@ -1617,10 +1724,14 @@ struct MsmJob {
             void* p5;
             if ((rc = zl_scratch_get(ctx, slotA, s5tot, &p5))) return rc;
             d_vs = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p5) + (s5tot - vs_bytes()));
-            if constexpr (G::GLV) {
+            if constexpr (G::GLV && G::ENDO_K == 2) {
                 hipLaunchKernelGGL((k_glv_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
                 if (phi_owner)
                     hipLaunchKernelGGL((k_glv_phi<G>), dim3((uint32_t)((n_real + 127) / 128)), dim3(128), 0, st, d_bases, (uint32_t)n_real, const_cast<Affine<F>*>(d_phi));
+            } else if constexpr (G::GLV && G::ENDO_K == 4) {
+                hipLaunchKernelGGL((k_gls_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
+                if (phi_owner)
+                    hipLaunchKernelGGL((k_gls_psi<G>), dim3((uint32_t)((n_real + 63) / 64)), dim3(64), 0, st, d_bases, (uint32_t)n_real, const_cast<Affine<F>*>(d_phi));
             }
             sc_eff = d_vs;
             inf_eff = nullptr;  // the split already dropped the scalars of bases at infinity

@@ -72,3 +72,46 @@ def test_g2_precomputed_table_and_skew(backend, curve):
     backend.bases_free(h)
     assert pinf == einf and (plain == exp).all()
     assert inf == einf and (got == exp).all()
+
+
+def test_msm_g2_gls_edge_scalars(backend):
+    """BLS12-381 G2 plain MSMs split every scalar into four base-|z| digits over P, psi(P), psi^2(P), psi^3(P) (csrc/zl_msm.hip k_gls_split /
+    k_gls_psi; psi acts as [-|z|] on G2).  Scalars on the digit boundaries -- multiples and powers of |z|, all-ones digits, r - 1 -- beside random
+    ones, through the LDS sort, the wide sort at c = 16 and a narrow window, single call and pipelined batch, and every edge scalar alone."""
+    import torch
+
+    curve = po.BLS12_381
+    r = curve.fr.p
+    z = 0xD201000000010000
+    assert r == z ** 4 - z ** 2 + 1
+    edge = [0, 1, 2, z - 1, z, z + 1, z * z - 1, z * z, z * z + 1, z ** 3 - 1, z ** 3, z ** 3 + 1, (z - 1) * (1 + z + z * z + z ** 3) % r, r - 1, r - 2, r - z,
+            (z - 1) * z, (z - 1) * z * z, (z - 1) * z ** 3 % r, 3 * z ** 3 + 5, 0xFFFFFFFFFFFFFFFF % z]
+    n = 600
+    S = ol.random_scalars(curve, n, 881)
+    S[: len(edge)] = ol.ints_to_limbs([e % r for e in edge], 4)
+    ks = ol.limbs_to_ints(ol.random_scalars(curve, n, 882))
+    B = gu.g2_mul_gen(curve, ks)
+    B[40] = 0  # a base at infinity
+    h = backend.bases_upload(curve.cid, B, group=ZL_G2)
+    exp, einf = _oracle_msm_g2(curve, B, S)
+    d_s = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    try:
+        for c in (0, 4, 9, 16):
+            backend.set_msm_window(c)
+            got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+            assert inf == einf and (got == exp).all(), c
+        backend.set_msm_window(0)
+        parts = backend.msm_batch_partial_dev(h, [d_s.data_ptr()] * 5, n)
+        for j in range(5):
+            xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1], group=ZL_G2)
+            assert pinf == einf and (xy == exp).all(), j
+        backend.set_msm_window(7)
+        for e in edge:
+            s1 = ol.ints_to_limbs([e % r], 4)
+            got, inf = backend.msm(h, s1)
+            e1, i1 = _oracle_msm_g2(curve, B[:1], s1, threads=1)
+            assert inf == i1 and (got == e1).all(), hex(e)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
