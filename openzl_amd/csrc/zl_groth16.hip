@@ -270,13 +270,20 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     XYZZ<F2> s_delta2;
     // (three threads: the four scalar multiplications are ~0.3 ms each in G1 and ~1 ms in G2 -- one after the other they were 1.9 ms, the
     // longest single item of a small proof)
-    std::thread pre([&]() {
-        r_delta1 = zl::mul_scalar(delta1, rw);
-        rs_delta = zl::mul_scalar(r_delta1, sw);
-        zl::neg_inplace(rs_delta);
-    });
-    std::thread pre_b([&]() { s_delta1 = zl::mul_scalar(delta1, sw); });
-    std::thread pre_g2([&]() { s_delta2 = zl::mul_scalar(delta2, sw); });
+    // (r s) delta1 from the product r s in Fr, so that all four are independent
+    uint32_t rsw[8];
+    {
+        using FrF = Fp<typename G1::FrP>;
+        FrF rm, sm;
+        memcpy(rm.l, rw, 32);
+        memcpy(sm.l, sw, 32);
+        const FrF rs = zl::from_mont(zl::mul(zl::to_mont(rm), zl::to_mont(sm)));
+        memcpy(rsw, rs.l, 32);
+    }
+    std::thread pre([&]() { r_delta1 = zl::mul_scalar_w4(delta1, rw); });
+    std::thread pre_c([&]() { rs_delta = zl::mul_scalar_w4(delta1, rsw); zl::neg_inplace(rs_delta); });
+    std::thread pre_b([&]() { s_delta1 = zl::mul_scalar_w4(delta1, sw); });
+    std::thread pre_g2([&]() { s_delta2 = zl::mul_scalar_w4(delta2, sw); });
     lap_us("z on device, host pre started");
     int rc_g2 = ZL_OK;
     XYZZ<F1> g_a = XYZZ<F1>::inf(), g1_b = XYZZ<F1>::inf(), g_c = XYZZ<F1>::inf();
@@ -308,6 +315,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
                 if (i != 1) return;
                 pre.join();
                 pre_b.join();
+                pre_c.join();
                 g_a = r_delta1;
                 zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
                 zl::add_full(g_a, from_partial<F1>(jp[0]));
@@ -319,8 +327,8 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
                 lap_us("a, b1 in: s A + r B1 starts");
                 {   // s A + r B1 as two single-scalar products side by side (0.3 ms) instead of one interleaved double-scalar product (0.45 ms)
                     XYZZ<F1> rb = XYZZ<F1>::inf();
-                    std::thread t_rb([&]() { rb = zl::mul_scalar(g1_b, rw); });
-                    g_c = zl::mul_scalar(g_a, sw);
+                    std::thread t_rb([&]() { rb = zl::mul_scalar_w4(g1_b, rw); });
+                    g_c = zl::mul_scalar_w4(g_a, sw);
                     t_rb.join();
                     zl::add_full(g_c, rb);
                 }
@@ -342,6 +350,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     }
     if (pre.joinable()) pre.join();
     if (pre_b.joinable()) pre_b.join();
+    if (pre_c.joinable()) pre_c.join();
     pre_g2.join();
     if (!rc) rc = rc_g2;
     if (!rc && !have_c) rc = ZL_EHIP;  // (the completion callback did not run: cannot happen after a successful pipeline)
