@@ -32,6 +32,11 @@ const char* zl_strerror(int code) {
 int zl_ctx_create(zl_ctx** out, int device_id) {
     if (!out) return ZL_EINVAL;
     *out = nullptr;
+    // The library runs up to ~12 streams at once (three pipeline phases, four side-by-side lanes, the G2 MSM, the witness map, tails); the HIP
+    // runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two chains of small dependent kernels that share a
+    // queue run one after the other.  8 queues: a 235-constraint proof 1.35 -> 1.16 ms (median), nothing else moves.  Only effective when this is
+    // the process's first HIP call (the runtime reads it once); a caller's own setting wins.
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZL_ENODEV;
     if (device_id < 0 || device_id >= count) return ZL_EINVAL;
@@ -62,10 +67,15 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
 void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (zl_ctx* c : {ctx, ctx->aux, ctx->aux2}) {
+        if (!c) continue;
+        for (auto& w : c->workers) { delete w; w = nullptr; }  // (joins: a worker is idle between calls)
+    }
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->bases) {
         if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
+        if (kv.second.d_endo) (void)hipFree(kv.second.d_endo);
         if (kv.second.d_inf) (void)hipFree(kv.second.d_inf);
     }
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
@@ -186,6 +196,7 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_pts) (void)hipFree(it->second.d_pts);
     if (it->second.d_table) (void)hipFree(it->second.d_table);
+    if (it->second.d_endo) (void)hipFree(it->second.d_endo);
     if (it->second.d_inf) (void)hipFree(it->second.d_inf);
     ctx->bases.erase(it);
     return ZL_OK;

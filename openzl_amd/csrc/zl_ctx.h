@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/zl_backend.h"
 #include "zl_curve.h"
+#include "zl_pool.h"
 
 #define ZL_HIP(ctx, call)                                   \
     do {                                                    \
@@ -89,6 +90,11 @@ struct zl_bases {
     size_t n_inf = 0;
     size_t n = 0;
     int curve = 0, group = 0;
+    // endomorphism images of points [endo_first, endo_first + endo_n) (GLV: phi(P); GLS: psi, psi^2, psi^3), built by the first small MSM over
+    // that range and kept with the handle: a proving key's queries are always used with the same range
+    mutable void* d_endo = nullptr;
+    mutable size_t endo_first = 0, endo_n = 0;
+    mutable int endo_k = 0;
     mutable std::vector<uint64_t> first_xy;  // canonical affine words of point 0, fetched once (Groth16: the z_0 = 1 term of a / b queries)
 };
 struct zl_scratch {
@@ -132,10 +138,15 @@ struct zl_ctx {
     zl_ctx* aux2 = nullptr;  // second auxiliary context (Groth16: the witness map runs beside the witness-only MSMs)
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
     void* fb_table[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base window tables of the generators (per group config, built on first use)
+    zl_worker* workers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // persistent host threads of this ctx: 0 witness-map issue, 1 G2 MSM (Groth16); 2..5 one per lane stream (side-by-side MSM batches)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 8; reset when the next proof starts)
     size_t g16_h_n = 0;
 };
 
+inline zl_worker& zl_ctx_worker(zl_ctx* ctx, int k) {
+    if (!ctx->workers[k]) ctx->workers[k] = new zl_worker();
+    return *ctx->workers[k];
+}
 // grow-only device scratch slot
 inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
     zl_scratch& s = ctx->scratch[slot];

@@ -273,43 +273,63 @@ struct Host56 {
     static void load(const F& a, uint64_t* o) {
         for (int j = 0; j < 7; j++) o[j] = (uint64_t)a.l[2 * j] | ((uint64_t)a.l[2 * j + 1] << 28);  // top limb may exceed 28 bits: < 2^58 here
     }
-    // r = (a*b [+ c*d]) / 2^392 mod q (+ multiple of q), CIOS in base 2^56
-    template <class F>
-    static F mac(const F& a, const F& b, const F* c, const F* d) {
+    // r = (a*b [+ c*d]) / 2^392 mod q (+ multiple of q): product scan in base 2^56, one 128-bit column accumulator (a column holds at most
+    // 7 + 7 products of < 2^116 and 7 of m q < 2^112: < 2^120), no per-product masking; SQ = a is b (28 distinct products instead of 49)
+    template <bool CD, bool SQ, class F>
+    static F mac_t(const F& a, const F& b, const F* c, const F* d) {
+        typedef unsigned __int128 u128;
         static const uint64_t ninv = inv();
-        uint64_t qa[7], x[7], y[7], u[7], v[7];
+        uint64_t qa[7], x[7], y[7], u[7], v[7], m[7], t[8];
+#pragma unroll
         for (int j = 0; j < 7; j++) qa[j] = q(j);
         load(a, x);
-        load(b, y);
-        if (c) { load(*c, u); load(*d, v); }
-        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 7; i++) {
-            unsigned __int128 cy = 0;
-            for (int j = 0; j < 7; j++) {
-                cy += (unsigned __int128)x[i] * y[j] + t[j];
-                if (c) cy += (unsigned __int128)u[i] * v[j];
-                t[j] = (uint64_t)cy & M56;
-                cy >>= 56;
+        if (!SQ) load(b, y);
+        if (CD) { load(*c, u); load(*d, v); }
+        u128 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            const int lo = k < 7 ? 0 : k - 6, hi = k < 7 ? k : 6;
+            if (SQ) {
+                u128 cross = 0;
+#pragma unroll
+                for (int i = lo; 2 * i < k; i++) cross += (u128)x[i] * x[k - i];
+                acc += cross + cross;
+                if ((k & 1) == 0) acc += (u128)x[k >> 1] * x[k >> 1];
+            } else {
+#pragma unroll
+                for (int i = lo; i <= hi; i++) acc += (u128)x[i] * y[k - i];
             }
-            t[7] += (uint64_t)cy;
-            const uint64_t m = (t[0] * ninv) & M56;
-            cy = ((unsigned __int128)m * qa[0] + t[0]) >> 56;
-            for (int j = 1; j < 7; j++) {
-                cy += (unsigned __int128)m * qa[j] + t[j];
-                t[j - 1] = (uint64_t)cy & M56;
-                cy >>= 56;
+            if (CD) {
+#pragma unroll
+                for (int i = lo; i <= hi; i++) acc += (u128)u[i] * v[k - i];
             }
-            cy += t[7];
-            t[6] = (uint64_t)cy & M56;
-            t[7] = (uint64_t)(cy >> 56);
+            if (k < 7) {
+#pragma unroll
+                for (int i = 0; i < k; i++) acc += (u128)m[i] * qa[k - i];
+                m[k] = ((uint64_t)acc * ninv) & M56;
+                acc += (u128)m[k] * qa[0];
+            } else {
+#pragma unroll
+                for (int i = lo; i <= 6; i++) acc += (u128)m[i] * qa[k - i];
+                t[k - 7] = (uint64_t)acc & M56;
+            }
+            acc >>= 56;
         }
+        t[7] = (uint64_t)acc;
         F r = a;
+#pragma unroll
         for (int j = 0; j < 7; j++) {
             r.l[2 * j] = (uint32_t)(t[j] & 0xFFFFFFFull);
             r.l[2 * j + 1] = (uint32_t)(t[j] >> 28);
         }
         r.l[13] += (uint32_t)(t[7] << 28);  // zero for in-contract operands (result < 2q)
         return r;
+    }
+    template <class F>
+    static F mac(const F& a, const F& b, const F* c, const F* d) {
+        if (c) return mac_t<true, false>(a, b, c, d);
+        if (&a == &b) return mac_t<false, true>(a, b, c, d);
+        return mac_t<false, false>(a, b, c, d);
     }
 };
 #endif
@@ -343,6 +363,12 @@ ZL_NOINLINE_HD Fp28<A, B> mul_call28(Fp28<A, B> a, Fp28<A, B> b) {
 #endif
     return mul_body28(a, b);
 }
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <class A, class B>
+__attribute__((noinline)) Fp28<A, B> sqr_host28(const Fp28<A, B>& a) {
+    return Host56<A>::mac(a, a, (const Fp28<A, B>*)nullptr, (const Fp28<A, B>*)nullptr);
+}
+#endif
 template <class A, class B>
 ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZL_NO_ASM_MUL28)
@@ -372,6 +398,9 @@ ZL_HD Fp28<A, B> sqr(const Fp28<A, B>& a) {
         sqr28_asm<A>(r.l, a.l);
         return r;
     }
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (A::L == 14) return sqr_host28<A, B>(a);
 #endif
     return mul(a, a);
 }

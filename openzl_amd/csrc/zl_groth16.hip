@@ -212,28 +212,40 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     hipStream_t s_wm = wm->stream;
     hipEvent_t ev_z = wm->ev[0], ev_h = wm->ev[1];
     ZL_HIP(ctx, hipEventRecord(ev_z, st));
-    ZL_HIP(ctx, hipStreamWaitEvent(s_wm, ev_z, 0));
-    for (int m = 0; m < 3; m++)
-        hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
-                           (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
-    ZL_HIP(ctx, hipGetLastError());
     const int timing_saved = ctx->timing_on;
     ctx->timing_on = 0;  // inner calls must not sync / overwrite the prover's events
     wm->timing_on = 0;
-    auto wm_fail = [&](int code) { (void)hipStreamSynchronize(s_wm); ctx->timing_on = timing_saved; return code; };
-    for (int m = 0; m < 3; m++) {
-        if ((rc = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) return wm_fail(rc);
-        if ((rc = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) return wm_fail(rc);
-    }
-    Fr g;
-    for (int i = 0; i < Fr::N; i++) g.l[i] = FrP::generator(i);
-    Fr gN = g;
-    for (unsigned i = 0; i < log_n; i++) gN = zl::sqr(gN);
-    const Fr zinv = zl::inv(zl::sub(gN, Fr::one()));
-    hipLaunchKernelGGL((k_qap_pointwise<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_b, d_c, zinv, N);
-    if ((rc = zl_ntt_run(wm, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE | ZL_COSET))) return wm_fail(rc);
-    hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_h, N);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(ev_h, s_wm) != hipSuccess) return wm_fail(ZL_EHIP);
+    // The ~16 launches of the witness map are issued by a persistent thread of the ctx while this one goes on to the MSMs (0.15 ms of host
+    // time that stood in front of every MSM of a small proof).  h_recorded: 4 once ev_h is recorded (the h job, index 3 of the pipeline below,
+    // may then wait for it), negative on failure.
+    std::atomic<int> h_recorded{0};
+    int rc_wm = ZL_OK;
+    zl_worker& w_wm = zl_ctx_worker(ctx, 0);
+    w_wm.run([&]() {
+        auto fail = [&](int code) { rc_wm = code; h_recorded.store(-1, std::memory_order_release); };
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamWaitEvent(s_wm, ev_z, 0) != hipSuccess) return fail(ZL_EHIP);
+        for (int m = 0; m < 3; m++)
+            hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
+                               (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+        if (hipGetLastError() != hipSuccess) return fail(ZL_EHIP);
+        int r;
+        for (int m = 0; m < 3; m++) {
+            if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) return fail(r);
+            if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) return fail(r);
+        }
+        Fr g;
+        for (int i = 0; i < Fr::N; i++) g.l[i] = FrP::generator(i);
+        Fr gN = g;
+        for (unsigned i = 0; i < log_n; i++) gN = zl::sqr(gN);
+        const Fr zinv = zl::inv(zl::sub(gN, Fr::one()));
+        hipLaunchKernelGGL((k_qap_pointwise<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_b, d_c, zinv, N);
+        if ((r = zl_ntt_run(wm, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE | ZL_COSET))) return fail(r);
+        hipLaunchKernelGGL((k_fr_from_mont<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, d_a, d_h, N);
+        if (hipGetLastError() != hipSuccess || hipEventRecord(ev_h, s_wm) != hipSuccess) return fail(ZL_EHIP);
+        h_recorded.store(4, std::memory_order_release);
+    });
+    // (every return below first waits for that thread: it works on this frame)
+    auto wm_fail = [&](int code) { w_wm.wait(); (void)hipStreamSynchronize(s_wm); ctx->timing_on = timing_saved; return code; };
     // ---- the five MSMs ----------------------------------------------------------------------------------------------
     uint64_t part[5][ZL_PARTIAL_WORDS];
     const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
@@ -280,10 +292,10 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         const FrF rs = zl::from_mont(zl::mul(zl::to_mont(rm), zl::to_mont(sm)));
         memcpy(rsw, rs.l, 32);
     }
-    std::thread pre([&]() { r_delta1 = zl::mul_scalar_w4(delta1, rw); });
+    std::thread pre([&]() { r_delta1 = zl::mul_scalar_w4(delta1, rw); lap_us("r delta1 done"); });
     std::thread pre_c([&]() { rs_delta = zl::mul_scalar_w4(delta1, rsw); zl::neg_inplace(rs_delta); });
     std::thread pre_b([&]() { s_delta1 = zl::mul_scalar_w4(delta1, sw); });
-    std::thread pre_g2([&]() { s_delta2 = zl::mul_scalar_w4(delta2, sw); });
+    std::thread pre_g2([&]() { s_delta2 = zl::mul_scalar_w4(delta2, sw); lap_us("s delta2 done"); });
     lap_us("z on device, host pre started");
     int rc_g2 = ZL_OK;
     XYZZ<F1> g_a = XYZZ<F1>::inf(), g1_b = XYZZ<F1>::inf(), g_c = XYZZ<F1>::inf();
@@ -295,7 +307,8 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         const zl_bases* b2 = bs[4];
         const int curve = pk->curve;
         uint64_t* out2 = part[4];
-        std::thread g2([&, aux, b2, curve, out2]() {
+        zl_worker& g2 = zl_ctx_worker(ctx, 1);
+        g2.run([&, aux, b2, curve, out2]() {
             if (hipSetDevice(aux->device) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
             rc_g2 = ZL_DISPATCH(curve, ZL_G2, zl_msm_run, aux, *b2, 1, zc + 32, nv - 1, out2);
         });
@@ -313,6 +326,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             // additions on the host, ~0.4 ms) runs on the pipeline's completion thread while the h MSM and the G2 MSM are still on the device
             const std::function<void(size_t)> on_done = [&](size_t i) {
                 if (i != 1) return;
+                lap_us("a, b1 delivered");
                 pre.join();
                 pre_b.join();
                 pre_c.join();
@@ -337,15 +351,17 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
                 have_c = true;
                 lap_us("s A + r B1 done");
             };
-            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)nullptr, &on_done);
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 4, &jp[0][0], (const std::atomic<int>*)&h_recorded, &on_done);
             memcpy(part[0], jp[0], sizeof jp[0]);
             memcpy(part[1], jp[1], sizeof jp[1]);
             memcpy(part[3], jp[2], sizeof jp[2]);
             memcpy(part[2], jp[3], sizeof jp[3]);
         }
         lap_us("G1 pipeline returned");
+        w_wm.wait();
         (void)hipStreamSynchronize(s_wm);  // also on the error path: nothing of this proof may still be running
-        g2.join();
+        g2.wait();
+        if (!rc) rc = rc_wm;
         lap_us("G2 joined");
     }
     if (pre.joinable()) pre.join();

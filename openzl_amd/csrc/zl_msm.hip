@@ -30,6 +30,7 @@
 #include <vector>
 #include "zl_ctx.h"
 #include "zl_pool.h"
+#include "zl_quad.h"
 
 // This file is compiled once per group: -DZL_G=BlsG1|BnG1|BlsG2|BnG2 (see openzl_amd/build.py)
 #ifndef ZL_G
@@ -947,6 +948,47 @@ static __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__
         if (flag_in) total_out[1] = *flag_in;
     }
 }
+// Small bucket counts (NB <= 16384): slice prefix + the three scan launches as ONE block of 1024 lanes, 16 consecutive buckets per lane.
+// counts[slice][bucket] -> in-place exclusive prefix over slices; offsets[b] = cursor[b] = exclusive prefix over buckets; offsets[NB] = total,
+// offsets[NB + 1] = *flag_in (as k_scan_top).  Four dependent launches of a few microseconds each are what a small job's sort phase consists of.
+static __global__ void __launch_bounds__(1024) k_msm_prefix_small(uint32_t* __restrict__ counts, uint32_t NB, uint32_t nslices, uint32_t* __restrict__ offsets,
+                                                                  uint32_t* __restrict__ cursor, const uint32_t* __restrict__ flag_in) {
+    ZL_SIDE_PRIO();
+    __shared__ uint32_t sh[1024];
+    const uint32_t base = threadIdx.x * 16;
+    uint32_t v[16];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t run = 0;
+        if (base + k < NB)
+            for (uint32_t sl = 0; sl < nslices; sl++) {
+                const uint32_t x = counts[(size_t)sl * NB + base + k];
+                counts[(size_t)sl * NB + base + k] = run;
+                run += x;
+            }
+        v[k] = run;
+        s += run;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t t = threadIdx.x >= (uint32_t)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (base + k < NB) { offsets[base + k] = run; cursor[base + k] = run; }
+        run += v[k];
+    }
+    if (threadIdx.x == 1023) {
+        offsets[NB] = sh[1023];
+        if (flag_in) offsets[NB + 1] = *flag_in;
+    }
+}
 static __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t count, const uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
     ZL_SIDE_PRIO();
@@ -988,8 +1030,8 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
 #define ZL_ACC_BLOCK 64
 #endif
 // one lane, one chunk: entries [t * ZL_CHUNK, (t + 1) * ZL_CHUNK) of the bucket-sorted list
-template <class G>
-__device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, uint32_t E, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+template <class G, bool QUAD = false>
+__device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_t E, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                     const Affine<typename HotField<typename G::F>::type>* __restrict__ bases,
                                                     XYZZ<typename HotField<typename G::F>::type>* __restrict__ bucket_sums,
                                                     XYZZ<typename HotField<typename G::F>::type>* __restrict__ partials, uint32_t ZL_CHUNK,
@@ -1007,8 +1049,10 @@ __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, uint32_t E, cons
     for (uint32_t e = start; e < end; e++) {
         while (e == b_end) {  // lane crosses into the next bucket (empty buckets: zero-length, skipped here)
             if (b_end > b_start) {
-                if (b_start >= start) bucket_sums[b] = acc;  // bucket lies inside this chunk (b_end <= e < end)
-                else partials[(size_t)2 * t] = acc;          // head bucket started in an earlier chunk
+                if (!QUAD || sub == 0) {
+                    if (b_start >= start) bucket_sums[b] = acc;  // bucket lies inside this chunk (b_end <= e < end)
+                    else partials[(size_t)2 * t] = acc;          // head bucket started in an earlier chunk
+                }
                 acc = XYZZ<F>::inf();
             }
             b++;
@@ -1018,10 +1062,14 @@ __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, uint32_t E, cons
         const uint32_t ent = entries[e];
         const uint32_t idx = ent & 0x7fffffffu;
         const Affine<F> P = (G::GLV && idx >= n_real ? phib : bases)[idx];
-        if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+        if (!P.is_inf()) {
+            if constexpr (QUAD) zl::add_mixed_quad(acc, P.x, P.y, (ent >> 31) != 0, sub);
+            else zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+        }
     }
     // last segment [max(b_start,start), end) of bucket b
     const bool complete = (b_start >= start) && (b_end <= end);
+    if (QUAD && sub != 0) return;
     if (complete) bucket_sums[b] = acc;
     else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
 }
@@ -1034,9 +1082,23 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
     using F = typename HotField<typename G::F>::type;
     static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
     // GLV: virtual point n_real + i = phi(P_i); else n_real = 2^32 - 1 (never selected)
-    zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+    zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
                            reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
                            reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+}
+// The same chunks with FOUR lanes per chunk (zl_quad.h): for lists that do not fill the machine (small MSMs), where the time of the launch is
+// the latency of one lane's chain of mixed additions -- 4 product slots per addition instead of 10.5.
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate_quad(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+    using F = typename HotField<typename G::F>::type;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    zl_accumulate_chunk<G, true>(gt >> 2, (int)(gt & 3u), offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+                                 reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
+                                 reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
 }
 // The same chunks on a grid that does NOT fill the register file (pipelined batches): k_msm_accumulate at three waves per SIMD holds 498 of
 // the 512 registers of every SIMD for as long as it runs, so the sort of the next MSM and the tail of the previous one only get onto the
@@ -1055,7 +1117,7 @@ __global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accu
     const uint32_t E = offsets[NB];
     // lanes of one wave take consecutive chunks (neighbouring entries), the grid strides over the list
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += gridDim.x * blockDim.x)
-        zl_accumulate_chunk<G>(t, E, entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_), reinterpret_cast<XYZZ<F>*>(bucket_sums_),
+        zl_accumulate_chunk<G>(t, 0, E, entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_), reinterpret_cast<XYZZ<F>*>(bucket_sums_),
                                reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK, reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
 }
 
@@ -1068,7 +1130,7 @@ template <class F> using TailF = typename HotField<F>::type;
 template <class F> using TailF = F;
 #endif
 // one lane per bucket: empty -> infinity; cut into <= ZL_BIG_SPAN chunks -> fold partials; else defer to a block
-template <class G>
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
                                                    const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
@@ -1077,20 +1139,23 @@ __global__ void __launch_bounds__(64) k_msm_merge(const uint32_t* __restrict__ o
     using F = TailF<typename G::F>;
     XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
     const XYZZ<F>* __restrict__ partials = reinterpret_cast<const XYZZ<F>*>(partials_);
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per bucket (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
     if (b >= NB) return;
     const uint32_t s = offsets[b], e = offsets[b + 1];
-    if (s == e) { bucket_sums[b] = XYZZ<F>::inf(); return; }
+    if (s == e) { if (sub == 0) bucket_sums[b] = XYZZ<F>::inf(); return; }
     const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
     if (t0 == t1) return;  // written directly by msm_accumulate
-    if (t1 - t0 + 1 > ZL_GIANT_SPAN) { giant_list[atomicAdd(giant_count, 1u)] = b; return; }
-    if (t1 - t0 + 1 > big_span) { big_list[atomicAdd(big_count, 1u)] = b; return; }
+    if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (sub == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
+    if (t1 - t0 + 1 > big_span) { if (sub == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t t = t0; t <= t1; t++) {
         const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
-        zl::add_full(acc, p);
+        if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
+        else zl::add_full(acc, p);
     }
-    bucket_sums[b] = acc;
+    if (sub == 0) bucket_sums[b] = acc;
 }
 // lanes of the block-tree kernels: 256 for G1, 128 for G2 (384-B points: a 256-lane block is capped at 256 VGPRs and spills)
 template <class G>
@@ -1186,6 +1251,10 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
     const uint32_t cnt = *ones_count;
+    if (cnt == 0) {  // the usual case for uniform scalars: no block tree over 128 / 256 points at infinity (15 us of the tail of a small G2 MSM)
+        if (threadIdx.x == 0) out[blockIdx.x] = XYZZ<F>::inf();
+        return;
+    }
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
         const uint32_t idx = ones_list[j];
@@ -1210,7 +1279,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __
 //             S_(w,b), position c w receives A_w (one extra addition per bit position, no extra doublings).
 // flat_set: the spread top window (k_msm_recode_wide): its buckets are weighted by their low spread_t bits only; level 0 is weightless
 // for it when spread_t == 0, and the host skips its S_b from bit spread_t on.
-template <class G>
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets_, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
                                                            XYZZ<typename G::F>* __restrict__ out_ /* [set][block][2]: T, A */) {
@@ -1218,7 +1287,9 @@ __global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_redu
     using X = XYZZ<TailF<typename G::F>>;
     const X* __restrict__ buckets = reinterpret_cast<const X*>(buckets_);
     X* __restrict__ out = reinterpret_cast<X*>(out_);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per block of buckets (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
     if (t >= total_blocks) return;
     const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
     const uint32_t i0 = blk * group, i1 = min(H, i0 + group);
@@ -1227,45 +1298,58 @@ __global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_redu
     X run = X::inf(), wsum = X::inf();
     for (uint32_t i = i1; i > i0; i--) {
         const X B = buckets[base + (i - 1)];
-        zl::add_full(run, B);
-        if (!flat) zl::add_full(wsum, run);
+        if constexpr (QUAD) {
+            zl::add_full_quad(run, B, sub);
+            if (!flat) zl::add_full_quad(wsum, run, sub);
+        } else {
+            zl::add_full(run, B);
+            if (!flat) zl::add_full(wsum, run);
+        }
     }
+    if (sub != 0) return;
     out[(size_t)2 * t] = run;
     out[(size_t)2 * t + 1] = flat ? run : wsum;
 }
 // one tree level: nodes of `level` (1-based) from the nodes of level - 1.  Node layout: [set][node][channel], ch_in = level + 1 channels
 // in (T, A, S_0 .. S_(level-2)), ch_out = level + 2 out.  One lane per (set, node, out channel).
-template <class G>
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F>* __restrict__ in_, XYZZ<typename G::F>* __restrict__ out_, uint32_t level,
                                                          uint32_t nodes_out_per_set, uint32_t total_lanes) {
     ZL_SIDE_PRIO();
     using X = XYZZ<TailF<typename G::F>>;
     const X* __restrict__ in = reinterpret_cast<const X*>(in_);
     X* __restrict__ out = reinterpret_cast<X*>(out_);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per (set, node, channel) (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
     if (t >= total_lanes) return;
     const uint32_t ch_out = level + 2, ch_in = level + 1;
     const uint32_t ch = t % ch_out, node = (t / ch_out) % nodes_out_per_set, set = t / (ch_out * nodes_out_per_set);
     const size_t left = ((size_t)set * nodes_out_per_set * 2 + (size_t)2 * node) * ch_in, right = left + ch_in;
     if (ch == ch_out - 1) {  // the new top channel: blocks of the right child have this bit set
-        out[t] = in[right];
+        if (sub == 0) out[t] = in[right];
         return;
     }
     X acc = in[left + ch];
     const X o = in[right + ch];
-    zl::add_full(acc, o);
-    out[t] = acc;
+    if constexpr (QUAD) zl::add_full_quad(acc, o, sub);
+    else zl::add_full(acc, o);
+    if (sub == 0) out[t] = acc;
 }
 // tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
 // set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
 // two-stage sum for sets with many segments.
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
-                                                         uint32_t parts, XYZZ<typename G::F>* __restrict__ out) {
+                                                         uint32_t parts, XYZZ<typename G::F>* __restrict__ out, const uint32_t* __restrict__ zero_if_zero) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    if (zero_if_zero && *zero_if_zero == 0) {  // nothing was listed: every part is the point at infinity
+        if (threadIdx.x == 0) out[blockIdx.x] = XYZZ<F>::inf();
+        return;
+    }
     const uint32_t set = blockIdx.x / parts, part = blockIdx.x % parts;
     const uint32_t lo = part * count, hi = min(set_stride, lo + count);
     XYZZ<F> acc = XYZZ<F>::inf();
@@ -1506,6 +1590,7 @@ struct MsmJob {
     int spread_t = -1;  // >= 0: the top window's entries are spread over its bucket set, weights = low spread_t bits + 1
     bool wide = false;  // three-level sort over (window, bucket) ids of up to 23 bits: table mode, or plain windows wider than 16 bits
     bool glv = false;   // the job runs on 2 n_real half-scalars of 127 bits over the points P_i and phi(P_i) (k_glv_split / k_glv_phi)
+    bool phi_cached = false;  // d_phi is the handle's own copy (zl_bases::d_endo)
     bool phi_owner = false;  // this job computes the phi image of its bases in its sort phase (else it borrows d_phi from an earlier job of the call)
     int sc_bits = 0, phi_slot = -1, endo_k = 1;  // endo_k: half-scalars per scalar (2: GLV on G1, 4: GLS on BLS12-381 G2)
     int slotA = 5, slotB = 6;  // scratch slots of the sort temporaries (shared by the jobs of a pipelined batch; per buffer set when small jobs run side by side)
@@ -1668,6 +1753,31 @@ struct MsmJob {
         d_sets = d_stage1 + lvl1_elems;    // the root channels of every set, then the sum of the scalar-1 bases
         d_ones_parts = d_sets + root_elems + 1;
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
+        if (glv) {
+            // The images depend on the bases only: kept with the handle (one range per handle; another range of the same handle falls back to
+            // the per-call scratch copy below).  k_gls_psi is 50 us of latency in front of the G2 MSM of every small proof, k_glv_phi 12-100 us.
+            const size_t endo_bytes = (size_t)(endo_k - 1) * n_real * sizeof(Affine<F>);
+            const zl_bases& bs = *bsp;
+            if (!bs.d_endo && endo_bytes <= ((size_t)zl_tune("ZL_TUNE_ENDO_CACHE_MB", 512) << 20)) {
+                void* q = nullptr;
+                if (hipMalloc(&q, endo_bytes) == hipSuccess) {
+                    if constexpr (G::GLV && G::ENDO_K == 2)
+                        hipLaunchKernelGGL((k_glv_phi<G>), dim3((uint32_t)((n_real + 127) / 128)), dim3(128), 0, ctx->stream, d_bases, (uint32_t)n_real, reinterpret_cast<Affine<F>*>(q));
+                    else if constexpr (G::GLV && G::ENDO_K == 4)
+                        hipLaunchKernelGGL((k_gls_psi<G>), dim3((uint32_t)((n_real + 63) / 64)), dim3(64), 0, ctx->stream, d_bases, (uint32_t)n_real, reinterpret_cast<Affine<F>*>(q));
+                    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(q); return ZL_EHIP; }
+                    bs.d_endo = q;
+                    bs.endo_first = first;
+                    bs.endo_n = n_real;
+                    bs.endo_k = endo_k;
+                }
+            }
+            if (bs.d_endo && bs.endo_first == first && bs.endo_n == n_real && bs.endo_k == endo_k) {
+                d_phi = reinterpret_cast<const Affine<F>*>(bs.d_endo);
+                phi_owner = false;
+                phi_cached = true;
+            }
+        }
         if (glv && phi_owner) {
             if ((rc = zl_scratch_get(ctx, phi_slot, (size_t)(endo_k - 1) * n_real * sizeof(Affine<F>), &p))) return rc;
             d_phi = reinterpret_cast<const Affine<F>*>(p);
@@ -1818,10 +1928,14 @@ struct MsmJob {
             uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
             hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
             hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
+            if (NB <= 16384 && nslices <= 64) {
+                hipLaunchKernelGGL(k_msm_prefix_small, dim3(1), dim3(1024), 0, st, d_slice_counts, NB, nslices, d_offsets, d_cursor, (const uint32_t*)d_bad_scalar);
+            } else {
             hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
             hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
             hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+            }
             // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
             uint32_t ranges = 1;
             while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
@@ -1845,6 +1959,9 @@ struct MsmJob {
         if (wg_per_cu > 0 && ctx->cu_count > 0 && nchunks >= 8 * (uint64_t)lanes_persist)  // >= 8 chunks per lane: the last, partial round costs little
             hipLaunchKernelGGL((k_msm_accumulate_persist<G>), dim3((uint32_t)wg_per_cu * (uint32_t)ctx->cu_count), dim3(ZL_ACC_PERSIST_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases,
                                d_buckets, d_partials, ZL_CHUNK, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, nchunks);
+        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // four lanes per chunk while that still fits the machine at three waves per SIMD
+            hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                            glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
@@ -1852,6 +1969,11 @@ struct MsmJob {
         return ZL_OK;
     }
     int tail(zl_ctx* ctx, hipStream_t st) {
+        // four lanes per group operation (zl_quad.h) in every tail launch that does not fill the machine
+        const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
+        if (NB <= quad_max)
+            hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
+        else
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK);
@@ -1862,15 +1984,21 @@ struct MsmJob {
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
                            pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
-                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set);
+                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set, (const uint32_t*)d_ones_count);
         {
             const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
             const uint32_t leaves = SETS * red_blocks;
             X* cur = red_levels == 0 ? d_sets : d_segs;
+            if (leaves <= quad_max)
+                hipLaunchKernelGGL((k_msm_reduce_level0<G, true>), dim3((4 * leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
+            else
             hipLaunchKernelGGL((k_msm_reduce_level0<G>), dim3((leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
             for (uint32_t lv = 1; lv <= red_levels; lv++) {
                 const uint32_t nodes = red_blocks >> lv, lanes = SETS * nodes * (lv + 2);
                 X* nxt = lv == red_levels ? d_sets : ((lv & 1) ? d_stage1 : d_segs);
+                if (lanes <= quad_max)
+                    hipLaunchKernelGGL((k_msm_reduce_tree<G, true>), dim3((4 * lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
+                else
                 hipLaunchKernelGGL((k_msm_reduce_tree<G>), dim3((lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
                 cur = nxt;
             }
@@ -2057,7 +2185,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     for (int pass = 0; pass < 2; pass++) {
         for (size_t i = 0; i < count; i++) {
             if ((rc = jobs[i].alloc(ctx, (int)(i % NS), side))) return rc;
-            if (one_key && !side && i > 0 && jobs[i].glv) jobs[i].d_phi = jobs[0].d_phi;
+            if (one_key && !side && i > 0 && jobs[i].glv && !jobs[i].phi_cached) jobs[i].d_phi = jobs[0].d_phi;
         }
     }
     const size_t per = sizeof(X) * (max_sets + 1) + 16;
@@ -2110,39 +2238,64 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
     if (side)
         for (size_t k = 0; k < NS && he == hipSuccess; k++) he = hipStreamWaitEvent(ctx->stream_lane[k], ev_begin, 0);
-    hipStream_t last_tail = nullptr;
     static const bool jtrace = getenv("ZL_HOST_TRACE") != nullptr;
     const auto jt0 = std::chrono::steady_clock::now();
-    for (size_t i = 0; i < count && he == hipSuccess && rc == ZL_OK; i++) {
-        // pipelined: three phases on three streams; side by side: the whole job on the stream of its buffer set (the waits below are then
-        // between operations of one stream, i.e. no-ops)
+    // issue of one job: sort | accumulate | tail with the events between them.  pipelined: three phases on three streams; side by side: the
+    // whole job on the stream of its buffer set (the waits are then between operations of one stream, i.e. no-ops)
+    auto issue_job = [&](size_t i) -> int {
         hipStream_t js_sort = side ? ctx->stream_lane[i % NS] : s_sort, js_acc = side ? ctx->stream_lane[i % NS] : s_acc;
         hipStream_t s_tail = side ? ctx->stream_lane[i % NS] : s_tails[i % 3];
-        if (i >= NS) he = hipStreamWaitEvent(js_sort, ev_tail[i - NS], 0);  // buffer set i % NS is free again
+        hipError_t e = hipSuccess;
+        if (i >= NS) e = hipStreamWaitEvent(js_sort, ev_tail[i - NS], 0);  // buffer set i % NS is free again
         if (recorded && specs[i].wait) {
             while (recorded->load(std::memory_order_acquire) >= 0 && recorded->load(std::memory_order_acquire) <= (int)i) std::this_thread::yield();
-            if (recorded->load() < 0) { rc = ZL_EHIP; break; }
+            if (recorded->load() < 0) return ZL_EHIP;
         }
-        if (he == hipSuccess && specs[i].wait) he = hipStreamWaitEvent(js_sort, specs[i].wait, 0);
-        if (he != hipSuccess) break;
-        if ((rc = jobs[i].sort(ctx, js_sort))) break;
-        he = hipEventRecord(ev_sorted[i], js_sort);
-        if (he == hipSuccess) he = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
-        if (he == hipSuccess && ctx->timing_on) he = hipEventRecord(ev_acc0[i], js_acc);
-        if (he != hipSuccess) break;
-        if ((rc = jobs[i].accumulate(ctx, js_acc, acc_wg_per_cu))) break;
-        he = hipEventRecord(ev_acc[i], js_acc);
-        if (he == hipSuccess) he = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
-        if (he != hipSuccess) break;
-        if ((rc = jobs[i].tail(ctx, s_tail))) break;
-        he = hipEventRecord(ev_tail[i], s_tail);
-        last_tail = s_tail;
+        if (e == hipSuccess && specs[i].wait) e = hipStreamWaitEvent(js_sort, specs[i].wait, 0);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+        int r;
+        if ((r = jobs[i].sort(ctx, js_sort))) return r;
+        e = hipEventRecord(ev_sorted[i], js_sort);
+        if (e == hipSuccess) e = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
+        if (e == hipSuccess && ctx->timing_on) e = hipEventRecord(ev_acc0[i], js_acc);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+        if ((r = jobs[i].accumulate(ctx, js_acc, acc_wg_per_cu))) return r;
+        e = hipEventRecord(ev_acc[i], js_acc);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+        if ((r = jobs[i].tail(ctx, s_tail))) return r;
+        e = hipEventRecord(ev_tail[i], s_tail);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
         if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu (n=%zu c=%d%s) issued at %.1f us\n", i, jobs[i].n_real, jobs[i].c, side ? ", side by side" : "",
                             (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
+        return ZL_OK;
+    };
+    // issued[i]: 0 not yet, 1 issued, < 0 failed (-code).  Side by side, every lane stream CAN be fed by its own persistent host thread
+    // (ZL_TUNE_LANE_THREADS=1): the ~25 launches of a small job are ~80 us of host time, four jobs 0.3 ms.  Measured (k = 1 proof, 40 runs): all
+    // four jobs then reach the device within 0.15 ms, but finish together and later than the staggered jobs of a single issuing thread
+    // (median 1.40 against 1.16 ms per proof at 8 hardware queues, 1.52 against 1.35 at 4) -- off by default.
+    std::unique_ptr<std::atomic<int>[]> issued(new std::atomic<int>[count]);
+    for (size_t i = 0; i < count; i++) issued[i].store(0);
+    const bool lanes_threaded = side && count > 1 && he == hipSuccess && zl_tune("ZL_TUNE_LANE_THREADS", 0) != 0;
+    if (lanes_threaded) {
+        for (size_t k = 0; k < NS; k++)
+            zl_ctx_worker(ctx, 2 + (int)k).run([&, k]() {
+                int r = hipSetDevice(ctx->device) == hipSuccess ? ZL_OK : ZL_EHIP;
+                for (size_t i = k; i < count; i += NS) {
+                    if (r == ZL_OK) r = issue_job(i);
+                    issued[i].store(r == ZL_OK ? 1 : -r, std::memory_order_release);
+                }
+            });
+    } else {
+        for (size_t i = 0; i < count; i++) {
+            if (he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
+            issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
+        }
     }
-    // ev_end: after the last tail of every stream that ran tails
-    for (size_t back = 1; back < NS && back < count && he == hipSuccess && rc == ZL_OK; back++) he = hipStreamWaitEvent(last_tail, ev_tail[count - 1 - back], 0);
-    if (he == hipSuccess && rc == ZL_OK) he = hipEventRecord(ev_end, last_tail);
+    auto lanes_join = [&]() {
+        if (lanes_threaded)
+            for (size_t k = 0; k < NS; k++) zl_ctx_worker(ctx, 2 + (int)k).wait();
+    };
     // Host tails: this thread waits for the jobs' tail events in order (a job's root channels are then in pinned memory) and hands every
     // finished job to a helper thread that runs its window Horner and delivers the result -- while the device works on the later jobs.  Small
     // jobs, which the device finishes faster than the host, get their Horners side by side; `on_done` is delivered in job order.  (The helpers
@@ -2150,6 +2303,18 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     std::atomic<int> frc{ZL_OK};
     std::atomic<size_t> delivered{0};
     std::vector<std::thread> finishers;
+    // every job issued (the lanes issue side by side: about the time of one job), then ev_end behind the last tail of every stream that ran tails
+    for (size_t i = 0; i < count; i++) {
+        int st;
+        while ((st = issued[i].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        if (st < 0 && rc == ZL_OK) rc = -st;
+    }
+    lanes_join();
+    if (he == hipSuccess && rc == ZL_OK) {
+        hipStream_t last_tail = side ? ctx->stream_lane[(count - 1) % NS] : s_tails[(count - 1) % 3];
+        for (size_t back = 1; back < NS && back < count && he == hipSuccess; back++) he = hipStreamWaitEvent(last_tail, ev_tail[count - 1 - back], 0);
+        if (he == hipSuccess) he = hipEventRecord(ev_end, last_tail);
+    }
     if (he == hipSuccess && rc == ZL_OK) {
         for (size_t i = 0; i < count; i++) {
             bool ok = frc.load() == ZL_OK;
@@ -2163,6 +2328,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
                     memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
                     memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
                 }
+                if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu Horner done at %.1f us\n", i,
+                                    (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
                 while (delivered.load(std::memory_order_acquire) != i) std::this_thread::yield();
                 if (ok && on_done && frc.load() == ZL_OK) (*on_done)(i);
                 delivered.store(i + 1, std::memory_order_release);

@@ -81,3 +81,56 @@ private:
     bool stop_ = false;
 };
 zl_pool& zl_pool_get();
+
+// One persistent thread with a one-slot mailbox: for host work that makes HIP calls beside the caller (a fresh thread's first HIP call costs
+// ~0.1 ms of per-thread runtime setup -- once per worker here instead of once per proof) and for issuing the launches of independent small
+// jobs side by side (a 237-point MSM is ~25 launches = ~80 us of host time; four of them one after the other were the longest item of a
+// small proof).  run() returns at once (after the previous task of this worker has finished); wait() blocks until the worker is idle.
+class zl_worker {
+public:
+    zl_worker() : th_([this]() { loop(); }) {}
+    ~zl_worker() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void run(std::function<void()> f) {
+        std::unique_lock<std::mutex> lk(m_);
+        idle_.wait(lk, [&]() { return !busy_; });
+        task_ = std::move(f);
+        busy_ = true;
+        lk.unlock();
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        idle_.wait(lk, [&]() { return !busy_; });
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return stop_ || busy_; });
+                if (stop_ && !busy_) return;
+                f = std::move(task_);
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                busy_ = false;
+            }
+            idle_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, idle_;
+    std::function<void()> task_;
+    bool busy_ = false, stop_ = false;
+    std::thread th_;  // last: the thread starts with every other member constructed
+};

@@ -48,7 +48,7 @@ if "g16" in what:
         for _ in range(3):
             keys.prove(seed=3)
         ts = []
-        for _ in range(10):
+        for _ in range(int(os.environ.get('ITERS', '10'))):
             t0 = time.perf_counter()
             keys.prove(seed=3)
             ts.append(time.perf_counter() - t0)
