@@ -47,7 +47,6 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call of the process (see openzl_amd/__init__.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

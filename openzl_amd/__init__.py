@@ -4,12 +4,6 @@ The product is the C-ABI shared library `libzl_backend.so` (include/zl_backend.h
 sources (csrc/), the build driver (build.py) and a thin ctypes binding (backend.py) used by the tests and the
 bench; it never falls back to a CPU implementation: without the HIP library or without a GPU it raises.
 """
-import os as _os
-
-# More hardware queues than the HIP runtime's default of 4: the library's concurrent streams (pipeline phases, side-by-side small jobs, G2 MSM,
-# witness map) otherwise share queues and serialise (zl_ctx_create sets the same default; here it also precedes torch's first HIP call).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from .backend import Backend, MultiBackend, BackendError, load_library, CURVES, ZL_BLS12_381, ZL_BN254, ZL_G1, ZL_G2  # noqa: F401
 from .backend import ZL_MONT, ZL_COSET, ZL_INVERSE, ZL_CHECK  # noqa: F401
 from .backend import Circuit, Groth16Keys, poseidon_permute, pairing  # noqa: F401

@@ -32,11 +32,10 @@ const char* zl_strerror(int code) {
 int zl_ctx_create(zl_ctx** out, int device_id) {
     if (!out) return ZL_EINVAL;
     *out = nullptr;
-    // The library runs up to ~12 streams at once (three pipeline phases, four side-by-side lanes, the G2 MSM, the witness map, tails); the HIP
-    // runtime multiplexes them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two chains of small dependent kernels that share a
-    // queue run one after the other.  8 queues: a 235-constraint proof 1.35 -> 1.16 ms (median), nothing else moves.  Only effective when this is
-    // the process's first HIP call (the runtime reads it once); a caller's own setting wins.
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (The library runs up to ~12 streams at once -- pipeline phases, side-by-side lanes, G2 MSM, witness map, tails -- which the HIP runtime
+    // multiplexes onto GPU_MAX_HW_QUEUES hardware queues, default 4.  Measured with 8: a 235-constraint proof 1.26 -> 1.11 ms (median), the
+    // 958 465-constraint proof 19.5 -> 20.25 ms (the G2 accumulation, one 416-register wave per SIMD, then runs beside the G1 accumulation instead
+    // of between two of them and both lose occupancy).  The default stays; a deployment of small circuits can set the variable itself.)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZL_ENODEV;
     if (device_id < 0 || device_id >= count) return ZL_EINVAL;

@@ -2211,6 +2211,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // beside the sort and to ~50 ms beside the level-0 / tree kernels (two instruction streams of 40-60 KB each share one 64-KB instruction
     // cache per CU pair, and the tail kernels' own additions take 6-10 ms instead of 1.6): 49.9 ms per MSM against 37.6.  ZL_TUNE_ACC_WG_PER_CU=2 enables it.
     const int acc_wg_per_cu = sizeof(X) > 256 ? 0 : zl_tune("ZL_TUNE_ACC_WG_PER_CU", 0);
+    // (Measured and dropped: making the accumulation of job i+1 wait for the merge kernels / level 0 of job i, so that two field-arithmetic
+    // kernels never share the machine -- 958 465-constraint proof 19.2-19.4 ms with or without, 2^20 batches 3.65 = 3.65 ms per MSM.)
     std::vector<hipEvent_t> ev_sorted(count), ev_acc(count), ev_tail(count), ev_acc0(ctx->timing_on ? count : 0);
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     auto cleanup = [&]() {
@@ -2273,7 +2275,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // issued[i]: 0 not yet, 1 issued, < 0 failed (-code).  Side by side, every lane stream CAN be fed by its own persistent host thread
     // (ZL_TUNE_LANE_THREADS=1): the ~25 launches of a small job are ~80 us of host time, four jobs 0.3 ms.  Measured (k = 1 proof, 40 runs): all
     // four jobs then reach the device within 0.15 ms, but finish together and later than the staggered jobs of a single issuing thread
-    // (median 1.40 against 1.16 ms per proof at 8 hardware queues, 1.52 against 1.35 at 4) -- off by default.
+    // (median 1.40 against 1.16 ms per proof at GPU_MAX_HW_QUEUES=8, 1.52 against 1.35 at the runtime's default of 4) -- off by default.  (Lanes in
+    // different stream-priority classes, i.e. different queue pools, measured no better either.)
     std::unique_ptr<std::atomic<int>[]> issued(new std::atomic<int>[count]);
     for (size_t i = 0; i < count; i++) issued[i].store(0);
     const bool lanes_threaded = side && count > 1 && he == hipSuccess && zl_tune("ZL_TUNE_LANE_THREADS", 0) != 0;

@@ -3,7 +3,6 @@ import sys
 
 import pytest
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as openzl_amd/__init__.py, but before anything can touch HIP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):

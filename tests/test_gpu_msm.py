@@ -443,3 +443,28 @@ def test_msm_glv_edge_scalars(backend):
     finally:
         backend.set_msm_window(0)
         backend.bases_free(h)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_msm_ranges_of_one_handle_and_repeated_points(backend, curve):
+    """Small MSMs over different ranges of ONE handle, interleaved: the endomorphism images of the bases are kept with the handle for the first
+    range used (zl_bases::d_endo, csrc/zl_msm.hip MsmJob::alloc) and every other range must fall back to its per-call copy.  The bases repeat
+    (P, P, -P, ...), so the four-lane additions of the small path (csrc/zl_quad.h: accumulate, merge, level 0, tree) meet P + P, P - P and
+    infinity inside buckets; all against the oracle."""
+    n = 1500
+    k, B = _bases(curve, n, 901)
+    B = B.copy()
+    B[10:40] = B[9]            # a run of equal points
+    neg = ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs([(curve.fr.p - int(x)) % curve.fr.p for x in ol.limbs_to_ints(k[50:60])], 4))
+    B[60:70] = neg             # B[60 + j] = -B[50 + j]
+    S = ol.random_scalars(curve, n, 902)
+    S[10:40] = S[9]            # equal scalars on equal points: doublings inside one bucket
+    S[60:70] = S[50:60]        # s P + s (-P): cancellations inside one bucket
+    h = backend.bases_upload(curve.cid, B)
+    try:
+        for first, cnt in ((0, n), (1, n - 1), (0, n), (7, 700), (1, n - 1), (0, 64), (0, n)):
+            got, inf = backend.msm(h, S[first:first + cnt], first=first)
+            exp, einf = ol.oracle_msm_g1(curve, B[first:first + cnt], S[first:first + cnt], algo=0, threads=4)
+            assert inf == einf and (got == exp).all(), (first, cnt)
+    finally:
+        backend.bases_free(h)

@@ -115,3 +115,25 @@ def test_msm_g2_gls_edge_scalars(backend):
     finally:
         backend.set_msm_window(0)
         backend.bases_free(h)
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_msm_g2_ranges_of_one_handle(backend, curve):
+    """Interleaved ranges of one G2 handle: psi / psi^2 / psi^3 images are kept with the handle for the first range used (BLS12-381: GLS) and
+    other ranges take the per-call copy; repeated and negated points inside buckets go through the four-lane additions (csrc/zl_quad.h) on Fq2."""
+    n = 600
+    ks = ol.limbs_to_ints(ol.random_scalars(curve, n, 911))
+    ks[20:30] = [ks[19]] * 10
+    ks[40:45] = [(curve.fr.p - x) % curve.fr.p for x in ks[30:35]]
+    B = gu.g2_mul_gen(curve, ks)
+    S = ol.random_scalars(curve, n, 912)
+    S[20:30] = S[19]
+    S[40:45] = S[30:35]
+    h = backend.bases_upload(curve.cid, B, group=ZL_G2)
+    try:
+        for first, cnt in ((1, n - 1), (0, n), (1, n - 1), (5, 300), (0, n)):
+            got, inf = backend.msm(h, S[first:first + cnt], first=first)
+            exp, einf = _oracle_msm_g2(curve, B[first:first + cnt], S[first:first + cnt])
+            assert inf == einf and (got == exp).all(), (first, cnt)
+    finally:
+        backend.bases_free(h)
