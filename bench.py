@@ -90,8 +90,8 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
     box, on the SAME bases and scalars the GPU was timed on (bases downloaded from the device, canonical affine).  Checker code used as a
     reported baseline only -- never on the product path.  Three configurations:
       all-core (chunk x window) grid (value): the FULL input is cut into chunks so that chunks x windows ~ threads, every (chunk, window)
-          pair is one task of ark's window routine, partial sums are added -- the strongest CPU arrangement of the same algorithm
-          (not an arkworks configuration); its result must equal the GPU's full-size result bit for bit;
+          pair is one task of ark's window routine, partial sums are added -- uses every core on the same algorithm (not an arkworks
+          configuration; NOT necessarily the fastest: on a many-core box the window-parallel sample below can beat it, `value` is the best of the two); its result must equal the GPU's full-size result bit for bit;
       window-parallel: what arkworks' `parallel` feature does (one thread per window), on a 2^22 sample with the window width ark's rule
           gives the full input;
       single thread: the reference's actual configuration (no `parallel` feature), on a 2^18 sample."""
