@@ -184,9 +184,30 @@ static __global__ void __launch_bounds__(1024) k_msm_hist_lds(const uint16_t* __
     __syncthreads();
     const uint32_t lo = slice * per_slice, hi = min(n, lo + per_slice);
     const uint16_t* dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t code = dw[i];
-        if (code != 0xFFFFu) atomicAdd(&hist[code & 0x7FFFu], 1u);
+    {
+        // 16-byte loads over the aligned middle of the slice (8 digits per lane and load), scalar loads at its ragged ends
+        const size_t row0 = (size_t)w * n;
+        uint32_t a = lo, b = hi;
+        while (a < b && ((row0 + a) & 7)) a++;
+        b = a + ((b - a) & ~7u);
+        for (uint32_t i = lo + threadIdx.x; i < a; i += blockDim.x) {
+            const uint32_t code = dw[i];
+            if (code != 0xFFFFu) atomicAdd(&hist[code & 0x7FFFu], 1u);
+        }
+        const uint4* dv = reinterpret_cast<const uint4*>(dw + a);
+        for (uint32_t j = threadIdx.x; j < (b - a) / 8; j += blockDim.x) {
+            const uint4 v = dv[j];
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t code = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                if (code != 0xFFFFu) atomicAdd(&hist[code & 0x7FFFu], 1u);
+            }
+        }
+        for (uint32_t i = b + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint32_t code = dw[i];
+            if (code != 0xFFFFu) atomicAdd(&hist[code & 0x7FFFu], 1u);
+        }
     }
     __syncthreads();
     uint32_t* out = counts + (size_t)slice * NB + (size_t)w * H;
@@ -209,40 +230,72 @@ static __global__ void __launch_bounds__(256) k_msm_slice_prefix(uint32_t* __res
 // scatters the matching entries through LDS cursors.  One block writes one contiguous, L2-resident slice of the entry list,
 // so partial-sector writes merge in L2 (the slice-owned variant measured 8.5 GB of HBM writes for 1 GB of entries).
 static __global__ void __launch_bounds__(1024) k_msm_scatter_range(const uint16_t* __restrict__ digits, uint32_t n, uint32_t H, uint32_t RB,
-                                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries) {
+                                                                     const uint32_t* __restrict__ offsets, uint32_t* __restrict__ entries,
+                                                                     const uint32_t* __restrict__ slice_prefix, uint32_t NB, uint32_t nslices, uint32_t per_slice,
+                                                                     uint32_t parts, uint32_t W) {
     ZL_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t range = blockIdx.x, w = blockIdx.y;
+    // XCD-aware order (workgroup L runs on XCD L % 8, each XCD has its own L2): all blocks that stream the digit row of one window sit on ONE
+    // XCD, so the row crosses the fabric once instead of once per XCD that hosts one of its `ranges x parts` readers
+    const uint32_t ranges = gridDim.y, xcd = blockIdx.x & 7u, jj = blockIdx.x >> 3;
+    const uint32_t w = xcd + 8u * jj, range = blockIdx.y, part = blockIdx.z;
+    if (w >= W) return;
+    (void)ranges;
     const uint32_t b0 = range * RB;
+    // part p of the digit row = slices [p nslices / parts, (p + 1) nslices / parts) of k_msm_hist_lds: its cursors start behind the entries of
+    // the earlier slices (slice_prefix[slice][bucket] = exclusive prefix over slices, k_msm_slice_prefix / k_msm_prefix_small).
+    const uint32_t s0 = (uint32_t)((uint64_t)part * nslices / parts), s1 = (uint32_t)((uint64_t)(part + 1) * nslices / parts);
+    const uint32_t lo = min(n, s0 * per_slice), hi = part + 1 == parts ? n : min(n, s1 * per_slice);
     const uint32_t* os = offsets + (size_t)w * H + b0;
-    for (uint32_t b = threadIdx.x; b < RB; b += blockDim.x) cur[b] = (b0 + b < H) ? os[b] : 0;
+    const uint32_t* sp = slice_prefix + (size_t)s0 * NB + (size_t)w * H + b0;
+    for (uint32_t b = threadIdx.x; b < RB; b += blockDim.x) cur[b] = (b0 + b < H) ? os[b] + (parts > 1 ? sp[b] : 0u) : 0;
     __syncthreads();
     const uint16_t* dw = digits + (size_t)w * n;
-    // 16-byte loads: 8 digits per lane per iteration (the window's digit row is 16-B aligned when n % 8 == 0)
-    const uint32_t n8 = ((((size_t)w * n) & 7) == 0) ? (n & ~7u) : 0;
-    const uint4* dv = reinterpret_cast<const uint4*>(dw);
-    for (uint32_t i8 = threadIdx.x; i8 < n8 / 8; i8 += blockDim.x) {
-        const uint4 v = dv[i8];
-        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t code = (words[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-            const uint32_t bucket = code & 0x7FFFu;
-            if (code != 0xFFFFu && bucket - b0 < RB) {
-                const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
-                entries[pos] = (i8 * 8 + k) | ((code >> 15) << 31);
-            }
-        }
-    }
-    for (uint32_t i = n8 + threadIdx.x; i < n; i += blockDim.x) {
+    auto take1 = [&](uint32_t i) {
         const uint32_t code = dw[i];
         const uint32_t bucket = code & 0x7FFFu;
         if (code != 0xFFFFu && bucket - b0 < RB) {
             const uint32_t pos = atomicAdd(&cur[bucket - b0], 1u);
             entries[pos] = i | ((code >> 15) << 31);
         }
+    };
+    // all eight LDS cursor atomics of a 16-byte load are issued before the first store needs its position
+    // A digit matches this block's bucket range with probability 1 / ranges, so eight predicated (atomic, store) pairs per load would each run
+    // with a few lanes: the hits of a lane's eight digits are collected in a bit mask and the wave loops max-over-lanes(hits) times (~3) instead.
+    auto take8 = [&](const uint4& v, uint32_t i0) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t word = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+            const uint32_t code = (word >> ((k & 1) * 16)) & 0xFFFFu;
+            if (code != 0xFFFFu && (code & 0x7FFFu) - b0 < RB) mask |= 1u << k;
+        }
+        while (mask) {
+            const uint32_t k = (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1u;
+            const uint32_t word = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+            const uint32_t code = (word >> ((k & 1u) * 16u)) & 0xFFFFu;
+            const uint32_t pos = atomicAdd(&cur[(code & 0x7FFFu) - b0], 1u);
+            entries[pos] = (i0 + k) | ((code >> 15) << 31);
+        }
+    };
+    // 16-byte loads (8 digits) over the aligned middle of [lo, hi), scalar loads at its ragged ends
+    const size_t row0 = (size_t)w * n;
+    uint32_t a = lo, e = hi;
+    while (a < e && ((row0 + a) & 7)) a++;
+    e = a + ((e - a) & ~7u);
+    for (uint32_t i = lo + threadIdx.x; i < a; i += blockDim.x) take1(i);
+    const uint4* dv = reinterpret_cast<const uint4*>(dw + a);
+    const uint32_t cnt8 = (e - a) / 8, stride = blockDim.x;
+    uint32_t j = threadIdx.x;
+    for (; j + stride < cnt8; j += 2 * stride) {
+        const uint4 v0 = dv[j], v1 = dv[j + stride];
+        take8(v0, a + j * 8);
+        take8(v1, a + (j + stride) * 8);
     }
+    for (; j < cnt8; j += stride) take8(dv[j], a + j * 8);
+    for (uint32_t i = e + threadIdx.x; i < hi; i += blockDim.x) take1(i);
 }
 
 // ---- wide windows over precomputed multiples (zl_bases_precompute): ONE bucket set of 2^(c-1) buckets, c up to 24 ----------
@@ -1941,7 +1994,11 @@ struct MsmJob {
             while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
             ranges = (uint32_t)std::max(1, zl_tune("ZL_TUNE_RANGES", (int)ranges));
             const uint32_t RB = (H + ranges - 1) / ranges;
-            hipLaunchKernelGGL(k_msm_scatter_range, dim3(ranges, W), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries);
+            // (the digit row of a window can be walked by `parts` blocks, slice-aligned: measured 1 = 2 = 4 = 8 at 2^18 .. 2^21 -- the kernel is bound by
+            // its 4-byte scattered stores, 16.8 M of them in 0.19 ms at 2^20, not by the length of the row, the load latency or the LDS atomics)
+            const uint32_t parts = (uint32_t)std::max(1, std::min<int>((int)nslices, zl_tune("ZL_TUNE_SCATTER_PARTS", 1)));
+            hipLaunchKernelGGL(k_msm_scatter_range, dim3(8 * ((W + 7) / 8), ranges, parts), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries,
+                               (const uint32_t*)d_slice_counts, NB, nslices, per_slice, parts, (uint32_t)W);
         } else {
             // wide windows without a table: histogram / scatter with global atomics
             hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
