@@ -6,7 +6,7 @@ import numpy as np, torch
 from openzl_amd import Backend, ZL_BLS12_381, Circuit, Groth16Keys
 be = Backend(0); be.enable_timing(True)
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cs = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]
+cs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else []
 circ = Circuit(ZL_BLS12_381, k); keys = Groth16Keys(be, circ, seed=1)
 def timeit(tag):
     p0, _, _ = keys.prove(seed=3)
@@ -15,7 +15,7 @@ def timeit(tag):
         torch.cuda.synchronize(); t0 = time.perf_counter(); p, _, _ = keys.prove(seed=3); ts.append(time.perf_counter() - t0)
     print(f"{tag}: prove min {min(ts)*1e3:.2f} med {np.median(ts)*1e3:.2f} ms", flush=True)
     return p
-p_plain = timeit("plain")
+p_plain = timeit("plain")  # "plain" = the keys as Groth16::compile leaves them (window tables for keys above 2^19 points: ZL_TUNE_G1_TABLE_C / ZL_TUNE_G2_TABLE_C)
 for c in cs:
     t0 = time.perf_counter()
     for name in ("a_query", "b_g1_query", "h_query", "l_query", "b_g2_query"):
