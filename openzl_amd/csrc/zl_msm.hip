@@ -2218,7 +2218,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // measured (round 3, batches of 6): 2^16 0.69 -> 0.50 ms per MSM, 2^20 3.31 -> 3.10; equal at 2^18 - 2^19; from 2^21 on the three-phase pipeline
     // wins (2^24: 36.3 against 37.3 ms)
     const bool side = biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
-    const size_t NS = side ? std::min<size_t>(count, 4) : 3;
+    const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
     for (size_t i = 0; i < count; i++) {
         // (side by side every job computes its own phi image: there is no common stream that would order a borrower behind the owner)
         if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, (one_key && !side) ? 18 : MsmJob<G>::phi_slot_of((int)(i % NS))))) return rc;
