@@ -163,7 +163,10 @@ static __global__ void __launch_bounds__(256) k_msm_recode(const uint32_t* __res
         uint32_t d = ((uint32_t)(v >> sh) & ((1u << c) - 1)) + carry;
         uint32_t neg = 0;
         carry = 0;
-        if (d > H) { d = 2 * H - d; neg = 1; carry = 1; }
+        // tie d == H: +H for a positive scalar, -H (carry 1) for a negative half-scalar, whose digits are all flipped below -- either way the
+        // magnitude H only ever appears with a clear sign bit in the code, so 0xFFFF stays free at c = 16 too.  (The tie cannot happen in the top
+        // window of a GLV half-scalar, where the carry would be lost: |k_i| <= lambda / 2 + 1 < 0.68 * 2^127.)
+        if (d > H - sg) { d = 2 * H - d; neg = 1; carry = 1; }
         uint32_t b = d - 1;
         // a narrow top window (spread_t + 1 bits) is spread over its whole bucket set like in k_msm_recode_wide; its digits are never
         // negative (magnitudes <= 2^spread_t <= H), so the code 0xFFFF stays free
@@ -1699,7 +1702,7 @@ struct MsmJob {
         first = first_;
         bsp = &bs;
         pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
-        c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, sc_bits, glv));
+        c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, sc_bits, glv && G::ENDO_K != 2));
         if (c < 2) c = 2;
         if (c > 24) c = 24;
         W = (sc_bits + 1 + c - 1) / c;
@@ -1712,9 +1715,10 @@ struct MsmJob {
         NB = (uint32_t)NB64;
         Gn = NB >> 15;  // sort groups of 32768 (window, bucket) ids; the group id travels in a byte, 0xFF = zero digit
         if (pre && (c < 16 || Gn < 1 || Gn > 255)) return ZL_EINVAL;
-        // plain windows beyond that (c >= 21) fall back to the global-atomics sort.  Half-scalars at c = 16 take the wide sort too: its
-        // zero-digit marker lives in hi8, while the 16-bit code of the LDS sort has no room for a digit of magnitude H with the sign set
-        wide = pre || ((c > 16 || (glv && c == 16)) && Gn >= 1 && Gn <= 255);
+        // plain windows beyond that (c >= 21) fall back to the global-atomics sort.  GLS quarter-scalars (G2) at c = 16 take the wide sort too: their
+        // narrow top window is spread over the bucket set, and a spread bucket index of all ones with the sign set would be the LDS sort's 0xFFFF =
+        // "zero digit" (GLV half-scalars on G1 have a full top window and a tie rule that keeps the code free: k_msm_recode)
+        wide = pre || ((c > 16 || (glv && c == 16 && G::ENDO_K != 2)) && Gn >= 1 && Gn <= 255);
         // chunk length: 64 entries per lane once there are enough entries to fill the chip (~2^18 lanes), shorter below
         // (128 once there are >= 2^20 lanes of that length: half as many cut buckets to merge; 32.8 -> 32.2 ms per pipelined 2^24 MSM)
         ZL_CHUNK = (maxE >> 7) >= (1u << 20) ? 128u : (uint32_t)ZL_CHUNK_MAX;
