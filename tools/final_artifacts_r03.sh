@@ -23,9 +23,9 @@ mkdir -p profiles; cp $O/r03_pmc_traffic.json $O/r03_pmc_traffic_ntt.json profil
 # ---- kernel stats ------------------------------------------------------------------------------------------------------------------
 rocprofv3 --kernel-trace --stats -d $O/p1 -o t -- python bench.py > $O/r03_bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 python tools/prof_summary.py $(dbof $O/p1) > $O/r03_kernel_stats_bench_default.txt
-# the headline leg alone (no fixed-key / skewed / NTT / Groth16 / CPU legs): every big k_msm_accumulate launch in this trace is one timed or warm-up step of `value`,
+# the headline leg alone (no fixed-key / skewed / NTT / Groth16 / CPU / configs legs): every big k_msm_accumulate launch in this trace is one timed or warm-up step of `value`,
 # so the table's big_avg_us is directly comparable with roofline.kernel_ms of the JSON line written by the same command
-rocprofv3 --kernel-trace --stats -d $O/p7 -o t -- python bench.py --no-skew --fixed-key -1 --no-ntt --groth16-k 0 --no-cpu > $O/r03_bench_headline_under_rocprof.json 2> $O/bench_headline_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d $O/p7 -o t -- python bench.py --no-skew --fixed-key -1 --no-ntt --groth16-k 0 --no-cpu --no-configs > $O/r03_bench_headline_under_rocprof.json 2> $O/bench_headline_under_rocprof.err
 python tools/prof_summary.py $(dbof $O/p7) > $O/r03_kernel_stats_bench_headline.txt
 rocprofv3 --kernel-trace --stats -d $O/p2 -o t -- python tools/msm_one.py 24 0 -1 3 > $O/msm_plain.log 2>&1
 python tools/prof_summary.py $(dbof $O/p2) reduce_tree > $O/r03_kernel_stats_msm_plain_single_call.txt
