@@ -42,6 +42,11 @@ int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint3
  * not re-uploaded per proof): zl_groth16_prove_circuit returns ZL_EINVAL instead of proving against the wrong matrices. */
 int zl_test_circuit_tweak(zl_circuit* c);
 
+/* MEASUREMENT ONLY (bench.py's integer-ALU roofline): chains of the accumulation kernel's 14 x 28-bit Montgomery product on per-lane pseudo-random
+ * operands, cu_count x 4 x waves_per_simd wavefronts, `iters` products per lane; returns 10^9 products per second.  This is the live-data ceiling of
+ * the multiplier on the box of the run (constant-pattern operands clock 15-20 % higher; profiles/r04_fbench_f64.log). */
+int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_products_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,7 @@ def load_library(path: Optional[str] = None):
     L.zl_test_fp28_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_circuit_tweak.argtypes = [vp]
+    L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -396,7 +397,7 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate"]
 
 
 def _p32(a: np.ndarray):
@@ -433,6 +434,13 @@ def hook_point_op(be: Optional["Backend"], group: int, hot: bool, op: int, pq: n
     if rc:
         raise BackendError(rc, "zl_test_point_op")
     return out
+
+
+def hook_fq_mul_rate(be: "Backend", waves_per_simd: int = 3, iters: int = 3000) -> float:
+    """10^9 Montgomery products per second of the accumulation kernel's multiplier on per-lane pseudo-random operands (measurement hook)"""
+    v = C.c_double(0.0)
+    be._check(be.L.zl_test_fq_mul_rate(be._ctx, waves_per_simd, iters, C.byref(v)), "zl_test_fq_mul_rate")
+    return v.value
 
 
 # ---- host mirror (openzl::R1CS / poseidon / Groth16<E>, csrc/zl_host.h) through its C hooks ---------------------------

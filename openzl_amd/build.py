@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -16,7 +17,23 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 FLAGS += [f for f in os.environ.get("ZL_EXTRA_FLAGS", "").split() if f]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
-HEADERS = ["zl_field.h", "zl_field28.h", "zl_curve.h", "zl_params.h", "zl_mul_gfx950.h", "zl_mul28_gfx950.h", "zl_bounds.h", "zl_ctx.h", "zl_host.h", "zl_pairing.h", "zl_serialize.h", os.path.join("..", "..", "include", "zl_backend.h"), os.path.join("..", "..", "include", "zl_backend_test.h")]
+_INC = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+
+
+def _deps(src: str) -> list[str]:
+    """Every file `src` reaches through quoted #include lines (recursively, whatever the preprocessor conditions say: device-only
+    includes count too).  Derived from the sources on every build, so a new header can never be forgotten in a hand-kept list
+    (round 3's zl_quad.h / zl_pool.h were)."""
+    seen, todo = [], [os.path.normpath(src)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f, encoding="utf-8", errors="replace") as fh:
+            for inc in _INC.findall(fh.read()):
+                todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    return sorted(seen)
 
 
 def _hipcc() -> str:
@@ -54,12 +71,11 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
     gen = os.path.join(CSRC, "gen_params.py")
     if not os.path.exists(params) or os.path.getmtime(params) < os.path.getmtime(gen):
         subprocess.check_call([sys.executable, gen])
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     todo, objs = [], []
     for name, src, defs in _units():
         obj = os.path.join(CSRC, name + ".o")
         stamp = obj + ".sha"
-        d = _digest([os.path.join(CSRC, src)] + hdrs, " ".join(FLAGS + defs))
+        d = _digest(_deps(os.path.join(CSRC, src)), " ".join(FLAGS + defs))
         objs.append(obj)
         if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == d:
             continue

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <functional>
 #include <map>
@@ -106,6 +107,8 @@ struct zl_twiddles {
     void* d_hi = nullptr;  // w^(i << lo_bits)
     void* d_small = nullptr;  // per-radix tables
     void* d_last = nullptr;   // combined inter-factor twiddles of the last pass, one per element (multi-pass sizes, built on first use)
+    size_t last_bytes = 0;    // ... its size, and when it was last used: the tables of one ctx share a byte budget (ZL_TUNE_NTT_LAST_MB), least recently used first out
+    uint64_t last_used = 0;
     unsigned lo_bits = 0;
 };
 struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Montgomery form)
@@ -129,6 +132,8 @@ struct zl_ctx {
     uint64_t next_handle = 1;
     zl_scratch scratch[40];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV); 4, 19, 23: tail buffers of the three sets
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
+    size_t ntt_last_bytes = 0;   // bytes held by the d_last tables of this ctx
+    uint64_t ntt_clock = 0;
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
     hipStream_t stream_tail[3] = {nullptr, nullptr, nullptr};  // one tail stream per buffer set: the tails of consecutive small jobs run side by side
@@ -143,6 +148,11 @@ struct zl_ctx {
     size_t g16_h_n = 0;
 };
 
+// developer tuning knob / deployment limit read from the environment (unset = the default)
+inline int zl_tune(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 inline zl_worker& zl_ctx_worker(zl_ctx* ctx, int k) {
     if (!ctx->workers[k]) ctx->workers[k] = new zl_worker();
     return *ctx->workers[k];

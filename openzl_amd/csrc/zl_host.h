@@ -178,8 +178,9 @@ public:
     }
     uint32_t var_index(uint32_t key) const { return (key & kWitnessBit) ? (uint32_t)instance_.size() + (key & ~kWitnessBit) : key; }
     const std::vector<LC>& rows(int m) const { return m == 0 ? A_ : m == 1 ? B_ : C_; }
-    // 64-bit fingerprint of the constraint MATRICES (not the assignment): row / variable counts and the keys + coefficients of up to
-    // 1024 evenly spaced rows of every matrix.  A proving context records it when it learns its circuit and refuses a compiler whose
+    // 64-bit fingerprint of the constraint MATRICES (not the assignment): row / variable counts and the keys + coefficients of EVERY
+    // row of every matrix (a sampled digest would let a circuit that differs only in unsampled rows through; hashing the 958 465-row
+    // Poseidon chain costs a few ms, once per compiler).  A proving context records it when it learns its circuit and refuses a compiler whose
     // fingerprint differs: two different circuits of the same shape must not silently share device matrices.  Rows are append-only, so
     // the value is cached per (row count, variable counts): prove() pays for it once per compiler.
     uint64_t structure_digest() const {
@@ -187,10 +188,10 @@ public:
         uint64_t h = 0xCBF29CE484222325ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
         mix(A_.size()); mix(instance_.size()); mix(witness_.size());
-        const size_t rows = A_.size(), step = rows > 1024 ? rows / 1024 : 1;
+        const size_t rows = A_.size();
         for (int m = 0; m < 3; m++) {
             const std::vector<LC>& M = this->rows(m);
-            for (size_t i = 0; i < rows; i += step) {
+            for (size_t i = 0; i < rows; i++) {
                 mix(M[i].terms.size());
                 for (const auto& t : M[i].terms) { mix(t.first); for (int k = 0; k < F::N; k += 2) mix((uint64_t)t.second.l[k] | ((uint64_t)t.second.l[k + 1] << 32)); }
             }

@@ -740,6 +740,23 @@ __device__ __forceinline__ bool zl_ge(zl_u128 a, zl_u128 b) { return a.hi > b.hi
 __device__ __forceinline__ zl_u128 zl_sub(zl_u128 a, zl_u128 b) { return zl_u128{a.lo - b.lo, a.hi - b.hi - (a.lo < b.lo ? 1u : 0u)}; }
 __device__ __forceinline__ zl_u128 zl_inc(zl_u128 a) { return zl_u128{a.lo + 1, a.hi + (a.lo + 1 == 0 ? 1u : 0u)}; }
 __device__ __forceinline__ zl_u128 zl_dec(zl_u128 a) { return zl_u128{a.lo - 1, a.hi - (a.lo == 0 ? 1u : 0u)}; }
+// Scalars in [r, 2^SC_BITS) pass zl_flag_wide_scalar but are not canonical: floor(k / lambda) then exceeds lambda + 1 and the balanced halves wrap.  The
+// plain path returns the sum mod r for them, so the endomorphism splits reduce such a scalar once (k < 2^255 < 2 r) and return the same point.
+template <class P>
+__device__ __forceinline__ void zl_reduce_once_mod_r(uint32_t* k) {
+    uint32_t d[8];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const uint64_t x = (uint64_t)k[w] - P::rmod(w) - borrow;
+        d[w] = (uint32_t)x;
+        borrow = (uint32_t)(x >> 63);
+    }
+    if (!borrow) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) k[w] = d[w];
+    }
+}
 // out: 2n records of 8 words -- record i = k1 of scalar i, record n + i = k2 of scalar i; magnitude in words 0..3, sign in bit 31 of word 7.
 // Scalars of bases at infinity give two zero records; a scalar with bits at or above sc_bits sets *bad (not canonical).
 template <class P>
@@ -752,7 +769,8 @@ __global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ 
     uint4 lo4 = sp[0], hi4 = sp[1];
     zl_flag_wide_scalar(hi4.w, sc_bits, bad);
     if (inf && inf[i]) lo4 = hi4 = make_uint4(0, 0, 0, 0);
-    const uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    zl_reduce_once_mod_r<P>(k);
     // q = floor(k m / 2^383), m = floor(2^383 / lambda): the quotient or one less
     uint32_t pw[16];
     {
@@ -922,6 +940,7 @@ __global__ void __launch_bounds__(256) k_gls_split(const uint32_t* __restrict__ 
     zl_flag_wide_scalar(hi4.w, sc_bits, bad);
     if (inf && inf[i]) lo4 = hi4 = make_uint4(0, 0, 0, 0);
     uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    zl_reduce_once_mod_r<P>(k);  // k in [r, 2^255) may exceed |z|^4 - 1: the fourth quotient would not be a digit
     uint64_t d[4];
     d[0] = zl_divmod_z<P>(k);
     d[1] = zl_divmod_z<P>(k);
@@ -1593,11 +1612,7 @@ __global__ void __launch_bounds__(64) k_bases_level_dbl(const Affine<typename G:
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
-// developer tuning knobs (profiling sweeps only; unset in production): ZL_TUNE_CHUNK, ZL_TUNE_SEG, ZL_TUNE_FS, ZL_TUNE_RANGES
-static int zl_tune(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+// developer tuning knobs (profiling sweeps only; unset in production): ZL_TUNE_CHUNK, ZL_TUNE_SEG, ZL_TUNE_FS, ZL_TUNE_RANGES (zl_tune, zl_ctx.h)
 static int zl_pick_window(size_t n, int sc_bits, bool wide16 = false /* c = 16 also runs the three-level sort (GLV jobs) */) {
     // cost in accumulated entries: n per window (+10 % for c <= 16: the one-level LDS counting sort streams every window's digits once per
     // bucket range and is the slower sort at large n) + ~5.7 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
@@ -1827,6 +1842,8 @@ struct MsmJob {
                     bs.endo_first = first;
                     bs.endo_n = n_real;
                     bs.endo_k = endo_k;
+                } else {
+                    (void)hipGetLastError();  // out of memory for the cache: clear HIP's sticky per-thread error, the per-call scratch copy below serves
                 }
             }
             if (bs.d_endo && bs.endo_first == first && bs.endo_n == n_real && bs.endo_k == endo_k) {

@@ -445,16 +445,33 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         // the combined twiddles of the last pass, tabulated once per (size, direction): forward (plain and coset share it: the coset scaling
         // rides on pass 1) and the scaled inverse; the coset inverse (its 1/n lives in the coset table) combines on the fly
         if (last && pl.P > 1 && !(inverse && coset) && n <= 26 && !getenv("ZL_NTT_NO_LAST_TABLE")) {
-            if (!tw->d_last) {
+            const size_t want = N * sizeof(F);
+            const size_t budget = (size_t)zl_tune("ZL_TUNE_NTT_LAST_MB", 2048) << 20;  // 2^24 forward + inverse = 1 GiB; a sweep over sizes stays bounded
+            if (!tw->d_last && want <= budget) {
+                // least recently used tables of other (size, direction) keys go first; the stream is drained before a table in flight is freed
+                while (ctx->ntt_last_bytes + want > budget) {
+                    zl_twiddles* victim = nullptr;
+                    for (auto& kv : ctx->twiddles)
+                        if (kv.second.d_last && &kv.second != tw && (!victim || kv.second.last_used < victim->last_used)) victim = &kv.second;
+                    if (!victim) break;
+                    ZL_HIP(ctx, hipStreamSynchronize(st));
+                    (void)hipFree(victim->d_last);
+                    ctx->ntt_last_bytes -= victim->last_bytes;
+                    victim->d_last = nullptr;
+                    victim->last_bytes = 0;
+                }
                 void* t = nullptr;
-                if (hipMalloc(&t, N * sizeof(F)) == hipSuccess) {
+                if (ctx->ntt_last_bytes + want <= budget && hipMalloc(&t, want) == hipSuccess) {
                     a.last_tw = nullptr;
                     hipLaunchKernelGGL((k_ntt_last_table<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
                     tw->d_last = t;
+                    tw->last_bytes = want;
+                    ctx->ntt_last_bytes += want;
                 } else {
                     (void)hipGetLastError();  // no room: keep combining on the fly
                 }
             }
+            if (tw->d_last) tw->last_used = ++ctx->ntt_clock;
             a.last_tw = tw->d_last;
         }
         // columns per tile
@@ -644,4 +661,5 @@ void zl_ntt_free(zl_ctx* ctx) {
         if (kv.second.d_last) (void)hipFree(kv.second.d_last);
     }
     ctx->twiddles.clear();
+    ctx->ntt_last_bytes = 0;
 }

@@ -196,6 +196,36 @@ static int run_dev(zl_ctx* ctx, const uint32_t* in, size_t in_words, uint32_t* o
     return ZL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ live-data multiplier rate
+// The ceiling bench.py's integer-ALU roofline is quoted against, measured on the box of the run: every lane chains x <- x * y with the product scan
+// of the accumulation kernel (zl_mul28_gfx950.h) on its OWN pseudo-random operands.  Constant-pattern operands (hipMemset, as tools/fbench28_asm.hip
+// uses) run 15-20 % faster on MI355X -- the chip clocks to its power budget and identical lanes toggle less -- and overstate what a kernel on real
+// field elements can reach (profiles/r04_fbench_f64.log).
+__global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sink, int iters) {
+    using A = BLS12_381_Fq28;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = 0x9E3779B97F4A7C15ull * (t + 1);
+    F28 x = F28::zero(), y = F28::zero();
+    for (int k = 0; k < 14; k++) {
+        s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
+        x.l[k] = (uint32_t)s & 0xFFFFFFFu;
+        y.l[k] = (uint32_t)(s >> 32) & 0xFFFFFFFu;
+    }
+    x.l[13] %= A::mod(13);
+    y.l[13] %= A::mod(13);
+    for (int k = 0; k < iters; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        F28 r = x;
+        mul28_asm<A>(r.l, x.l, y.l);
+        x = r;
+#endif
+    }
+    uint32_t acc = 0;
+    for (int k = 0; k < 14; k++) acc ^= x.l[k];
+    sink[t] = acc;
+}
+
 extern "C" {
 
 int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state) {
@@ -240,6 +270,31 @@ int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint3
         else if (hot) hipLaunchKernelGGL((k_test_point<Fp2LT<F28, true>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
         else hipLaunchKernelGGL((k_test_point<Fp2LT<F28, false>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
     });
+}
+
+int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_products_per_s) {
+    if (!ctx || !g_products_per_s || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 20)) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t blocks = (uint32_t)ctx->cu_count * 4u * (uint32_t)waves_per_simd;
+    void* d = nullptr;
+    int rc = zl_scratch_get(ctx, 9, (size_t)blocks * 64 * 4, &d);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    ZL_HIP(ctx, hipEventCreate(&e0));
+    ZL_HIP(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, 8);
+    ZL_HIP(ctx, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, iters);
+    ZL_HIP(ctx, hipEventRecord(e1, st));
+    ZL_HIP(ctx, hipStreamSynchronize(st));
+    ZL_HIP(ctx, hipGetLastError());
+    float ms = 0;
+    ZL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *g_products_per_s = (double)blocks * 64.0 * (double)iters / ((double)ms * 1e-3) / 1e9;
+    return ZL_OK;
 }
 
 }  // extern "C"

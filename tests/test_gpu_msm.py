@@ -445,6 +445,65 @@ def test_msm_glv_edge_scalars(backend):
         backend.bases_free(h)
 
 
+def test_msm_scalars_between_r_and_2_255(backend):
+    """ADVICE r3 (medium): scalars in [r, 2^255) pass the MODULUS_BITS check but are not canonical.  The plain path returns the sum mod r for them;
+    the endomorphism splits (k_glv_split for G1, k_gls_split for G2; n <= 2^19) used to wrap (floor(k / lambda) > lambda + 1) and return a wrong point.
+    They now reduce such a scalar once: k = r, r + 1, r + lambda, 2^255 - 1, r + random, mixed with canonical scalars, every sort path, against the
+    oracle on the scalars reduced mod r."""
+    import groth16_util as gu
+    from openzl_amd.backend import ZL_G2
+
+    curve = po.BLS12_381
+    r = curve.fr.p
+    z = 0xD201000000010000
+    lam = z * z - 1
+    rnd = ol.limbs_to_ints(ol.random_scalars(curve, 40, 4242))
+    wide = [r, r + 1, r + lam, r + lam + 1, (1 << 255) - 1, (1 << 255) - 2, r + (lam >> 1), r + z, r + z ** 3] + [r + (x % ((1 << 255) - r)) for x in rnd]
+    assert all(r <= x < (1 << 255) for x in wide)
+    n = 1200
+    S = ol.random_scalars(curve, n, 4243)
+    S[5:5 + len(wide)] = ol.ints_to_limbs(wide, 4)
+    S_red = S.copy()
+    S_red[5:5 + len(wide)] = ol.ints_to_limbs([x - r for x in wide], 4)
+    k, B = _bases(curve, n, 4244)
+    h = backend.bases_upload(curve.cid, B)
+    exp, einf = ol.oracle_msm_g1(curve, B, S_red, algo=0, threads=4)
+    try:
+        for c in (0, 8, 16, 18):
+            backend.set_msm_window(c)
+            got, inf = backend.msm(h, S)
+            assert inf == einf and (got == exp).all(), c
+        backend.set_msm_window(8)
+        for j, x in enumerate(wide[:9]):
+            got, inf = backend.msm(h, ol.ints_to_limbs([x], 4))
+            e1, i1 = ol.oracle_msm_g1(curve, B[:1], ol.ints_to_limbs([x - r], 4))
+            assert inf == i1 and (got == e1).all(), hex(x)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
+    # G2 (four base-|z| digits: a scalar >= |z|^4 > r would not fit four digits)
+    n2 = 300
+    B2 = gu.g2_mul_gen(curve, ol.limbs_to_ints(ol.random_scalars(curve, n2, 4245)))
+    S2, S2_red = S[:n2].copy(), S_red[:n2].copy()
+    import ctypes as C
+
+    exp2 = np.zeros(4 * ol.nlq(curve), dtype=np.uint64)
+    einf2 = C.c_uint8(0)
+    assert ol.lib().zlo_msm_g2(curve.cid, ol.p64(B2), 0, ol.p64(S2_red), n2, 0, 4, ol.p64(exp2), C.byref(einf2)) == 0
+    einf2 = einf2.value
+    h2 = backend.bases_upload(curve.cid, B2, group=ZL_G2)
+    try:
+        got_red, inf_red = backend.msm(h2, S2_red)
+        for c in (0, 7, 16):
+            backend.set_msm_window(c)
+            got, inf = backend.msm(h2, S2)
+            assert inf == inf_red and (got == got_red).all(), c
+            assert inf == einf2 and (got == exp2).all(), c
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h2)
+
+
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 def test_msm_ranges_of_one_handle_and_repeated_points(backend, curve):
     """Small MSMs over different ranges of ONE handle, interleaved: the endomorphism images of the bases are kept with the handle for the first

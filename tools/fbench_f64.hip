@@ -1,0 +1,278 @@
+// tools/fbench_f64.hip -- VERDICT r3 item 1 / SURVEY.md 7.2: an FP64-FMA Montgomery multiplier for the BLS12-381 base field (8 x 49-bit signed limbs
+// held as doubles, hi/lo split by the FMA's own rounding; tools/gen_mul_f64.py) against the 14 x 28-bit v_mad_u64_u32 product scan of zl_field28.h,
+// plus the scalar field on 6 x 44-bit limbs.  Two parts:
+//   1. GATE: 2^20 random + boundary operand pairs; the FP64 product must equal the product of zl_field28.h bit for bit (same Montgomery radix 2^392,
+//      compared as canonical integers in [0, q) on the host).
+//   2. RATE: chains x <- x * y (and x <- x^2) at 1..5 waves per SIMD, the same harness as tools/fbench28_asm.hip, both multipliers in one binary on one
+//      box, plus the bare issue rates of v_fma_f64 / v_add_f64 / v_mad_u64_u32 on LIVE data (the r01 table's FMA chain saturates to inf, which clocks
+//      higher: MI355X_MICROARCH.md "DVFS give-back").
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/fbench_f64.hip -o tools/fbench_f64
+#include "../openzl_amd/csrc/zl_field28.h"
+#include "mul_f64_gen.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using A = BLS12_381_Fq28;
+using F = Fp28<A, BLS12_381_Fq>;
+struct D8 { double l[8]; };
+struct D6 { double l[6]; };
+
+// ------------------------------------------------------------------------------------------------ gate
+__global__ void k_once_f64(const D8* a, const D8* b, D8* r, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    D8 x = a[i], y = b[i], z;
+    mul_f64_fq(z.l, x.l, y.l);
+    r[i] = z;
+}
+__global__ void k_once_sqr_f64(const D8* a, D8* r, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    D8 x = a[i], z;
+    sqr_f64_fq(z.l, x.l);
+    r[i] = z;
+}
+__global__ void k_once_ref(const F* a, const F* b, F* r, F* rs, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    r[i] = zl::canon(zl::mul(a[i], b[i]));
+    rs[i] = zl::canon(zl::sqr(a[i]));
+}
+// host: 448-bit two's-complement integers as 7 x u64
+struct Big { uint64_t w[7]; };
+static void big_add_shifted(Big& x, int64_t v, int shift) {  // x += v * 2^shift
+    // sign-extended v as a 448-bit number shifted left
+    uint64_t ext[8] = {0};
+    const int word = shift / 64, bit = shift % 64;
+    const uint64_t lo = (uint64_t)v, sign = v < 0 ? ~0ull : 0ull;
+    for (int k = 0; k < 7; k++) {
+        uint64_t val;
+        if (k < word) val = 0;
+        else if (k == word) val = lo << bit;
+        else if (k == word + 1) val = bit ? ((lo >> (64 - bit)) | (sign << bit)) : sign;
+        else val = sign;
+        ext[k] = val;
+    }
+    unsigned __int128 c = 0;
+    for (int k = 0; k < 7; k++) { c += (unsigned __int128)x.w[k] + ext[k]; x.w[k] = (uint64_t)c; c >>= 64; }
+}
+static Big big_from28(const uint32_t* l) { Big x{}; for (int i = 0; i < 14; i++) big_add_shifted(x, (int64_t)l[i], 28 * i); return x; }
+static Big big_from49(const double* l) { Big x{}; for (int i = 0; i < 8; i++) big_add_shifted(x, (int64_t)l[i], 49 * i); return x; }
+static void to49(const Big& v, double* out) {  // non-negative v < 2^392 -> 8 signed-normalised limbs (the top one takes the rest)
+    int64_t carry = 0;
+    for (int i = 0; i < 8; i++) {
+        const int sh = 49 * i, word = sh / 64, bit = sh % 64;
+        uint64_t chunk = v.w[word] >> bit;
+        if (bit > 15 && word + 1 < 7) chunk |= v.w[word + 1] << (64 - bit);
+        int64_t d = (int64_t)(chunk & ((1ull << 49) - 1)) + carry;
+        carry = 0;
+        if (i < 7 && d >= (1ll << 48)) { d -= 1ll << 49; carry = 1; }
+        out[i] = (double)d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rate
+template <int MODE>
+__global__ void k_chain_f64(D8* a, const D8* b, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    D8 x = a[i], y = b[i];
+    for (int k = 0; k < iters; k++) {
+        D8 r;
+        if (MODE == 0) mul_f64_fq(r.l, x.l, y.l);
+        else sqr_f64_fq(r.l, x.l);
+        x = r;
+    }
+    a[i] = x;
+}
+__global__ void k_chain_fr(D6* a, const D6* b, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    D6 x = a[i], y = b[i];
+    for (int k = 0; k < iters; k++) { D6 r; mul_f64_fr(r.l, x.l, y.l); x = r; }
+    a[i] = x;
+}
+template <int MODE>
+__global__ void k_chain_28(F* a, const F* b, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    F x = a[i], y = b[i];
+    for (int k = 0; k < iters; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        F r = x;
+        if (MODE == 0) mul28_asm<A>(r.l, x.l, y.l);
+        else sqr28_asm<A>(r.l, x.l);
+        x = r;
+#endif
+    }
+    a[i] = x;
+}
+using Fr = Fp<BLS12_381_Fr>;
+__global__ void k_chain_fr32(Fr* a, const Fr* b, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr x = a[i], y = b[i];
+    for (int k = 0; k < iters; k++) x = zl::mul(x, y);
+    a[i] = x;
+}
+// bare issue rates on live data: 4 independent chains whose values stay bounded and keep changing
+__global__ void k_rate_fma(double* out, int iters) {
+    double x0 = 1.0 + threadIdx.x * 1e-3, x1 = x0 + 0.11, x2 = x0 + 0.23, x3 = x0 + 0.37;
+    const double c = 0.999999, d = 1e-7 * (1 + blockIdx.x);
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c), "v"(d));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3;
+}
+__global__ void k_rate_mad(uint64_t* out, int iters) {
+    uint64_t d0 = threadIdx.x * 0x9E3779B97F4A7C15ull, d1 = d0 * 3, d2 = d0 * 5, d3 = d0 * 7;
+    uint32_t a0 = (uint32_t)d0 | 1, a1 = a0 * 2654435761u, a2 = a1 * 2654435761u, a3 = a2 * 2654435761u;
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %5, %6, %1\n v_mad_u64_u32 %2, vcc, %6, %7, %2\n v_mad_u64_u32 %3, vcc, %7, %4, %3"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = d0 ^ d1 ^ d2 ^ d3;
+}
+
+static uint64_t sm64(uint64_t& s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+int main(int argc, char** argv) {
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("# device %s, %d CUs; FP64 product = %d FP64 instructions (%d v_fma_f64), square = %d, Fr 6x44 = %d; 28-bit scan = 406 v_mad_u64_u32 + 70 others\n",
+           prop.gcnArchName, prop.multiProcessorCount, MUL_F64_FQ_OPS, MUL_F64_FQ_FMAS, SQR_F64_FQ_OPS, MUL_F64_FR_OPS);
+    // ---- gate
+    {
+        const uint32_t n = 1u << 20;
+        std::vector<F> ha(n), hb(n);
+        std::vector<D8> da(n), db(n);
+        uint64_t seed = 0x5EED0F64;
+        const uint32_t qtop = A::mod(13);
+        for (uint32_t i = 0; i < n; i++) {
+            for (int side = 0; side < 2; side++) {
+                F& x = side ? hb[i] : ha[i];
+                memset(&x, 0, sizeof(F));
+                if (i < 64) {
+                    // boundary operands: the seven low 49-bit limbs at +-2^48 (every sign pattern class) with a small top part, 0, 1, q - 1
+                    Big v{};
+                    if (i == 0) {}
+                    else if (i == 1) v.w[0] = 1;
+                    else if (i == 2) { for (int k = 0; k < 14; k++) big_add_shifted(v, (int64_t)A::mod(k), 28 * k); big_add_shifted(v, -1, 0); }
+                    else {
+                        for (int k = 0; k < 7; k++) big_add_shifted(v, (((i + side) >> k) & 1) ? -(1ll << 48) : (1ll << 48), 49 * k);
+                        big_add_shifted(v, 4 + (int64_t)(i & 7), 343);  // makes the value positive and far below q (q >> 343 is about 2^37.7)
+                    }
+                    for (int k = 0; k < 14; k++) {
+                        const int sh = 28 * k, word = sh / 64, bit = sh % 64;
+                        uint64_t chunk = v.w[word] >> bit;
+                        if (bit > 36 && word + 1 < 7) chunk |= v.w[word + 1] << (64 - bit);
+                        x.l[k] = (uint32_t)(chunk & 0xFFFFFFFu);
+                    }
+                } else {
+                    for (int k = 0; k < 13; k++) x.l[k] = (uint32_t)(sm64(seed) & 0xFFFFFFFu);
+                    x.l[13] = (uint32_t)(sm64(seed) % qtop);  // value < q
+                }
+                to49(big_from28(x.l), side ? db[i].l : da[i].l);
+            }
+        }
+        F *ga, *gb, *gr, *grs; D8 *fa, *fb, *fr, *fs;
+        CHECK(hipMalloc(&ga, n * sizeof(F))); CHECK(hipMalloc(&gb, n * sizeof(F))); CHECK(hipMalloc(&gr, n * sizeof(F))); CHECK(hipMalloc(&grs, n * sizeof(F)));
+        CHECK(hipMalloc(&fa, n * sizeof(D8))); CHECK(hipMalloc(&fb, n * sizeof(D8))); CHECK(hipMalloc(&fr, n * sizeof(D8))); CHECK(hipMalloc(&fs, n * sizeof(D8)));
+        CHECK(hipMemcpy(ga, ha.data(), n * sizeof(F), hipMemcpyHostToDevice)); CHECK(hipMemcpy(gb, hb.data(), n * sizeof(F), hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(fa, da.data(), n * sizeof(D8), hipMemcpyHostToDevice)); CHECK(hipMemcpy(fb, db.data(), n * sizeof(D8), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_once_ref, dim3(n / 64), dim3(64), 0, 0, ga, gb, gr, grs, n);
+        hipLaunchKernelGGL(k_once_f64, dim3(n / 64), dim3(64), 0, 0, fa, fb, fr, n);
+        hipLaunchKernelGGL(k_once_sqr_f64, dim3(n / 64), dim3(64), 0, 0, fa, fs, n);
+        CHECK(hipDeviceSynchronize());
+        std::vector<F> hr(n), hrs(n); std::vector<D8> dr(n), ds(n);
+        CHECK(hipMemcpy(hr.data(), gr, n * sizeof(F), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hrs.data(), grs, n * sizeof(F), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(dr.data(), fr, n * sizeof(D8), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ds.data(), fs, n * sizeof(D8), hipMemcpyDeviceToHost));
+        Big q{}; for (int k = 0; k < 14; k++) big_add_shifted(q, (int64_t)A::mod(k), 28 * k);
+        uint64_t bad = 0, bad_limb = 0, neg = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            for (int which = 0; which < 2; which++) {
+                const double* l = which ? ds[i].l : dr[i].l;
+                for (int k = 0; k < 7; k++) if (!(l[k] >= -281474976710656.0 && l[k] <= 281474976710656.0) || l[k] != (double)(int64_t)l[k]) bad_limb++;
+                Big v = big_from49(l);
+                if (v.w[6] >> 63) { neg++; unsigned __int128 c = 0; for (int k = 0; k < 7; k++) { c += (unsigned __int128)v.w[k] + q.w[k]; v.w[k] = (uint64_t)c; c >>= 64; } }
+                const Big e = big_from28(which ? hrs[i].l : hr[i].l);
+                if (memcmp(&v, &e, sizeof(Big)) != 0) { if (bad < 4) printf("MISMATCH pair %u (%s)\n", i, which ? "sqr" : "mul"); bad++; }
+            }
+        }
+        printf("gate: %u operand pairs (64 boundary + random), mul and sqr, FP64 vs zl_field28.h as canonical integers: %llu mismatches, %llu limbs out of the signed-normalised range, %llu negative results (+q)  => %s\n",
+               n, (unsigned long long)bad, (unsigned long long)bad_limb, (unsigned long long)neg, bad == 0 && bad_limb == 0 ? "BIT-EXACT" : "FAILED");
+        if (bad || bad_limb) return 2;
+        hipFree(ga); hipFree(gb); hipFree(gr); hipFree(grs); hipFree(fa); hipFree(fb); hipFree(fr); hipFree(fs);
+    }
+    // ---- bare issue rates on live data
+    for (int wps : {1, 2, 4, 8}) {
+        int threads = 64, blocks = prop.multiProcessorCount * 4 * wps;
+        void* out; CHECK(hipMalloc(&out, (size_t)threads * blocks * 8));
+        const int iters = 2000;
+        for (int which = 0; which < 2; which++) {
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            if (which == 0) hipLaunchKernelGGL(k_rate_fma, dim3(blocks), dim3(threads), 0, 0, (double*)out, 10); else hipLaunchKernelGGL(k_rate_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)out, 10);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            if (which == 0) hipLaunchKernelGGL(k_rate_fma, dim3(blocks), dim3(threads), 0, 0, (double*)out, iters); else hipLaunchKernelGGL(k_rate_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)out, iters);
+            CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("rate  %-14s waves/SIMD=%d  %8.3f ms  %8.1f G wave-instr/s (live data)\n", which ? "v_mad_u64_u32" : "v_fma_f64", wps, ms, (double)blocks * iters * 64.0 / (ms * 1e-3) / 1e9);
+        }
+        CHECK(hipFree(out));
+    }
+    // ---- multiplier chains
+    struct Leg { const char* name; int kind; };
+    const Leg legs[] = {{"Fq mul  FP64 8x49      ", 0}, {"Fq sqr  FP64 8x49      ", 1}, {"Fq mul  28-bit mad scan", 2}, {"Fq sqr  28-bit mad scan", 3}, {"Fr mul  FP64 6x44      ", 4}, {"Fr mul  8x32 carry     ", 5}};
+    for (const Leg& leg : legs) for (int wps : {1, 2, 3, 4, 5}) {
+        int threads = 64, blocks = prop.multiProcessorCount * 4 * wps;
+        size_t n = (size_t)threads * blocks;
+        const int iters = 4000;
+        void *a, *b; CHECK(hipMalloc(&a, n * 64)); CHECK(hipMalloc(&b, n * 64));
+        std::vector<uint8_t> ha(n * 64), hb(n * 64);
+        uint64_t seed = 77;
+        if (leg.kind <= 1 || leg.kind == 4) {
+            const int L = leg.kind == 4 ? 6 : 8, w = leg.kind == 4 ? 44 : 49;
+            for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
+                double* d = reinterpret_cast<double*>((side ? hb : ha).data() + i * (size_t)L * 8);
+                for (int k = 0; k < L; k++) d[k] = (double)((int64_t)(sm64(seed) >> (64 - w)) - (1ll << (w - 1))) * (k == L - 1 ? 0x1p-14 : 1.0);
+            }
+        } else if (leg.kind <= 3) {
+            for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
+                uint32_t* l = reinterpret_cast<uint32_t*>((side ? hb : ha).data() + i * 64);
+                for (int k = 0; k < 13; k++) l[k] = (uint32_t)(sm64(seed) & 0xFFFFFFFu);
+                l[13] = (uint32_t)(sm64(seed) % A::mod(13));
+            }
+        } else {
+            for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
+                uint32_t* l = reinterpret_cast<uint32_t*>((side ? hb : ha).data() + i * 32);
+                for (int k = 0; k < 8; k++) l[k] = (uint32_t)sm64(seed);
+                l[7] &= 0x3FFFFFFFu;
+            }
+        }
+        CHECK(hipMemcpy(a, ha.data(), n * 64, hipMemcpyHostToDevice)); CHECK(hipMemcpy(b, hb.data(), n * 64, hipMemcpyHostToDevice));
+        auto launch = [&](int it) {
+            switch (leg.kind) {
+                case 0: hipLaunchKernelGGL(k_chain_f64<0>, dim3(blocks), dim3(threads), 0, 0, (D8*)a, (const D8*)b, it); break;
+                case 1: hipLaunchKernelGGL(k_chain_f64<1>, dim3(blocks), dim3(threads), 0, 0, (D8*)a, (const D8*)b, it); break;
+                case 2: hipLaunchKernelGGL(k_chain_28<0>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
+                case 3: hipLaunchKernelGGL(k_chain_28<1>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
+                case 4: hipLaunchKernelGGL(k_chain_fr, dim3(blocks), dim3(threads), 0, 0, (D6*)a, (const D6*)b, it); break;
+                default: hipLaunchKernelGGL(k_chain_fr32, dim3(blocks), dim3(threads), 0, 0, (Fr*)a, (const Fr*)b, it); break;
+            }
+        };
+        launch(4);
+        CHECK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        CHECK(hipEventRecord(e0));
+        launch(iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("chain %s waves/SIMD=%d  %8.3f ms  %8.2f G products/s\n", leg.name, wps, ms, (double)n * iters / (ms * 1e-3) / 1e9);
+        CHECK(hipFree(a)); CHECK(hipFree(b));
+    }
+    return 0;
+}
