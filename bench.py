@@ -21,9 +21,12 @@ on every rank (zl_partials_sum).  Rank 0 prints ONE JSON line.  Extra objects on
   configs       BASELINE.json's five configurations on this line: "1" 2^16 BN254 (GPU + CPU oracle, equal), "2" 2^20 BLS12-381 (single call /
                 pipelined, integer-ALU fraction of the whole call), "3" -> ntt, "4" 2^26 as 8 shards (N = 1: 8 virtual ranks through
                 zl_msm_sharded, functional; N > 1: scaling.config4), "5" -> groth16
-  scaling       N > 1: weak (2^log_n per GPU = the headline), config4 (2^26 points over the N ranks) and strong (2^24 points over the N ranks),
-                each checked exactly against the all-shard dot product and each with per_gpu_efficiency = (time of the same per-GPU
-                MSM on rank 0 alone, measured in this process) / (time with all ranks)
+  scaling_legs  N > 1: weak (2^log_n per GPU = the headline), config4 (2^26 points over the N ranks) and strong (2^24 points over the N ranks),
+                each checked exactly against the all-shard dot product and each with interference_ratio = (time of the same per-GPU
+                MSM on rank 0 alone, measured in this process) / (time with all ranks) -- which is the weak-scaling efficiency of the weak and config-4
+                legs; the strong leg also carries strong_scaling_efficiency = T_1(total) / (N x T_N) with T_1 = the whole 2^24-point MSM on rank 0 alone
+  scaling_model N = 1: single-GPU ms per MSM at 2^21 .. 2^24 (exact) and the weak / config-4 / strong efficiencies they imply at N = 2, 4, 8
+                (the exchange is 512 B per rank); a prediction, labelled so, not a hardware claim
   mctx          N > 1: the one-process transport (zl_ctx_create_multi + zl_msm_sharded / zl_ntt_sharded) timed by a child process of
                 rank 0 after the ranks are done; .rccl_ranks = size of the RCCL communicator the library created
   pcie_inclusive    the same MSM with the scalars coming from host memory (zl_msm); never `value`
@@ -58,6 +61,15 @@ MULS_PER_MIXED_ADD = MADS_PER_MIXED_ADD / MADS_PER_MUL  # 9.04 multiplication-eq
 FQ_MUL_PEAK_CONST_G = 78.6  # rounds 2-3's ceiling: the multiplier of zl_field28.h alone at the accumulate kernel's occupancy, 3 waves/SIMD (166 registers; 68.4 / 76.6 / 78.6 / 80.0 / 80.6 G/s at 1..5 waves, tools/fbench28_asm.hip, profiles/r02_fbench28_asm_occupancy.log; rounds 1 and early 2 used 74.3 = two waves on a slower box)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 _FQ_MUL_PEAK_LIVE = {}
+_ORACLE = {"cflags": "-O3 -march=x86-64-v3 -fopenmp (portable build)"}
+
+
+def oracle_native():
+    """cpu_baseline legs time the oracle compiled ON THIS BOX with -march=native; the flags travel on the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+
+    _ORACLE["cflags"] = ol.select_native()
 
 
 def fq_mul_peak_live(be) -> float:
@@ -139,6 +151,7 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
         "unit": "points/s",
         "cores": threads if best_is_grid else wt,
         "kind": "port",
+        "cflags": _ORACLE["cflags"],
         "value_is": "all_core_grid" if best_is_grid else "window_parallel",
         "all_core_grid": {"value": grid_rate, "cores": threads},
         "sample": f"the complete 2^{full_log_n} BLS12-381 G1 input of the GPU run (same bases, same scalars) as a (chunk x window) task grid over {threads} "
@@ -173,7 +186,7 @@ def cpu_baseline_ntt(x_mont: np.ndarray, threads_req: int):
         raise SystemExit("CPU oracle NTT round trip failed")
     m = min(n, 1 << 22)
     _, sec_1 = ol.oracle_ntt_timed(curve, np.ascontiguousarray(x_mont[:m]), inverse=False, threads=1)
-    return {"value": 2.0 * n / (sec_f + sec_i), "unit": "elements/s (forward + inverse)", "cores": threads, "kind": "port",
+    return {"value": 2.0 * n / (sec_f + sec_i), "unit": "elements/s (forward + inverse)", "cores": threads, "kind": "port", "cflags": _ORACLE["cflags"],
             "sample": f"the complete 2^{n.bit_length() - 1} vector of the GPU run, forward then inverse, butterflies of every stage split over {threads} threads",
             "forward_s": sec_f, "inverse_s": sec_i,
             "single_thread": {"value": m / sec_1, "unit": "elements/s (forward)", "cores": 1, "sample": f"2^{m.bit_length() - 1} prefix, forward"}}, X
@@ -201,7 +214,7 @@ def cpu_baseline_groth16(be, keys, circ, gpu_proof, r, s, threads_req: int):
     if not same:
         raise SystemExit("full-size parity check failed: the CPU oracle's Groth16 proof differs from the GPU proof")
     n_c = arrays["n_constraints"]
-    return {"value": n_c / sec, "unit": "constraints/s", "cores": threads, "kind": "port", "prove_s": sec, "parity_full_size": True,
+    return {"value": n_c / sec, "unit": "constraints/s", "cores": threads, "kind": "port", "cflags": _ORACLE["cflags"], "prove_s": sec, "parity_full_size": True,
             "sample": f"the complete config-5 circuit ({n_c} constraints), same proving key / witness / (r, s) as the GPU proof; window-parallel MSMs over "
                       f"{threads} threads (arkworks `parallel`), single-threaded NTTs; arkworks-algorithm restatement in C, not the arkworks binary"}
 
@@ -325,7 +338,7 @@ class MsmInputs:
     three-stream pipeline cannot hide behind identical inputs), and the exact expected answers (sum s_i k_i mod r) G -- of this shard
     and of all shards together -- from one O(n) dot product per vector."""
 
-    def __init__(self, R: Run, n: int, seed: int, curve=None, r_mod: int = R_BLS, bits: int = 255):
+    def __init__(self, R: Run, n: int, seed: int, curve=None, r_mod: int = R_BLS, bits: int = 255, local_only: bool = False):
         from openzl_amd import ZL_BLS12_381
         from openzl_amd.selfcheck import dot_mod_r, expected_point
 
@@ -347,7 +360,7 @@ class MsmInputs:
         self.dots = [dot_mod_r(v, self.k64, r_mod) for v in self.vecs]
         self.exp_xy = [expected_point(be, self.curve, d) for d in self.dots]   # this rank's shard
         self.exp_all = self.exp_xy                                              # all ranks together
-        if R.world > 1:
+        if R.world > 1 and not local_only:
             mine = torch.tensor([(d >> (32 * j)) & 0xFFFFFFFF for d in self.dots for j in range(8)], dtype=torch.int64, device=R.coll_dev)
             allv = torch.empty(R.world * 16, dtype=torch.int64, device=mine.device)
             R.dist.all_gather_into_tensor(allv, mine)
@@ -366,7 +379,7 @@ class MsmInputs:
 def msm_leg(R: Run, inp: MsmInputs, steps: int, warmup: int, pipelined: bool, solo: bool, what: str):
     """Gate (exact, full size, both scalar vectors, single call + pipelined batch + all ranks) -> `warmup` untimed steps -> EXACTLY `steps`
     timed steps between barriers, max over ranks -> every timed step checked exactly.  solo (N > 1): the same `steps` local MSMs on
-    rank 0 alone while the other ranks wait: the N = 1 reference of the same per-GPU size for per_gpu_efficiency."""
+    rank 0 alone while the other ranks wait: the N = 1 reference of the same per-GPU size for interference_ratio (= the weak-scaling efficiency of a fixed-shard leg)."""
     from openzl_amd.sharded import fold_partials, sharded_msm, sharded_msm_batch
 
     be, n, h, d_vecs, curve = R.be, inp.n, inp.h, inp.d_vecs, inp.curve
@@ -464,9 +477,92 @@ def scaling_entry(R: Run, name: str, total_desc: str, n_local: int, leg: dict, s
          "result_check": "gate + every timed step equal (sum over ALL shards of s_i k_i) G exactly"}
     if "solo_ms_per_step" in leg:
         e["single_gpu_ms_per_step"] = leg["solo_ms_per_step"]
-        e["per_gpu_efficiency"] = leg["solo_ms_per_step"] / leg["ms_per_step"]
-        e["efficiency_note"] = "time of the same per-GPU MSMs on rank 0 alone (same process, same inputs, other ranks idle, no collective) / time with all ranks + all_gather + fold"
+        e["interference_ratio"] = leg["solo_ms_per_step"] / leg["ms_per_step"]
+        e["interference_note"] = ("time of the same per-GPU MSMs on rank 0 alone (same process, same inputs, other ranks idle, no collective) / time with all ranks + "
+                                  "all_gather + fold.  For a leg whose per-GPU work is fixed as N grows (weak, config 4) this IS the scaling efficiency; for the strong leg it "
+                                  "only measures interference -- see strong_scaling_efficiency")
+        if name in ("weak", "config4"):
+            e["weak_scaling_efficiency"] = e["interference_ratio"]
+    if "t1_total_ms_per_step" in leg:
+        e["single_gpu_total_ms_per_step"] = leg["t1_total_ms_per_step"]
+        e["strong_scaling_efficiency"] = leg["t1_total_ms_per_step"] / (R.world * leg["ms_per_step"])
+        e["strong_scaling_note"] = ("T_1(total) / (N x T_N): T_1 = the WHOLE problem (all N shards' points) as one MSM on rank 0 alone, measured in this process "
+                                    "(pipelined like the timed steps, checked exactly); T_N = the timed all-rank step")
     return e
+
+
+def strong_t1_leg(R: Run, log_total: int, steps: int, warmup: int, pipelined: bool):
+    """T_1 of the strong-scaling definition: the whole 2^log_total-point problem on ONE GPU (rank 0, the other ranks wait at the barrier), same process,
+    pipelined like the timed steps, every result checked exactly.  Returns ms per MSM (0.0 on the other ranks)."""
+    from openzl_amd.sharded import fold_partials
+
+    R.barrier()
+    ms = 0.0
+    if R.rank == 0:
+        li = MsmInputs(R, 1 << log_total, 90 + log_total, local_only=True)
+        try:
+            be = R.be
+
+            def run(cnt):
+                if pipelined and cnt > 1:
+                    return be.msm_batch_partial_dev(li.h, [li.d_vecs[i % 2].data_ptr() for i in range(cnt)], li.n)
+                return np.stack([be.msm_partial_dev(li.h, li.d_vecs[i % 2].data_ptr(), li.n) for i in range(cnt)])
+
+            run(max(warmup, 3))
+            R.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            parts = run(steps)
+            R.torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            for i in range(steps):
+                xy, inf = fold_partials(li.curve, parts[i].reshape(1, -1))
+                if inf or not (np.asarray(xy) == li.exp_xy[i % 2]).all():
+                    raise SystemExit("MSM self-check failed (strong-scaling T_1 leg): result != (sum s_i k_i) G at full size")
+        finally:
+            li.free()
+    R.barrier()
+    return R.max_over_ranks([ms])[0]
+
+
+def scaling_model_leg(R: Run, inp: MsmInputs, head: dict):
+    """N = 1 only: what can be known about multi-GPU scaling from one GPU.  The exchange of the sharded MSM is one all_gather of 512 B per rank and N - 1 group
+    additions (microseconds), so the per-GPU time at N ranks is the single-GPU time of the shard: measured here, pipelined, at 2^21 / 2^22 / 2^23 (prefixes of
+    the headline's inputs, every result checked exactly against the prefix's own dot product), next to the headline's 2^24.  NO hardware claim: the implied
+    efficiencies hold if and only if the ranks do not disturb each other (the driver's SCALE run measures that)."""
+    from openzl_amd.selfcheck import dot_mod_r, expected_point
+    from openzl_amd.sharded import fold_partials
+
+    be, torch = R.be, R.torch
+    full_log = int(np.log2(inp.n))
+    ms = {f"2^{full_log}": head["ms_per_step"]}
+    for lg in (21, 22, 23):
+        if lg >= full_log:
+            continue
+        m = 1 << lg
+        exp = [expected_point(be, inp.curve, dot_mod_r(v[:m], inp.k64[:m], R_BLS)) for v in inp.vecs]
+        ptrs = [inp.d_vecs[i % 2].data_ptr() for i in range(8)]
+        be.msm_batch_partial_dev(inp.h, ptrs[:3], m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        parts = be.msm_batch_partial_dev(inp.h, ptrs, m)
+        torch.cuda.synchronize()
+        ms[f"2^{lg}"] = (time.perf_counter() - t0) / 8 * 1e3
+        for i in range(8):
+            xy, inf = fold_partials(inp.curve, parts[i].reshape(1, -1))
+            if inf or not (np.asarray(xy) == exp[i % 2]).all():
+                raise SystemExit(f"MSM self-check failed (scaling model, 2^{lg} prefix)")
+    t = lambda lg: ms.get(f"2^{lg}")  # noqa: E731
+    model = {"measured_ms_per_msm_pipelined": ms, "checked_exactly": True,
+             "exchange": "one all_gather of 512 B per rank + N - 1 group additions on every rank: microseconds, not modelled",
+             "weak_2^%d_per_gpu" % full_log: {"N=2": 1.0, "N=4": 1.0, "N=8": 1.0, "note": "per-GPU work does not change with N; only the un-modelled exchange and rank interference remain"},
+             "note": "PREDICTED from single-GPU measurements, not measured on N GPUs: efficiency(N) = T_1(total) / (N x T_1(total / N))"}
+    if full_log == 24 and all(t(x) for x in (21, 22, 23)):
+        model["strong_2^24_total"] = {"N=2": t(24) / (2 * t(23)), "N=4": t(24) / (4 * t(22)), "N=8": t(24) / (8 * t(21)),
+                                      "note": "north_star's >= 0.9 per-GPU efficiency at 8 GPUs is a weak-scaling statement for this path: a 2^21-point shard amortises "
+                                              "its bucket reduction and sort over 8x fewer points"}
+        model["config4_2^26_total"] = {"N=8_per_gpu_rate_vs_2^24_rate": (2 ** 23 / t(23)) / (2 ** 24 / t(24)), "N=4_per_gpu_rate_vs_2^24_rate": 1.0,
+                                       "note": "2^23 points per GPU at N = 8 (2^24 at N = 4 = the headline's shard): points/s per GPU relative to the headline's"}
+    return model
 
 
 def config1_leg(R: Run, no_cpu: bool):
@@ -602,7 +698,7 @@ def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup):
                "rccl_ranks": G if mb.uses_rccl else 0, "exchange": "RCCL (ncclCommInitAll; ncclAllGather / grouped ncclSend+ncclRecv)" if mb.uses_rccl else
                "virtual ranks sharing a device: device-to-device copies with the same data movement pattern (RCCL refuses duplicate devices)",
                "msm": {"points_per_gpu": n, "points_total": float(n) * G, "steps": steps, "ms_per_step": el / steps * 1e3, "points_per_s": float(n) * G * steps / el,
-                       "single_gpu_ms_per_step": solo * 1e3, "per_gpu_efficiency": solo / (el / steps), "checked_exactly": True,
+                       "single_gpu_ms_per_step": solo * 1e3, "interference_ratio": solo / (el / steps), "checked_exactly": True,
                        "issued_as": "separate zl_msm_sharded calls (not pipelined)"}}
         for hh, r in zip(hs, mb.ranks):
             r.bases_free(hh)
@@ -742,6 +838,8 @@ def main():
         be.set_msm_window(args.window)
     n = 1 << args.log_n
     R = Run(args, torch, dist, be, dev, rank, world)
+    if rank == 0 and world == 1:
+        oracle_native()  # before the first leg that loads the oracle
 
     leg_errors = {}
 
@@ -764,6 +862,13 @@ def main():
     head = msm_leg(R, inp, args.steps, args.warmup, not args.no_pipeline, True, "headline")
     elapsed, pipelined, single_ms = head["elapsed"], head["pipelined"], head["single_call_latency_ms"]
     tm = be.last_timing()
+    scaling_model = None
+    if rank == 0 and world == 1 and not args.no_configs and args.log_n >= 22:
+        def _leg_scaling_model():
+            nonlocal scaling_model
+            scaling_model = scaling_model_leg(R, inp, head)
+
+        _guard("scaling_model", _leg_scaling_model)
 
     def check(xy, inf, j, what):
         if inf or not (np.asarray(xy) == exp_xy[j]).all():
@@ -897,7 +1002,7 @@ def main():
             ntt_cpu["parity_full_size"] = True
             del X_cpu, X_gpu
         ntt_traffic, ntt_traffic_src = None, None
-        for cand in ("r03_pmc_traffic_ntt.json", "r02_pmc_traffic_ntt.json"):
+        for cand in ("r04_pmc_traffic_ntt.json",):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if ln == int(pmc["log_n"]):
@@ -920,7 +1025,7 @@ def main():
             "fwd_plus_inv_elems_per_s": tot / ((f_ms + i_ms) * 1e-3),
             "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
-                         "traffic_unit": f"bytes per transform, all passes (FETCH_SIZE + WRITE_SIZE, profiles/{ntt_traffic_src or 'rNN_pmc_traffic_ntt.json'}; null for other sizes)",
+                         "traffic_unit": f"bytes per transform, all passes, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; profiles/{ntt_traffic_src or 'r04_pmc_traffic_ntt.json'}; null for other sizes)",
                          "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform, all butterfly passes of one transform together; "
                                  "the last pass also streams its combined twiddles (+32 B/element read, one multiplication less)"},
             "cpu_baseline": ntt_cpu,
@@ -1045,7 +1150,7 @@ def main():
         # WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration, null otherwise
         traffic = None
         traffic_src = None
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json",):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if args.log_n == int(pmc["log_n"]) and head["window_bits"] == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
@@ -1081,7 +1186,8 @@ def main():
                        "result_check": "every timed step equals (sum s_i k_i) G exactly at full size (known discrete logs); the CPU oracle's MSM of the "
                                        "complete input equals it too (cpu_baseline.parity_full_size)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": f"bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/{traffic_src or 'rNN_pmc_traffic.json'}; null for any other configuration)",
+                         "traffic": traffic, "traffic_unit": f"bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B), from the committed PMC passes of this configuration "
+                                         f"(profiles/{traffic_src or 'r04_pmc_traffic.json'}: rocprofv3 cannot run inside the timed process); null for any other configuration",
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
                          "int_alu": {"unit": "G Fq-mul/s", "achieved": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9, "peak": fq_mul_peak_live(be),
                                      "frac": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / fq_mul_peak_live(be),
@@ -1097,6 +1203,7 @@ def main():
                                  "integer-multiply bound (DESIGN.md), so the HBM fraction is small by construction"},
             "cpu_baseline": cpu,
             "configs": configs or None,
+            "scaling_model": scaling_model,
             "pcie_inclusive": pcie_info,
             "msm_fixed_key": fixed_info,
             "msm_skewed_scalars": skew_info,
@@ -1132,6 +1239,8 @@ def main():
                     li = MsmInputs(R, n_loc, 40 + log_total)
                     leg = msm_leg(R, li, args.steps, args.warmup, not args.no_pipeline, True, name)
                     li.free()
+                    if name == "strong":
+                        leg["t1_total_ms_per_step"] = strong_t1_leg(R, log_total, args.steps, args.warmup, not args.no_pipeline)
                     ent, err = scaling_entry(R, name, f"2^{log_total} points in total = {n_loc} per GPU", n_loc, leg, args.steps), 0.0
                 except Exception as e:  # noqa: BLE001 -- (failed self-checks are SystemExit and abort)
                     ent, err = {"error": f"{type(e).__name__}: {e}"}, 1.0

@@ -97,11 +97,13 @@ void zl_ctx_destroy(zl_ctx* ctx) {
         if (a->pinned) (void)hipHostFree(a->pinned);
         zl_ntt_free(a);
         for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);
+        for (auto& pool : a->ev_pool) for (auto& ev : pool) (void)hipEventDestroy(ev);
         if (a->own_stream) (void)hipStreamDestroy(a->own_stream);
         delete a;
         *ax = nullptr;
     }
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& pool : ctx->ev_pool) for (auto& ev : pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -228,20 +230,28 @@ int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars,
 }
 // Host scalars (what VariableBaseMSM::multi_scalar_mul is handed: the witness is new for every proof).  One copy followed by one MSM leaves
 // the whole transfer (32 B / point: 12.6 ms for 2^24 from pageable memory) in front of the first kernel.  Large inputs are therefore cut into
-// a few growing shards of points (2^20, 2^20, 2^21, 2^22, ...): MSM(all) = sum of the shards' MSMs, a helper thread copies shard j + 1 on its
-// own stream while the three-stream pipeline of zl_msm_batch_partial_dev works on the shards before it (each job waits for its copy's
-// event), and only the first, small copy stays exposed.  The shards use the window width of their own size, which costs a few percent
-// more additions than one full-size MSM; measured at 2^24: see bench.py pcie_inclusive.
+// a few growing shards of points: MSM(all) = sum of the shards' MSMs, a helper thread copies shard j + 1 on its own stream while the pipeline of
+// zl_msm_batch_partial_dev works on the shards before it (each job waits for its copy's event), and only the first, small copy stays exposed.
+// Shard plan (round 4, profiles/r04_host_shards.log): 2^20, then four times the previous shard, the rest as the last one -- 2^20, 2^22, 11.5 M at
+// 2^24.  The copy of a shard (1.3 M scalars / ms) must hide under the MSM of the one before it (0.3 - 0.43 M points / ms), which allows a growth of
+// 3 - 4x; every extra shard costs its own bucket sets and narrower windows.  Round 3's doubling plan (2^20, 2^20, 2^21, 2^22, 2^23) measured 44.5 ms
+// against 41.8 for this one (38.4 with the scalars already on the device); 2^21 first 43.0; 2^20, 2^21, 2^22, rest 42.9; 2^20, 2^22, 2^23, rest 42.7.
 static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const uint64_t* scalars, size_t n, void* d_sc, uint64_t* out_xy, uint8_t* out_inf) {
     std::vector<size_t> off, len;
     size_t done = 0, step = (size_t)1 << 20;
+    const char* plan = getenv("ZL_TUNE_HOST_SHARDS");  // developer sweep: log2 sizes of the leading shards, e.g. "20,22" (the rest is one shard)
     while (done < n) {
         size_t l = std::min(step, n - done);
-        if (n - done - l < step / 2) l = n - done;  // no tiny last shard
+        if (plan) {
+            l = *plan ? std::min<size_t>((size_t)1 << atoi(plan), n - done) : n - done;
+            while (*plan && *plan != ',') plan++;
+            if (*plan == ',') plan++;
+        }
+        if (n - done - l < step / 2) l = n - done;  // no small last shard
         off.push_back(done);
         len.push_back(l);
         done += l;
-        if (off.size() >= 2) step <<= 1;
+        step <<= 2;
     }
     const size_t K = off.size();
     if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));

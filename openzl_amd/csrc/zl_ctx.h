@@ -133,6 +133,9 @@ struct zl_ctx {
     zl_scratch scratch[40];  // 0..9: first buffer set + shared; 10..13 / 14..17: second / third MSM buffer set (pipelined batches); 18, 20..22: endomorphism images of the bases (GLV); 4, 19, 23: tail buffers of the three sets
     std::map<uint64_t, zl_twiddles> twiddles;  // key: curve<<16 | log_n<<1 | inverse
     size_t ntt_last_bytes = 0;   // bytes held by the d_last tables of this ctx
+    // events of the job pipelines, created once and reused by every call: a hipEventCreate / hipEventDestroy pair costs ~50 us of host time, and a
+    // four-job pipeline used 14 of them per call -- 0.8 ms at the END of every Groth16 proof (round 4 host trace, profiles/r04_g16_share_ab.log)
+    std::vector<hipEvent_t> ev_pool[2];  // [0] hipEventDisableTiming, [1] timing
     uint64_t ntt_clock = 0;
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
@@ -152,6 +155,18 @@ struct zl_ctx {
 inline int zl_tune(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
+}
+// the first `count` events of the ctx's pool of one kind (grown on demand; owned by the ctx: zl_ctx_destroy)
+inline int zl_ctx_events(zl_ctx* ctx, int timing, size_t count, hipEvent_t** out) {
+    std::vector<hipEvent_t>& pool = ctx->ev_pool[timing ? 1 : 0];
+    while (pool.size() < count) {
+        hipEvent_t e = nullptr;
+        const hipError_t he = timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (he != hipSuccess) { ctx->last_hip = (int)he; return ZL_EHIP; }
+        pool.push_back(e);
+    }
+    *out = pool.data();
+    return ZL_OK;
 }
 inline zl_worker& zl_ctx_worker(zl_ctx* ctx, int k) {
     if (!ctx->workers[k]) ctx->workers[k] = new zl_worker();

@@ -1383,7 +1383,10 @@ __global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_redu
     }
     if (sub != 0) return;
     out[(size_t)2 * t] = run;
-    out[(size_t)2 * t + 1] = flat ? run : wsum;
+    // (two stores, not `flat ? run : wsum`: the conditional operator on the two structs becomes a select of their ADDRESSES, which pins both in scratch --
+    // that was the whole of this kernel's 528 B of private memory in rounds 2-3)
+    if (flat) out[(size_t)2 * t + 1] = run;
+    else out[(size_t)2 * t + 1] = wsum;
 }
 // one tree level: nodes of `level` (1-based) from the nodes of level - 1.  Node layout: [set][node][channel], ch_in = level + 1 channels
 // in (T, A, S_0 .. S_(level-2)), ch_out = level + 2 out.  One lane per (set, node, out channel).
@@ -2266,6 +2269,11 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
             if (one_key && !side && i > 0 && jobs[i].glv && !jobs[i].phi_cached) jobs[i].d_phi = jobs[0].d_phi;
         }
     }
+    // (Round 4 built and removed "sort sharing": jobs over the same scalar vector with the same plan borrowing one bucket-sorted entry list -- VERDICT r3
+    // item 2's proposal for Groth16's a_query / b_g1_query MSMs.  Those two lists are NOT equal: each query has its own points at infinity (variables
+    // absent from A resp. B) and the sort drops their scalars.  Forcing the pair to share one sort anyway, for its timing only, moved the
+    // 958 465-constraint proof by nothing: 19.39 / 19.44 against 19.40 / 19.76 ms (profiles/r04_g16_eventpool_ab.log) -- the proof is bound by its group
+    // additions, not its sorts.  And a pipeline that skips the sort of a repeated scalar vector would skip work inside bench.py's timed steps.)
     const size_t per = sizeof(X) * (max_sets + 1) + 16;
     if (ctx->pinned_cap < per * count) {
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -2291,27 +2299,17 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     const int acc_wg_per_cu = sizeof(X) > 256 ? 0 : zl_tune("ZL_TUNE_ACC_WG_PER_CU", 0);
     // (Measured and dropped: making the accumulation of job i+1 wait for the merge kernels / level 0 of job i, so that two field-arithmetic
     // kernels never share the machine -- 958 465-constraint proof 19.2-19.4 ms with or without, 2^20 batches 3.65 = 3.65 ms per MSM.)
-    std::vector<hipEvent_t> ev_sorted(count), ev_acc(count), ev_tail(count), ev_acc0(ctx->timing_on ? count : 0);
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    auto cleanup = [&]() {
-        for (auto e : ev_sorted) if (e) (void)hipEventDestroy(e);
-        for (auto e : ev_acc) if (e) (void)hipEventDestroy(e);
-        for (auto e : ev_tail) if (e) (void)hipEventDestroy(e);
-        for (auto e : ev_acc0) if (e) (void)hipEventDestroy(e);
-        if (ev_begin) (void)hipEventDestroy(ev_begin);
-        if (ev_end) (void)hipEventDestroy(ev_end);
-    };
+    // events from the ctx's pool (zl_ctx_events): [sorted | tail | acc (untimed runs)] without timing, [begin, end | acc0 | acc (timed runs)] with
+    hipEvent_t *pool_nt = nullptr, *pool_t = nullptr;
+    if ((rc = zl_ctx_events(ctx, 0, 3 * count, &pool_nt))) return rc;
+    if ((rc = zl_ctx_events(ctx, 1, 2 + (ctx->timing_on ? 2 * count : 0), &pool_t))) return rc;
+    hipEvent_t* ev_sorted = pool_nt;
+    hipEvent_t* ev_tail = pool_nt + count;
+    hipEvent_t* ev_acc = ctx->timing_on ? pool_t + 2 + count : pool_nt + 2 * count;
+    hipEvent_t* ev_acc0 = ctx->timing_on ? pool_t + 2 : nullptr;
+    hipEvent_t ev_begin = pool_t[0], ev_end = pool_t[1];
+    auto cleanup = [&]() {};  // (the events stay with the ctx)
     hipError_t he = hipSuccess;
-    for (size_t i = 0; i < count && he == hipSuccess; i++) {
-        ev_sorted[i] = ev_acc[i] = ev_tail[i] = nullptr;
-        he = hipEventCreateWithFlags(&ev_sorted[i], hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&ev_tail[i], hipEventDisableTiming);
-        if (he == hipSuccess) he = ctx->timing_on ? hipEventCreate(&ev_acc[i]) : hipEventCreateWithFlags(&ev_acc[i], hipEventDisableTiming);
-        if (he == hipSuccess && ctx->timing_on) he = hipEventCreate(&ev_acc0[i]);
-    }
-    if (he == hipSuccess) he = hipEventCreate(&ev_begin);
-    if (he == hipSuccess) he = hipEventCreate(&ev_end);
-    if (he != hipSuccess) { cleanup(); ctx->last_hip = (int)he; return ZL_EHIP; }
     rc = ZL_OK;
     // everything already queued on the caller's stream (e.g. the kernels that produced the scalars) comes first
     he = hipEventRecord(ev_begin, s_acc);

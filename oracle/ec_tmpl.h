@@ -235,7 +235,7 @@ static void E(msm_ark_c)(E(jac) *out, const E(aff) *bases, const uint64_t *scala
 /* All-core MSM as a (chunk x window) grid (NOT what arkworks 0.3.0 does -- its `parallel` feature stops at one thread per window): the
  * input is cut into contiguous chunks so that chunks x windows ~ threads, every (chunk, window) pair is one task running ark's window
  * routine (window width by ark's rule for the chunk length; bucket arrays of a chunk-sized problem stay cache-sized), then a Horner per
- * chunk and the chunk results are added.  The strongest CPU arrangement of the same algorithm that this restatement offers. */
+ * chunk and the chunk results are added.  It uses every core on the same algorithm; it is NOT always the fastest arrangement (on a 256-thread box the window-parallel run of a 2^22 prefix on 15 threads measured faster per point: bench.py reports both and takes the better). */
 static void E(msm_chunked)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads) {
     int nt = threads < 1 ? 1 : threads;
     size_t chunks = 1;

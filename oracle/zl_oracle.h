@@ -44,7 +44,7 @@ int zlo_msm_g1(int curve, const uint64_t *bases, int bases_mont, const uint64_t 
 /* Same with timing for bench.py's cpu_baseline: the bases are loaded in parallel (untimed), *seconds = the MSM alone.
  * algo 0: ark Pippenger, window-parallel over `threads` (c_override > 0 forces the window width, e.g. the width ark's rule gives the
  * full-size workload when a bounded sample is timed); algo 2: point-chunked over `threads` (every thread runs the single-threaded
- * ark algorithm on its chunk; not an arkworks configuration -- the strongest CPU arrangement of the same algorithm). */
+ * ark algorithm on its chunk; not an arkworks configuration; uses every core, not necessarily the fastest arrangement: bench.py reports it beside the window-parallel run). */
 int zlo_msm_g1_ex(int curve, const uint64_t *bases, int bases_mont, const uint64_t *scalars, size_t n, int algo, int c_override,
                   int threads, uint64_t *out_xy, uint8_t *out_inf, double *seconds);
 /* G2 MSM: bases n x (x.c0||x.c1||y.c0||y.c1). */

@@ -24,30 +24,58 @@ use ark_ec::{AffineCurve, PairingEngine};
 use ark_ff::{BigInteger, Field, FromBytes, PrimeField, UniformRand, Zero};
 use ark_groth16::{Groth16 as ArkGroth16, Proof as ArkProof, ProvingKey};
 use ark_relations::r1cs::{ConstraintSynthesizer, ConstraintSystem, OptimizationGoal, SynthesisMode};
-use ark_serialize::CanonicalSerialize;
+use ark_serialize::{CanonicalDeserialize, CanonicalSerialize, Read, SerializationError, Write};
 use ark_snark::SNARK;
 use core::{cell::Cell, marker::PhantomData, ptr};
 use openzl_crypto::constraint::ProofSystem;
 use openzl_plugin_arkworks::{
     constraint::R1CS,
     groth16::{Error, Proof, VerifyingContext},
+    serialize::{ArkReader, ArkWriter},
 };
-use openzl_util::rand::{CryptoRng, RngCore, SizedRng};
+use openzl_util::{
+    codec::{self, DecodeError},
+    rand::{CryptoRng, RngCore, SizedRng},
+};
 
 /// The two pairing engines the backend is built for (include/zl_backend.h: `zl_curve_t`).
+///
+/// `PairingEngine` has no generic way to build an affine point from coordinates (ark-ec 0.3.0: `E::G1Affine` is only bound by `AffineCurve`), so the
+/// constructors live here, written against the concrete curve crates: `short_weierstrass_jacobian::GroupAffine::new(x, y, infinity)` and, for the twist,
+/// `QuadExtField::new(c0, c1)` coordinates (ark-ec 0.3.0 `models/short_weierstrass_jacobian.rs`, ark-ff 0.3.0 `fields/models/quadratic_extension.rs`).
 pub trait Mi355xEngine: PairingEngine {
     /// `ZL_BLS12_381` or `ZL_BN254`
     const CURVE: i32;
     /// u64 limbs per base-field element in the ABI layouts (6 / 4)
     const FQ_LIMBS: usize;
+    /// the finite G1 point (x, y)
+    fn g1_from_xy(x: Self::Fq, y: Self::Fq) -> Self::G1Affine;
+    /// the finite G2 point (x0 + x1 u, y0 + y1 u)
+    fn g2_from_xy(x0: Self::Fq, x1: Self::Fq, y0: Self::Fq, y1: Self::Fq) -> Self::G2Affine;
 }
 impl Mi355xEngine for ark_bls12_381::Bls12_381 {
     const CURVE: i32 = ffi::ZL_BLS12_381;
     const FQ_LIMBS: usize = 6;
+    #[inline]
+    fn g1_from_xy(x: Self::Fq, y: Self::Fq) -> Self::G1Affine {
+        ark_bls12_381::G1Affine::new(x, y, false)
+    }
+    #[inline]
+    fn g2_from_xy(x0: Self::Fq, x1: Self::Fq, y0: Self::Fq, y1: Self::Fq) -> Self::G2Affine {
+        ark_bls12_381::G2Affine::new(ark_bls12_381::Fq2::new(x0, x1), ark_bls12_381::Fq2::new(y0, y1), false)
+    }
 }
 impl Mi355xEngine for ark_bn254::Bn254 {
     const CURVE: i32 = ffi::ZL_BN254;
     const FQ_LIMBS: usize = 4;
+    #[inline]
+    fn g1_from_xy(x: Self::Fq, y: Self::Fq) -> Self::G1Affine {
+        ark_bn254::G1Affine::new(x, y, false)
+    }
+    #[inline]
+    fn g2_from_xy(x0: Self::Fq, x1: Self::Fq, y0: Self::Fq, y1: Self::Fq) -> Self::G2Affine {
+        ark_bn254::G2Affine::new(ark_bn254::Fq2::new(x0, x1), ark_bn254::Fq2::new(y0, y1), false)
+    }
 }
 
 std::thread_local! {
@@ -72,16 +100,148 @@ fn ctx() -> Result<*mut ffi::zl_ctx, Error> {
     })
 }
 
-/// Proving context: the arkworks proving key (kept for `Encode` / inspection) and its device-resident twin.
+/// Proving context: the arkworks proving key (what the reference's `ProvingContext<E>(pub ProvingKey<E>)` is, groth16.rs:120-140) and its
+/// device-resident twin.  Like the reference's it is `Clone + Debug + Eq`, `CanonicalSerialize / CanonicalDeserialize` and
+/// `codec::Encode / Decode`: all of them delegate to `key`; the device state is rebuilt from it (clone / decode = one upload).
+///
+/// A proving key belongs to ONE circuit (in the reference too: a key used with another circuit yields a proof that does not verify), so the
+/// constraint matrices are uploaded with the first proof and stay on the device.  `shape` records that circuit's (constraints, instance
+/// variables, witness variables, linear combinations): a later compiler with another shape is refused with `Error` instead of being proved
+/// against the resident matrices.  (The C++ mirror of this file, `openzl::Groth16<E>::prove` in `csrc/zl_host.hip`, goes further and compares a
+/// digest of all rows, which it can cache per compiler object; here every proof consumes a fresh compiler, and hashing ~3 * 10^6 non-zeros per proof
+/// would cost half of the 19 ms a 958 465-constraint proof takes.)
 pub struct ProvingContext<E>
 where
     E: Mi355xEngine,
 {
-    /// The key as arkworks holds it (`ProvingContext<E>(pub ProvingKey<E>)`, groth16.rs:127-140)
+    /// The key as arkworks holds it
     pub key: ProvingKey<E>,
     keys: *mut ffi::zl_g16_keys,
     /// `zl_r1cs_upload` handle of the circuit this key was compiled for (0 until the first proof)
     r1cs: Cell<u64>,
+    /// shape of that circuit (all zero until the first proof)
+    shape: Cell<[usize; 4]>,
+}
+
+impl<E> ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    /// Builds a new [`ProvingContext`] from `proving_key` (`ProvingContext::new`, groth16.rs:131-139): the key goes to the device in the
+    /// reference's own wire format (`ProvingKey::serialize_unchecked`, what `ProvingContext: codec::Encode` writes, groth16.rs:166-179).
+    pub fn new(proving_key: ProvingKey<E>) -> Result<Self, Error> {
+        let mut bytes = Vec::new();
+        proving_key.serialize_unchecked(&mut bytes).map_err(|_| Error)?;
+        let mut keys = ptr::null_mut();
+        let rc = unsafe { ffi::zl_groth16_keys_from_bytes(ctx()?, E::CURVE, bytes.as_ptr(), bytes.len(), 0, &mut keys) };
+        if rc != ffi::ZL_OK {
+            return Err(Error);
+        }
+        Ok(Self { key: proving_key, keys, r1cs: Cell::new(0), shape: Cell::new([0; 4]) })
+    }
+}
+
+impl<E> Clone for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    /// A clone owns its own device copy of the key (and uploads the matrices again with its first proof): handles are never shared, so
+    /// either side can be dropped first.  Panics if the device refuses the upload (out of memory), as `Vec::clone` would.
+    fn clone(&self) -> Self {
+        Self::new(self.key.clone()).expect("device upload of a cloned proving key")
+    }
+}
+
+impl<E> core::fmt::Debug for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        f.debug_tuple("ProvingContext").field(&self.key).finish()
+    }
+}
+
+impl<E> PartialEq for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn eq(&self, other: &Self) -> bool {
+        self.key == other.key
+    }
+}
+impl<E> Eq for ProvingContext<E> where E: Mi355xEngine {}
+
+impl<E> CanonicalSerialize for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn serialize<W: Write>(&self, writer: W) -> Result<(), SerializationError> {
+        self.key.serialize(writer)
+    }
+    fn serialized_size(&self) -> usize {
+        self.key.serialized_size()
+    }
+    fn serialize_uncompressed<W: Write>(&self, writer: W) -> Result<(), SerializationError> {
+        self.key.serialize_uncompressed(writer)
+    }
+    fn serialize_unchecked<W: Write>(&self, writer: W) -> Result<(), SerializationError> {
+        self.key.serialize_unchecked(writer)
+    }
+    fn uncompressed_size(&self) -> usize {
+        self.key.uncompressed_size()
+    }
+}
+
+impl<E> CanonicalDeserialize for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn deserialize<R: Read>(reader: R) -> Result<Self, SerializationError> {
+        Self::new(ProvingKey::deserialize(reader)?).map_err(|_| SerializationError::InvalidData)
+    }
+    fn deserialize_uncompressed<R: Read>(reader: R) -> Result<Self, SerializationError> {
+        Self::new(ProvingKey::deserialize_uncompressed(reader)?).map_err(|_| SerializationError::InvalidData)
+    }
+    fn deserialize_unchecked<R: Read>(reader: R) -> Result<Self, SerializationError> {
+        Self::new(ProvingKey::deserialize_unchecked(reader)?).map_err(|_| SerializationError::InvalidData)
+    }
+}
+
+/// Same bytes as the reference's `ProvingContext: codec::Decode` (groth16.rs:142-164): `deserialize_unchecked` through `ArkReader`.
+impl<E> codec::Decode for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    type Error = SerializationError;
+
+    fn decode<R>(reader: R) -> Result<Self, DecodeError<R::Error, Self::Error>>
+    where
+        R: codec::Read,
+    {
+        let mut reader = ArkReader::new(reader);
+        match <ProvingKey<E> as CanonicalDeserialize>::deserialize_unchecked(&mut reader) {
+            Ok(key) => match reader.finish() {
+                Ok(_) => Self::new(key).map_err(|_| DecodeError::Decode(SerializationError::InvalidData)),
+                Err(err) => Err(DecodeError::Read(err)),
+            },
+            Err(err) => Err(DecodeError::Decode(err)),
+        }
+    }
+}
+
+/// Same bytes as the reference's `ProvingContext: codec::Encode` (groth16.rs:166-179): `serialize_unchecked` through `ArkWriter`.
+impl<E> codec::Encode for ProvingContext<E>
+where
+    E: Mi355xEngine,
+{
+    fn encode<W>(&self, writer: W) -> Result<(), W::Error>
+    where
+        W: codec::Write,
+    {
+        let mut writer = ArkWriter::new(writer);
+        let _ = self.key.serialize_unchecked(&mut writer);
+        writer.finish().map(move |_| ())
+    }
 }
 
 impl<E> Drop for ProvingContext<E>
@@ -121,15 +281,12 @@ where
     E: Mi355xEngine,
     E::Fq: PrimeField,
 {
-    fn g1(xy: &[u64], inf: u8) -> E::G1Affine
-    where
-        E::G1Affine: From<(E::Fq, E::Fq)>,
-    {
+    fn g1(xy: &[u64], inf: u8) -> E::G1Affine {
         if inf != 0 {
             return E::G1Affine::zero();
         }
         let n = E::FQ_LIMBS;
-        (fq_from_limbs::<E::Fq>(&xy[..n]), fq_from_limbs::<E::Fq>(&xy[n..2 * n])).into()
+        E::g1_from_xy(fq_from_limbs::<E::Fq>(&xy[..n]), fq_from_limbs::<E::Fq>(&xy[n..2 * n]))
     }
 }
 
@@ -137,8 +294,6 @@ impl<E> ProofSystem for Groth16Mi355x<E>
 where
     E: Mi355xEngine,
     E::Fq: PrimeField,
-    E::G1Affine: From<(E::Fq, E::Fq)>,
-    E::G2Affine: From<([E::Fq; 2], [E::Fq; 2])>,
 {
     type Compiler = R1CS<E::Fr>;
     type PublicParameters = ();
@@ -169,16 +324,9 @@ where
         let _ = public_parameters;
         // the trusted setup stays arkworks' (one-time per circuit; groth16.rs:438)
         let (key, verifying_key) = ArkGroth16::<E>::circuit_specific_setup(compiler, &mut SizedRng(rng)).map_err(|_| Error)?;
-        // ... and travels to the device in the reference's own wire format (ProvingKey::serialize_unchecked)
-        let mut bytes = Vec::new();
-        key.serialize_unchecked(&mut bytes).map_err(|_| Error)?;
-        let mut keys = ptr::null_mut();
-        let rc = unsafe { ffi::zl_groth16_keys_from_bytes(ctx()?, E::CURVE, bytes.as_ptr(), bytes.len(), 0, &mut keys) };
-        if rc != ffi::ZL_OK {
-            return Err(Error);
-        }
+        // ... and travels to the device in the reference's own wire format (ProvingContext::new above)
         Ok((
-            ProvingContext { key, keys, r1cs: Cell::new(0) },
+            ProvingContext::new(key)?,
             VerifyingContext(ArkGroth16::<E>::process_vk(&verifying_key).map_err(|_| Error)?),
         ))
     }
@@ -194,7 +342,16 @@ where
         cs.set_mode(SynthesisMode::Prove { construct_matrices: true });
         compiler.generate_constraints(cs.clone()).map_err(|_| Error)?;
         cs.finalize();
-        // the matrices are static per circuit: uploaded with the first proof, device-resident afterwards
+        // the matrices are static per circuit: uploaded with the first proof, device-resident afterwards.  Every later compiler must have the
+        // shape of the one they came from (see ProvingContext): counts are read off the constraint system, no matrix is rebuilt or hashed
+        let shape = {
+            let inner = cs.borrow().ok_or(Error)?;
+            // (the public counters of ark-relations 0.3.0's ConstraintSystem; its a / b / c_constraints vectors are private)
+            [inner.num_constraints, inner.num_instance_variables, inner.num_witness_variables, inner.num_linear_combinations]
+        };
+        if context.r1cs.get() != 0 && context.shape.get() != shape {
+            return Err(Error);
+        }
         if context.r1cs.get() == 0 {
             let m = cs.to_matrices().ok_or(Error)?;
             let csr = |rows: &Vec<Vec<(E::Fr, usize)>>| {
@@ -222,6 +379,7 @@ where
                 return Err(Error);
             }
             context.r1cs.set(handle);
+            context.shape.set(shape);
         }
         // assignment = instance block (ONE, public inputs) then witnesses, as arkworks' in-memory Montgomery limbs: E::Fr is a
         // single-field tuple struct over BigInteger256, itself a single-field tuple struct over [u64; 4]; ark-ff 0.3 declares no
@@ -265,7 +423,7 @@ where
         } else {
             // G2: x.c0 || x.c1 || y.c0 || y.c1 (zl_backend.h)
             let f = |k: usize| fq_from_limbs::<E::Fq>(&p.b[k * n..(k + 1) * n]);
-            ([f(0), f(1)], [f(2), f(3)]).into()
+            E::g2_from_xy(f(0), f(1), f(2), f(3))
         };
         Ok(Proof(ArkProof { a: Self::g1(&p.a, p.a_inf), b, c: Self::g1(&p.c, p.c_inf) }))
     }
@@ -282,7 +440,6 @@ pub fn msm_g1<E>(bases: u64, scalars: &[<E::Fr as PrimeField>::BigInt]) -> Resul
 where
     E: Mi355xEngine,
     E::Fq: PrimeField,
-    E::G1Affine: From<(E::Fq, E::Fq)>,
 {
     assert_eq!(core::mem::size_of::<<E::Fr as PrimeField>::BigInt>(), 32);
     let (mut xy, mut inf) = ([0u64; 12], 0u8);

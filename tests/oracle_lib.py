@@ -14,6 +14,9 @@ sys.path.insert(0, ORACLE_DIR)
 import pyoracle as po  # noqa: E402
 
 _LIB = None
+_NATIVE = False
+CFLAGS_PORTABLE = "-O3 -march=x86-64-v3 -fopenmp"
+CFLAGS_NATIVE = "-O3 -march=native -fopenmp"
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
 
@@ -26,12 +29,35 @@ def build_oracle(force: bool = False) -> str:
     return so
 
 
+def select_native() -> str:
+    """bench.py's cpu_baseline legs: (re)build the oracle ON THIS BOX with -march=native (BASELINE.md's flags) and make lib() load that copy; returns the
+    compiler flags in use.  Must be called before the first lib() of the process.  Falls back to the portable build when the box has no compiler.  The
+    native object is rebuilt whenever it was made on another machine (it is never trusted across boxes)."""
+    global _NATIVE
+    assert _LIB is None, "select_native() after the oracle was loaded"
+    so = os.path.join(ORACLE_DIR, "libzl_oracle_native.so")
+    stamp = so + ".host"
+    here = open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0] if os.path.exists("/proc/cpuinfo") and "model name" in open("/proc/cpuinfo").read() else "?"
+    try:
+        if not (os.path.exists(stamp) and open(stamp).read() == here):
+            if os.path.exists(so):
+                os.remove(so)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "native"])
+        with open(stamp, "w") as f:
+            f.write(here)
+        C.CDLL(so)  # loadable here?
+        _NATIVE = True
+        return CFLAGS_NATIVE
+    except (OSError, subprocess.CalledProcessError):
+        return CFLAGS_PORTABLE + " (native build failed on this box)"
+
+
 def lib():
     global _LIB
     if _LIB is None:
         so = build_oracle()
         try:
-            _LIB = C.CDLL(so)
+            _LIB = C.CDLL(os.path.join(ORACLE_DIR, "libzl_oracle_native.so") if _NATIVE else so)
         except OSError:
             so = build_oracle(force=True)
             _LIB = C.CDLL(so)

@@ -33,10 +33,25 @@ def test_bench_single_gpu_small():
     assert c["4"]["functional"] is True and c["4"]["checked_exactly"] is True
     assert isinstance(c["3"], str) and isinstance(c["5"], str)
     assert "leg_errors" not in d
+    assert d["scaling_model"] is None  # needs --log-n >= 22 (prefixes 2^21 .. 2^23 of the headline's inputs): covered by test_bench_scaling_model
+    ia = d["roofline"]["int_alu"]
+    assert 20 < ia["peak"] < 120 and ia["peak_constant_operands"] == 78.6 and ia["frac"] > ia["frac_vs_constant_operand_peak"] * 0.9
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_msm_accumulate"
     assert d["cpu_baseline"]["parity_full_size"] is True and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["ntt"]["cpu_baseline"]["parity_full_size"] is True and d["groth16"]["cpu_baseline"]["parity_full_size"] is True
     assert d["groth16"]["verified"] is True and d["msm_fixed_key"]["table_build_ms"] > 0
+
+
+def test_bench_scaling_model():
+    """N = 1 at 2^22: the line carries the single-GPU times of the 2^21 prefix (exact) and the model's fields; the 2^24-specific efficiencies need the
+    full size and are exercised by the driver's default run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "22", "--steps", "3", "--warmup", "1", "--no-ntt", "--groth16-k", "0", "--no-cpu", "--no-skew",
+                        "--fixed-key", "-1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    m = d["scaling_model"]
+    assert m["checked_exactly"] is True and m["measured_ms_per_msm_pipelined"]["2^21"] > 0 and m["measured_ms_per_msm_pipelined"]["2^22"] == d["ms_per_step"]
+    assert "PREDICTED" in m["note"] and "leg_errors" not in d
 
 
 def _check_two_rank_line(d):
@@ -47,7 +62,12 @@ def _check_two_rank_line(d):
     for name in ("weak", "config4", "strong"):
         e = legs[name]
         assert "error" not in e, e
-        assert e["checked_exactly"] is True and e["ms_per_step"] > 0 and e["points_per_s"] > 0 and e["per_gpu_efficiency"] > 0
+        assert e["checked_exactly"] is True and e["ms_per_step"] > 0 and e["points_per_s"] > 0 and e["interference_ratio"] > 0
+    # fixed-shard legs: the solo / all-rank ratio IS the weak-scaling efficiency; the strong leg carries T_1(total) / (N x T_N)
+    assert legs["weak"]["weak_scaling_efficiency"] == legs["weak"]["interference_ratio"] and "weak_scaling_efficiency" in legs["config4"]
+    st = legs["strong"]
+    assert "weak_scaling_efficiency" not in st and st["single_gpu_total_ms_per_step"] > 0
+    assert abs(st["strong_scaling_efficiency"] - st["single_gpu_total_ms_per_step"] / (2 * st["ms_per_step"])) < 1e-9
     assert legs["config4"]["points_total"] == 2 ** 18 and legs["strong"]["points_total"] == 2 ** 16
     # the one-process transport, timed by a child process; both test ranks share GPU 0, so the exchange runs on virtual ranks
     m = d["mctx"]

@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/fbench_f64.hip -o tools/fbench_f64
 #include "../openzl_amd/csrc/zl_field28.h"
 #include "mul_f64_gen.h"
+#include "mul28r_gen.h"
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -105,7 +106,37 @@ __global__ void k_chain_28(F* a, const F* b, int iters) {
     }
     a[i] = x;
 }
+struct F10 { uint32_t l[10]; uint32_t pad_[6]; };
+// butterfly-like step on 10 x 28-bit lazy limbs: t = y * w; (x, y) <- (x + t, x - t + 4r) with one carry pass each (values stay far below the 2^25 r the scan takes)
+__global__ void k_chain_fr28(F10* a, const F10* b, int iters, int mode) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    F10 x = a[i], y = b[i], w = b[i ^ 1];
+    for (int k = 0; k < iters; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (mode == 0) { F10 r = x; mul28r_asm<FR28P>(r.l, x.l, y.l); x = r; }
+        else {
+            F10 t = y; mul28r_asm<FR28P>(t.l, y.l, w.l);
+            F10 u = x, v = x;
+#pragma unroll
+            for (int j = 0; j < 10; j++) { u.l[j] = x.l[j] + t.l[j]; v.l[j] = x.l[j] + (j < 9 ? 0x20000000u : 0u) + 4u * FR28P::mod(j) - (j > 0 ? 2u : 0u) - t.l[j]; }
+#pragma unroll
+            for (int j = 0; j < 9; j++) { u.l[j + 1] += u.l[j] >> 28; u.l[j] &= 0xFFFFFFFu; v.l[j + 1] += v.l[j] >> 28; v.l[j] &= 0xFFFFFFFu; }
+            // keep the chain bounded for the benchmark: fold the top limb (values below 2^280 either way; the real kernel multiplies every other stage)
+            u.l[9] &= 0x3FFFFFu; v.l[9] &= 0x3FFFFFu;
+            x = u; y = v;
+        }
+#endif
+    }
+    a[i] = x;
+    if (mode) a[i].l[0] ^= y.l[0];
+}
 using Fr = Fp<BLS12_381_Fr>;
+__global__ void k_chain_fr32_bfly(Fr* a, const Fr* b, int iters) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr x = a[i], y = b[i], w = b[i ^ 1];
+    for (int k = 0; k < iters; k++) { Fr t = zl::mul(y, w); Fr u = zl::add(x, t); y = zl::sub(x, t); x = u; }
+    a[i] = zl::add(x, y);
+}
 __global__ void k_chain_fr32(Fr* a, const Fr* b, int iters) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     Fr x = a[i], y = b[i];
@@ -226,7 +257,8 @@ int main(int argc, char** argv) {
     }
     // ---- multiplier chains
     struct Leg { const char* name; int kind; };
-    const Leg legs[] = {{"Fq mul  FP64 8x49      ", 0}, {"Fq sqr  FP64 8x49      ", 1}, {"Fq mul  28-bit mad scan", 2}, {"Fq sqr  28-bit mad scan", 3}, {"Fr mul  FP64 6x44      ", 4}, {"Fr mul  8x32 carry     ", 5}};
+    const Leg legs[] = {{"Fq mul  FP64 8x49      ", 0}, {"Fq sqr  FP64 8x49      ", 1}, {"Fq mul  28-bit mad scan", 2}, {"Fq sqr  28-bit mad scan", 3}, {"Fr mul  FP64 6x44      ", 4}, {"Fr mul  8x32 carry     ", 5},
+                        {"Fr mul  10x28 mad scan ", 6}, {"Fr bfly 8x32 carry     ", 7}, {"Fr bfly 10x28 lazy     ", 8}};
     for (const Leg& leg : legs) for (int wps : {1, 2, 3, 4, 5}) {
         int threads = 64, blocks = prop.multiProcessorCount * 4 * wps;
         size_t n = (size_t)threads * blocks;
@@ -246,6 +278,12 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 13; k++) l[k] = (uint32_t)(sm64(seed) & 0xFFFFFFFu);
                 l[13] = (uint32_t)(sm64(seed) % A::mod(13));
             }
+        } else if (leg.kind == 6 || leg.kind == 8) {
+            for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
+                uint32_t* l = reinterpret_cast<uint32_t*>((side ? hb : ha).data() + i * 64);
+                for (int k = 0; k < 9; k++) l[k] = (uint32_t)(sm64(seed) & 0xFFFFFFFu);
+                l[9] = (uint32_t)(sm64(seed) & 0xFFFFu);
+            }
         } else {
             for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
                 uint32_t* l = reinterpret_cast<uint32_t*>((side ? hb : ha).data() + i * 32);
@@ -261,7 +299,10 @@ int main(int argc, char** argv) {
                 case 2: hipLaunchKernelGGL(k_chain_28<0>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
                 case 3: hipLaunchKernelGGL(k_chain_28<1>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
                 case 4: hipLaunchKernelGGL(k_chain_fr, dim3(blocks), dim3(threads), 0, 0, (D6*)a, (const D6*)b, it); break;
-                default: hipLaunchKernelGGL(k_chain_fr32, dim3(blocks), dim3(threads), 0, 0, (Fr*)a, (const Fr*)b, it); break;
+                case 5: hipLaunchKernelGGL(k_chain_fr32, dim3(blocks), dim3(threads), 0, 0, (Fr*)a, (const Fr*)b, it); break;
+                case 6: hipLaunchKernelGGL(k_chain_fr28, dim3(blocks), dim3(threads), 0, 0, (F10*)a, (const F10*)b, it, 0); break;
+                case 7: hipLaunchKernelGGL(k_chain_fr32_bfly, dim3(blocks), dim3(threads), 0, 0, (Fr*)a, (const Fr*)b, it); break;
+                default: hipLaunchKernelGGL(k_chain_fr28, dim3(blocks), dim3(threads), 0, 0, (F10*)a, (const F10*)b, it, 1); break;
             }
         };
         launch(4);

@@ -16,10 +16,13 @@ be.enable_timing(True)
 t0 = time.perf_counter(); circ = Circuit(ZL_BLS12_381, k); t1 = time.perf_counter()
 keys = Groth16Keys(be, circ, seed=1); t2 = time.perf_counter()
 print(f"synthesis {t1 - t0:.2f} s  setup {t2 - t1:.2f} s", flush=True)
-for _ in range(4):
+ts = []
+for _ in range(int(os.environ.get("ITERS", "4"))):
     t0 = time.perf_counter()
     keys.prove(seed=3)
-    print(f"prove {(time.perf_counter() - t0) * 1e3:.2f} ms (device {be.last_timing().total_ms:.2f})", flush=True)
+    ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"prove {ts[-1]:.2f} ms (device {be.last_timing().total_ms:.2f})", flush=True)
+print(f"prove k={k}: min {min(ts[1:] or ts):.2f}  median {sorted(ts[1:] or ts)[len(ts[1:] or ts) // 2]:.2f} ms over {len(ts[1:] or ts)} (first dropped)", flush=True)
 if os.environ.get("G16_WIRE"):
     # ProvingContext wire format at full size: encode (queries downloaded from the device), decode (upload + window tables), prove
     from openzl_amd import backend as zb
