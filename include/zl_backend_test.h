@@ -42,6 +42,12 @@ int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint3
  * not re-uploaded per proof): zl_groth16_prove_circuit returns ZL_EINVAL instead of proving against the wrong matrices. */
 int zl_test_circuit_tweak(zl_circuit* c);
 
+/* The lazily reduced 10 x 28-bit scalar field of the NTT passes (openzl_amd/csrc/zl_field28r.h), host (ctx == NULL) or device (inline-asm product scan).
+ * in: n records of two values a, b as 8 u32 words each (any value < 2^256); out: n x 8 words, always the canonical result.  j = log2 of the bias
+ * multiple of r used by the subtractions (0..20).  op: 0 mul(a, b) (= a b 2^-280 mod r)  1 a + b  2 a - b  3 canon(a)  4 a chain of lazy
+ * additions / biased subtractions at the bounds the passes reach, closed by one product (zl_testhooks.hip). */
+int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out);
+
 /* MEASUREMENT ONLY (bench.py's integer-ALU roofline): chains of the accumulation kernel's 14 x 28-bit Montgomery product on per-lane pseudo-random
  * operands, cu_count x 4 x waves_per_simd wavefronts, `iters` products per lane; returns 10^9 products per second.  This is the live-data ceiling of
  * the multiplier on the box of the run (constant-pattern operands clock 15-20 % higher; profiles/r04_fbench_f64.log). */

@@ -148,6 +148,7 @@ def load_library(path: Optional[str] = None):
     L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_circuit_tweak.argtypes = [vp]
     L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.zl_test_fr28_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     if path is None:
         _lib = L
     return L
@@ -397,7 +398,7 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
 
 
 def _p32(a: np.ndarray):
@@ -433,6 +434,18 @@ def hook_point_op(be: Optional["Backend"], group: int, hot: bool, op: int, pq: n
     rc = L.zl_test_point_op(be._ctx if be is not None else None, group, int(hot), op, _p32(a), n, _p32(out))
     if rc:
         raise BackendError(rc, "zl_test_point_op")
+    return out
+
+
+def hook_fr28_op(be: Optional["Backend"], curve: int, op: int, ab: np.ndarray, j: int = 2) -> np.ndarray:
+    """ab: (n, 2, 8) uint32 words of two values < 2^256 -> (n, 8) canonical result words; be = None runs the host code path"""
+    a = np.ascontiguousarray(ab, dtype=np.uint32)
+    n = a.shape[0]
+    out = np.zeros((n, 8), dtype=np.uint32)
+    L = load_library()
+    rc = L.zl_test_fr28_op(be._ctx if be is not None else None, curve, op, j, _p32(a), n, _p32(out))
+    if rc:
+        raise BackendError(rc, "zl_test_fr28_op")
     return out
 
 

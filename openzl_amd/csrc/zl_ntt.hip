@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 #include "zl_ctx.h"
+#include "zl_field28r.h"
 
 // first / last two-stage round fused with the global loads / stores (measured, 2^24: no gain over staging through LDS: the fused kernel needs
 // 145-158 VGPRs, one workgroup per CU, 3.0 ms; capped at 128 VGPRs it spills and ties with the unfused form at 2.6 ms)
@@ -38,6 +39,7 @@ struct NttArgs {
     const void *t_lo, *t_hi;  // w^lo, w^(hi << L)
     const void* w_small;      // w_(2^s)^i, i < 2^(s-1)
     const void *g_lo, *g_hi;  // coset powers (hi table carries n^-1 for the inverse)
+    const void* row_tw;       // middle pass (lazy form): w_N^((r K0(hi)) << shift) for every (hi, r), hi = the tile's high index (or null: combined per tile)
     const void* last_tw;      // last pass of a multi-pass transform: the complete inter-factor twiddle of every element, in load order (or null)
     uint32_t ninv[8];
 };
@@ -263,6 +265,323 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_pass(const Fp<FrP>* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the passes on lazily reduced 28-bit limbs
+// Round 4: the same pass with the tile held as 10 x 28-bit lazily reduced elements (zl_field28r.h).  A butterfly addition is ten
+// v_add_u32 and a carry pass, a subtraction adds a biased multiple 2^j r of the modulus first (no comparison anywhere between two multiplications), a
+// product is a carry-free chain of 210 v_mad_u64_u32 under the Montgomery radix R' = 2^280 -- of the MULTIPLIER only: the data keeps the caller's form
+// (canonical or R = 2^256 Montgomery; mul(x, w R') = x w), so a canonical -> canonical transform needs no conversion multiplications at all, and the
+// tables hold w R' mod r (built in the 32-bit field, converted once: k_ntt_to_lazy).  Global memory keeps its 32-byte elements: unpack on load; on store a
+// weak reduction from the top limb (< 2r < 2^256) between passes and the canonical form at the end.
+// Bounds: two-stage round r of a pass enters with every element below B_r r; its subtractions use K1 = 2^j r >= (B_r + 2) r (first stage; also the
+// second stage's a2 - a3, whose subtrahend is a product < 2r) and K2 >= (2 B_r + 2) r (second stage's a0 - a1); B_(r+1) = max(4 B_r, B_r + K1 + 4, 2 B_r + K2)
+// <= 6 B_r + 7: five rounds from B = 6 stay below 2^16 (the multiplier takes 2^25, the top limb 2^29).  The host simulates this and passes the biases.
+#define NTT28_THREADS 256
+#define NTT28_TILE 1024
+template <class FrP> struct Fr28Of;
+template <> struct Fr28Of<BLS12_381_Fr> { using type = BLS12_381_Fr28; };
+template <> struct Fr28Of<BN254_Fr> { using type = BN254_Fr28; };
+// bias exponents per two-stage round of a pass (round 0 enters with B = 6: a caller's canonical-or-not 256-bit input is below 5.3 r, a product below 2 r)
+struct Ntt28Plan {
+    int j1[6], j2[6];              // K1 = 2^j1 r >= (B + 2) r, K2 = 2^j2 r >= (2 B + 2) r; the single last stage of an odd s uses K1 of its round index
+    unsigned long long bound[7];   // B entering round r
+};
+constexpr Ntt28Plan ntt28_plan() {
+    Ntt28Plan p{};
+    unsigned long long B = 6;
+    for (int r = 0; r < 6; r++) {
+        p.bound[r] = B;
+        int j1 = 0, j2 = 0;
+        while ((1ull << j1) < B + 2) j1++;
+        while ((1ull << j2) < 2 * B + 2) j2++;
+        p.j1[r] = j1;
+        p.j2[r] = j2;
+        const unsigned long long b1 = 4 * B, b2 = B + (1ull << j1) + 4, b3 = 2 * B + (1ull << j2);
+        B = b1 > b2 ? (b1 > b3 ? b1 : b3) : (b2 > b3 ? b2 : b3);
+    }
+    p.bound[6] = B;
+    return p;
+}
+constexpr Ntt28Plan NTT28_PLAN = ntt28_plan();
+static_assert(NTT28_PLAN.bound[5] < (1ull << 16) && NTT28_PLAN.j2[4] <= 20 && NTT28_PLAN.j1[5] <= 20, "lazy NTT bounds: five rounds (s <= 10) stay far below the multiplier's 2^25 and wred's 2^20");
+// the exponents are linear in the round index, which is how the kernel computes them (a runtime index into a host constexpr object is not device code)
+constexpr bool ntt28_plan_is_linear() {
+    for (int r = 0; r < 6; r++)
+        if (NTT28_PLAN.j1[r] != 3 + 2 * r || NTT28_PLAN.j2[r] != 4 + 2 * r) return false;
+    return true;
+}
+static_assert(ntt28_plan_is_linear(), "k_ntt_pass28 computes j1 = 3 + 2 r, j2 = 4 + 2 r");
+template <class P28>
+__device__ __forceinline__ void load_bias28(uint32_t (&K)[10], int j) {  // uniform: constant-memory lookups
+#pragma unroll
+    for (int i = 0; i < 10; i++) K[i] = P28::kq(j, i);
+}
+template <class E>
+__device__ __forceinline__ E lds_load28(const uint32_t* sh, uint32_t pos) {
+    E r;
+#pragma unroll
+    for (int k = 0; k < 10; k++) r.l[k] = sh[k * NTT28_TILE + pos];
+    return r;
+}
+template <class E>
+__device__ __forceinline__ void lds_store28(uint32_t* sh, uint32_t pos, const E& v) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) sh[k * NTT28_TILE + pos] = v.l[k];
+}
+template <class P28>
+__device__ __forceinline__ Fr28<P28> load28(const void* __restrict__ base, uint64_t idx) {  // one 32-byte element -> 10 limbs
+    const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * idx;
+    const uint4 lo = p[0], hi = p[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return zl::unpack28r<P28>(w);
+}
+template <class P28>
+__device__ __forceinline__ Fr28<P28> twiddle2_28(const void* lo, const void* hi, uint32_t L, uint64_t e) {
+    return zl::mul(load28<P28>(lo, e & ((1ull << L) - 1)), load28<P28>(hi, e >> L));
+}
+template <class P28, class WordsFn>
+__device__ __forceinline__ Fr28<P28> const28(WordsFn f) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = f(i);
+    return zl::unpack28r<P28>(w);
+}
+
+template <class FrP, bool LAST>
+__global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
+    using P28 = typename Fr28Of<FrP>::type;
+    using E = Fr28<P28>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                          // [10][NTT28_TILE]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t s = a.s, logC = a.logC, R = 1u << s, C = 1u << logC;
+    E* sh_w = reinterpret_cast<E*>(smem + (size_t)10 * 4 * NTT28_TILE);         // [2^(s-1)] butterfly roots
+    E* sh_row = sh_w + (R >> 1);                                                // [2^s] per-row twiddles (non-last passes)
+    const uint32_t n_log = a.n_log;
+
+    // ---- tile addressing (as k_ntt_pass) --------------------------------------------------------------------
+    uint64_t in_base, out_base, in_row, in_col, out_row;
+    uint64_t K0 = 0, tile_hi = 0;
+    {
+        const uint64_t tile = blockIdx.x;
+        if (!LAST) {
+            const uint32_t stride_log = n_log - a.S_prev - s;
+            const uint64_t lo_blocks = (1ull << stride_log) >> logC;
+            const uint64_t hi = tile / lo_blocks, lo0 = (tile % lo_blocks) << logC;
+            tile_hi = hi;
+            in_base = (hi << (s + stride_log)) + lo0;
+            out_base = in_base;
+            in_row = 1ull << stride_log;
+            in_col = 1;
+            out_row = in_row;
+            uint64_t rem = hi;
+            uint32_t Sq = a.S_prev;
+            for (int q = (int)a.p - 2; q >= 0; q--) {
+                Sq -= a.sizes[q];
+                K0 += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+                rem >>= a.sizes[q];
+            }
+        } else if (a.P == 1) {
+            in_base = out_base = 0;
+            in_row = out_row = 1;
+            in_col = 1;
+        } else {
+            const uint32_t s1 = a.sizes[0];
+            const uint32_t rest_log = a.S_prev - s1;
+            const uint64_t k1_blocks = (1ull << s1) >> logC;
+            const uint64_t k1_0 = (tile % k1_blocks) << logC, rest = tile / k1_blocks;
+            in_base = ((k1_0 << rest_log) + rest) << s;
+            in_col = 1ull << (rest_log + s);
+            in_row = 1;
+            uint64_t rem = rest, Krest = 0;
+            uint32_t Sq = a.S_prev;
+            for (int q = (int)a.P - 2; q >= 1; q--) {
+                Sq -= a.sizes[q];
+                Krest += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+                rem >>= a.sizes[q];
+            }
+            K0 = k1_0 + Krest;
+            out_base = K0;
+            out_row = 1ull << a.S_prev;
+        }
+    }
+    // ---- stage the small tables (unpacked once per tile) ----------------------------------------------------
+    {
+        for (uint32_t i = tid; i < (R >> 1); i += NTT28_THREADS) sh_w[i] = load28<P28>(a.w_small, i);
+        if (!LAST && a.p > 1) {
+            // the row twiddles depend on the tile's high index only: tabulated once per (size, direction) (k_ntt_row_table28) -- a tile of 1024 elements
+            // would otherwise pay 2^s products for them (measured: the middle pass of 2^24 0.92 ms against 0.85 for the 32-bit kernel's 2048-element tiles)
+            if (a.row_tw) {
+                for (uint32_t r = tid; r < R; r += NTT28_THREADS) sh_row[r] = load28<P28>(a.row_tw, (tile_hi << s) + r);
+            } else {
+                const uint32_t shift = n_log - a.S_prev - s;
+                for (uint32_t r = tid; r < R; r += NTT28_THREADS) sh_row[r] = twiddle2_28<P28>(a.t_lo, a.t_hi, a.L, ((uint64_t)r * K0) << shift);
+            }
+        }
+    }
+    __syncthreads();
+    auto load_elem = [&](uint32_t r, uint32_t col) -> E {
+        const uint64_t m = in_base + (uint64_t)r * in_row + (uint64_t)col * in_col;
+        E x = load28<P28>(in, m);
+        if (a.p == 1) {
+            if (a.to_mont) x = zl::mul(x, const28<P28>([](int i) { return P28::to_mont(i); }));
+            if (a.pre_coset) x = zl::mul(x, twiddle2_28<P28>(a.g_lo, a.g_hi, a.L, m));
+        } else if (!LAST) {
+            x = zl::mul(x, sh_row[r]);
+        } else if (a.last_tw) {
+            x = zl::mul(x, load28<P28>(a.last_tw, m));
+        } else {
+            x = zl::mul(x, twiddle2_28<P28>(a.t_lo, a.t_hi, a.L, (uint64_t)r * (K0 + col)));
+        }
+        return x;
+    };
+    auto store_elem = [&](uint32_t k, uint32_t col, E x) {
+        const uint64_t m = out_base + (uint64_t)k * out_row + col;
+        if (LAST) {
+            if (a.post_coset) {
+                x = zl::mul(x, twiddle2_28<P28>(a.g_lo, a.g_hi, a.L, m));
+            } else if (a.post_scale) {
+                uint32_t w[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = a.ninv[i];
+                x = zl::mul(x, zl::unpack28r<P28>(w));
+            }
+            if (a.from_mont) x = zl::mul(x, const28<P28>([](int i) { return P28::from_mont(i); }));
+            x = zl::canon(x);
+        } else {
+            x = zl::wred(x);  // < 2r: fits the 32-byte element of the scratch vector
+        }
+        uint32_t w[8];
+        zl::pack28r<P28>(w, x);
+        uint4* q = reinterpret_cast<uint4*>(out) + 2 * m;
+        q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    };
+    uint32_t K1[10], K2[10], K3[10];
+    load_bias28<P28>(K3, 2);  // 4 r: a2 - a3 (a3 is always a product, < 2r)
+    auto quad = [&](E& x0, E& x1, E& x2, E& x3, uint32_t k2, uint32_t hl) {
+        const uint32_t h2 = 1u << hl, sh1 = s - 2 - hl;
+        // carry passes only where a value becomes a subtrahend or goes back to LDS (3 per quad instead of 8): everything else feeds a product or the
+        // minuend side of a biased subtraction with fat limbs (< 2^31; zl_field28r.h)
+        const E a0 = zl::add_nc(x0, x2), a1 = zl::add(x1, x3);
+        E a2 = zl::subk_nc(x0, x2, K1);
+        if (k2 != 0) a2 = zl::mul(a2, sh_w[k2 << sh1]);
+        const E a3 = zl::mul(zl::subk_nc(x1, x3, K1), sh_w[(k2 + h2) << sh1]);
+        x0 = zl::add(a0, a1);
+        x2 = zl::add(a2, a3);
+        x1 = zl::subk_nc(a0, a1, K2);
+        x3 = zl::subk_nc(a2, a3, K3);
+        if (k2 != 0) {
+            const E w = sh_w[k2 << (sh1 + 1)];
+            x1 = zl::mul(x1, w);
+            x3 = zl::mul(x3, w);
+        } else {
+            zl::carry28r(x1);
+            zl::carry28r(x3);
+        }
+    };
+    for (uint32_t idx = tid; idx < R * C; idx += NTT28_THREADS) {
+        const uint32_t col = idx & (C - 1), r = idx >> logC;
+        lds_store28(sh, tile_pos(r, col, logC), load_elem(r, col));
+    }
+    __syncthreads();
+    uint32_t hl = s, rd = 0;
+    while (hl >= 2u) {
+        hl -= 2;
+        const uint32_t h2 = 1u << hl, h = h2 << 1;
+        load_bias28<P28>(K1, 3 + 2 * (int)rd);
+        load_bias28<P28>(K2, 4 + 2 * (int)rd);
+        rd++;
+        for (uint32_t q = tid; q < (R >> 2) * C; q += NTT28_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t k2 = rr & (h2 - 1), blk = rr >> hl;
+            const uint32_t i0 = (blk << (hl + 2)) | k2;
+            const uint32_t p0 = tile_pos(i0, col, logC), p1 = tile_pos(i0 + h2, col, logC), p2 = tile_pos(i0 + h, col, logC),
+                           p3 = tile_pos(i0 + h + h2, col, logC);
+            E x0 = lds_load28<E>(sh, p0), x1 = lds_load28<E>(sh, p1), x2 = lds_load28<E>(sh, p2), x3 = lds_load28<E>(sh, p3);
+            quad(x0, x1, x2, x3, k2, hl);
+            lds_store28(sh, p0, x0);
+            lds_store28(sh, p1, x1);
+            lds_store28(sh, p2, x2);
+            lds_store28(sh, p3, x3);
+        }
+        __syncthreads();
+    }
+    if (hl == 1) {  // odd s: the last stage (distance 1) on its own
+        load_bias28<P28>(K1, 3 + 2 * (int)rd);
+        for (uint32_t q = tid; q < (R >> 1) * C; q += NTT28_THREADS) {
+            const uint32_t col = q & (C - 1), rr = q >> logC;
+            const uint32_t i = rr << 1;
+            const uint32_t pu = tile_pos(i, col, logC), pv = tile_pos(i + 1, col, logC);
+            const E u = lds_load28<E>(sh, pu), v = lds_load28<E>(sh, pv);
+            lds_store28(sh, pu, zl::add(u, v));
+            lds_store28(sh, pv, zl::subk(u, v, K1));
+        }
+        __syncthreads();
+    }
+    for (uint32_t idx = tid; idx < R * C; idx += NTT28_THREADS) {
+        const uint32_t col = idx & (C - 1), k = idx >> logC;
+        const uint32_t row = s ? (__brev(k) >> (32 - s)) : 0;
+        store_elem(k, col, lds_load28<E>(sh, tile_pos(row, col, logC)));
+    }
+}
+// tables of the lazy passes: every entry x R (32-bit Montgomery form, as the table kernels write it) becomes the canonical integer x R' mod r
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_to_lazy(Fp<FrP>* __restrict__ table, size_t count) {
+    using F = Fp<FrP>;
+    using P28 = typename Fr28Of<FrP>::type;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    F rp;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) rp.l[k] = P28::rp(k);
+    table[i] = zl::mul(table[i], rp);  // (x R)(R') / R = x R', reduced below r
+}
+// the combined twiddles of the last pass (k_ntt_last_table) in the lazy multiplier's form
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_last_table28(Fp<FrP>* __restrict__ table, NttArgs a) {
+    using P28 = typename Fr28Of<FrP>::type;
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >> a.n_log) return;
+    const uint32_t s = a.s, s1 = a.sizes[0], rest_log = a.S_prev - s1;
+    const uint64_t r = m & ((1ull << s) - 1), rest = (m >> s) & ((1ull << rest_log) - 1), k1 = m >> (s + rest_log);
+    uint64_t rem = rest, Krest = 0;
+    uint32_t Sq = a.S_prev;
+    for (int q = (int)a.P - 2; q >= 1; q--) {
+        Sq -= a.sizes[q];
+        Krest += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+        rem >>= a.sizes[q];
+    }
+    const Fr28<P28> t = zl::canon(twiddle2_28<P28>(a.t_lo, a.t_hi, a.L, r * (k1 + Krest)));
+    uint32_t w[8];
+    zl::pack28r<P28>(w, t);
+    uint4* q = reinterpret_cast<uint4*>(table) + 2 * m;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// the per-row twiddles of a middle pass for every value of the tile's high index: table[(hi << s) + r] = w_N^((r K0(hi)) << shift), K0 as in k_ntt_pass28
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_row_table28(Fp<FrP>* __restrict__ table, NttArgs a) {
+    using P28 = typename Fr28Of<FrP>::type;
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >> (a.S_prev + a.s)) return;
+    const uint64_t r = m & ((1ull << a.s) - 1), hi = m >> a.s;
+    uint64_t rem = hi, K0 = 0;
+    uint32_t Sq = a.S_prev;
+    for (int q = (int)a.p - 2; q >= 0; q--) {
+        Sq -= a.sizes[q];
+        K0 += (rem & ((1ull << a.sizes[q]) - 1)) << Sq;
+        rem >>= a.sizes[q];
+    }
+    const uint32_t shift = a.n_log - a.S_prev - a.s;
+    const Fr28<P28> t = zl::canon(twiddle2_28<P28>(a.t_lo, a.t_hi, a.L, (r * K0) << shift));
+    uint32_t w[8];
+    zl::pack28r<P28>(w, t);
+    uint4* q = reinterpret_cast<uint4*>(table) + 2 * m;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 // table[i] = scale * base^(i << shift), i < count
 template <class FrP>
 __global__ void __launch_bounds__(256) k_ntt_pow_table(Fp<FrP>* __restrict__ table, uint32_t count, uint32_t shift, Fp<FrP> base, Fp<FrP> scale) {
@@ -326,10 +645,12 @@ static NttPlan ntt_plan(unsigned n) {
     return pl;
 }
 
+// lazy: the tables of the 28-bit passes (entries w R' mod r as canonical integers) -- a separate set: the distributed transform's cross kernel
+// (k_ntt_cross) keeps the 32-bit field and its Montgomery tables
 template <class FrP>
-static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twiddles** out) {
+static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twiddles** out, bool lazy = false) {
     using F = Fp<FrP>;
-    const uint64_t key = ((uint64_t)curve << 16) | ((uint64_t)n << 1) | (inverse ? 1 : 0);
+    const uint64_t key = ((uint64_t)curve << 16) | (lazy ? 0x100u : 0u) | ((uint64_t)n << 1) | (inverse ? 1 : 0);
     auto it = ctx->twiddles.find(key);
     if (it != ctx->twiddles.end()) { *out = &it->second; return ZL_OK; }
     // root of unity of order 2^n (host)
@@ -371,6 +692,7 @@ static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twidd
         const uint32_t cnt = 1u << (s - 1);
         hipLaunchKernelGGL((k_ntt_pow_table<FrP>), dim3((cnt + 255) / 256), dim3(256), 0, st, small + cnt, cnt, n - s, w, one);
     }
+    if (lazy) hipLaunchKernelGGL((k_ntt_to_lazy<FrP>), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, d, total);
     ZL_HIP(ctx, hipGetLastError());
     tw.d_lo = t_lo;
     tw.d_hi = t_hi;
@@ -392,9 +714,11 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         if (mont_in != mont_out) return ZL_EINVAL;
         return ZL_OK;
     }
+    // Round 4: the passes run on lazily reduced 28-bit limbs (k_ntt_pass28) unless ZL_NTT_NO_LAZY is set (developer A/B switch; the 32-bit passes stay)
+    static const bool lazy = getenv("ZL_NTT_NO_LAZY") == nullptr;
     zl_twiddles* tw;
     int rc;
-    if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw))) return rc;
+    if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw, lazy))) return rc;
     const NttPlan pl = ntt_plan(n);
     const size_t N = (size_t)1 << n;
     F* data = reinterpret_cast<F*>(d_data);
@@ -411,10 +735,18 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     const F* g_hi = g_lo + ((size_t)1 << L);
     const F* small = reinterpret_cast<const F*>(tw->d_small);
     F ninv = zl::inv(zl::from_u64<FrP>(1ull << n));
+    if (lazy) {  // n^-1 R -> n^-1 R' (canonical), the multiplier form of the lazy passes
+        using P28 = typename Fr28Of<FrP>::type;
+        F rp;
+        for (int k = 0; k < F::N; k++) rp.l[k] = P28::rp(k);
+        ninv = zl::mul(ninv, rp);
+    }
     hipStream_t st = ctx->stream;
     // tiles + tables can exceed the 64 KiB default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so set per call
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     uint32_t S_prev = 0;
     for (uint32_t p = 1; p <= pl.P; p++) {
@@ -433,8 +765,10 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         a.g_hi = g_hi;
         a.w_small = small + ((size_t)1 << (a.s ? a.s - 1 : 0));
         a.to_mont = (p == 1 && !mont_in) ? 1 : 0;
+        if (lazy) a.to_mont = (p == 1 && !mont_in && mont_out) ? 1 : 0;  // the data keeps its form: a conversion only when the caller asks for one
         a.pre_coset = (p == 1 && coset && !inverse) ? 1 : 0;
         a.from_mont = (last && !mont_out) ? 1 : 0;
+        if (lazy) a.from_mont = (last && mont_in && !mont_out) ? 1 : 0;
         a.post_coset = (last && coset && inverse) ? 1 : 0;
         a.post_scale = (last && inverse && !coset) ? 1 : 0;
         if (a.post_scale && pl.P > 1) {  // n^-1 rides on the last pass's twiddles (ntt_tables)
@@ -463,7 +797,8 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
                 void* t = nullptr;
                 if (ctx->ntt_last_bytes + want <= budget && hipMalloc(&t, want) == hipSuccess) {
                     a.last_tw = nullptr;
-                    hipLaunchKernelGGL((k_ntt_last_table<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
+                    if (lazy) hipLaunchKernelGGL((k_ntt_last_table28<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
+                    else hipLaunchKernelGGL((k_ntt_last_table<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
                     tw->d_last = t;
                     tw->last_bytes = want;
                     ctx->ntt_last_bytes += want;
@@ -474,21 +809,41 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
             if (tw->d_last) tw->last_used = ++ctx->ntt_clock;
             a.last_tw = tw->d_last;
         }
+        if (lazy && !last && p > 1 && p <= 4 && S_prev + a.s <= 20) {  // middle pass: its row twiddles per tile high index, <= 32 MB, kept with the tables
+            if (!tw->d_row[p - 1]) {
+                void* t = nullptr;
+                if (hipMalloc(&t, (sizeof(F)) << (S_prev + a.s)) == hipSuccess) {
+                    const uint64_t cnt = 1ull << (S_prev + a.s);
+                    hipLaunchKernelGGL((k_ntt_row_table28<FrP>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
+                    tw->d_row[p - 1] = t;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            a.row_tw = tw->d_row[p - 1];
+        }
         // columns per tile
         uint32_t cols_avail_log;
         if (pl.P == 1) cols_avail_log = 0;
         else if (!last) cols_avail_log = n - S_prev - a.s;
         else cols_avail_log = pl.sizes[0];
-        uint32_t logC = 11 - a.s;  // NTT_TILE = 2^11
-        if (a.s > 11) return ZL_EINVAL;
+        uint32_t logC = (lazy ? 10 : 11) - a.s;  // NTT_TILE = 2^11, NTT28_TILE = 2^10
+        if (a.s > 10) return ZL_EINVAL;
         if (logC > cols_avail_log) logC = cols_avail_log;
         a.logC = logC;
         const uint64_t tiles = (uint64_t)N >> (a.s + logC);
-        const size_t lds = (size_t)F::N * 4 * NTT_TILE + sizeof(F) * (((size_t)1 << a.s) / 2 + ((size_t)1 << a.s));
         const F* src = (p == 1) ? data : scratch;
         F* dst = last ? data : scratch;
+        if (lazy) {
+            // tile + butterfly roots (+ the per-row twiddles of a middle pass): 45 KB at s = 8 -> three workgroups per CU (55 KB, two, for a middle pass)
+            const size_t lds28 = (size_t)10 * 4 * NTT28_TILE + (size_t)40 * (((size_t)1 << a.s) / 2 + ((!last && p > 1) ? ((size_t)1 << a.s) : 0));
+            if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+            else hipLaunchKernelGGL((k_ntt_pass28<FrP, false>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+        } else {
+        const size_t lds = (size_t)F::N * 4 * NTT_TILE + sizeof(F) * (((size_t)1 << a.s) / 2 + ((size_t)1 << a.s));
         if (last) hipLaunchKernelGGL((k_ntt_pass<FrP, true>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
         else hipLaunchKernelGGL((k_ntt_pass<FrP, false>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
+        }
         S_prev += a.s;
     }
     ZL_HIP(ctx, hipGetLastError());
@@ -659,6 +1014,7 @@ void zl_ntt_free(zl_ctx* ctx) {
     for (auto& kv : ctx->twiddles) {
         if (kv.second.d_lo) (void)hipFree(kv.second.d_lo);
         if (kv.second.d_last) (void)hipFree(kv.second.d_last);
+        for (void* r : kv.second.d_row) if (r) (void)hipFree(r);
     }
     ctx->twiddles.clear();
     ctx->ntt_last_bytes = 0;

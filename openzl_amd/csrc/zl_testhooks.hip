@@ -5,6 +5,7 @@
 #include "../../include/zl_backend_test.h"
 #include "zl_ctx.h"
 #include "zl_host.h"
+#include "zl_field28r.h"
 
 using namespace openzl;
 
@@ -134,6 +135,44 @@ static __global__ void __launch_bounds__(64) k_test_fp28(int op, const uint32_t*
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fp28_op(op, in + (size_t)i * 56, out + (size_t)i * 14);
+}
+
+
+// ------------------------------------------------------------------------------------------------ the lazy 10 x 28-bit scalar field (zl_field28r.h)
+// in: records of two 8-word values a, b (< 2^256); out: 8 words (the canonical result, packed).  `j` selects the bias 2^j r of the subtractions.
+//   0 canon(mul(a, b))   1 canon(add(a, b))   2 canon(subk(a, b, 2^j r))   3 canon(a)
+//   4 a lazy chain at the bounds the NTT passes reach: x = a; four times { u = x + x; v = x - b' + 2^j r; x = u + v } with b' = mul(b, b), then canon(mul(x, b))
+template <class P>
+ZL_HD static void fr28_op(int op, int j, const uint32_t* in, uint32_t* out) {
+    using E = Fr28<P>;
+    const E a = zl::unpack28r<P>(in), b = zl::unpack28r<P>(in + 8);
+    uint32_t K[10];
+    for (int i = 0; i < 10; i++) K[i] = P::kq(j, i);
+    E r = a;
+    switch (op) {
+    case 0: r = zl::canon(zl::mul(a, b)); break;
+    case 1: r = zl::canon(zl::add(a, b)); break;
+    case 2: r = zl::canon(zl::subk(a, b, K)); break;
+    case 3: r = zl::canon(a); break;
+    case 4: {
+        const E bb = zl::mul(b, b);  // < 2r
+        E x = a;
+        for (int k = 0; k < 4; k++) {
+            const E u = zl::add(x, x), v = zl::subk(x, bb, K);
+            x = zl::add(u, v);
+        }
+        r = zl::canon(zl::mul(x, b));
+        break;
+    }
+    default: break;
+    }
+    zl::pack28r<P>(out, r);
+}
+template <class P>
+static __global__ void __launch_bounds__(64) k_test_fr28(int op, int j, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr28_op<P>(op, j, in + (size_t)i * 16, out + (size_t)i * 8);
 }
 
 template <class F> struct RawIO;
@@ -269,6 +308,25 @@ int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint3
         if (group == ZL_G1) hipLaunchKernelGGL((k_test_point<F28>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
         else if (hot) hipLaunchKernelGGL((k_test_point<Fp2LT<F28, true>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
         else hipLaunchKernelGGL((k_test_point<Fp2LT<F28, false>>), grid, block, 0, st, op, d_in, (uint32_t)n, d_out);
+    });
+}
+
+int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out) {
+    if ((!in || !out) && n) return ZL_EINVAL;
+    if (op < 0 || op > 4 || j < 0 || j > 20 || n >= (1u << 24) || (curve != ZL_BLS12_381 && curve != ZL_BN254)) return ZL_EINVAL;
+    if (!n) return ZL_OK;
+    if (!ctx) {
+        for (size_t i = 0; i < n; i++) {
+            if (curve == ZL_BLS12_381) fr28_op<BLS12_381_Fr28>(op, j, in + i * 16, out + i * 8);
+            else fr28_op<BN254_Fr28>(op, j, in + i * 16, out + i * 8);
+        }
+        return ZL_OK;
+    }
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return run_dev(ctx, in, n * 16, out, n * 8, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
+        const dim3 grid((uint32_t)((n + 63) / 64)), block(64);
+        if (curve == ZL_BLS12_381) hipLaunchKernelGGL((k_test_fr28<BLS12_381_Fr28>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
+        else hipLaunchKernelGGL((k_test_fr28<BN254_Fr28>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
     });
 }
 
