@@ -334,6 +334,26 @@ __device__ __forceinline__ Fr28<P28> load28(const void* __restrict__ base, uint6
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return zl::unpack28r<P28>(w);
 }
+// the scratch vector between two lazy passes holds the ten limbs as they are (40 bytes per element, carried, bound as the pass left it): no weak
+// reduction, no packing on the way out and no unpacking on the way in (90 instructions per element and pass boundary)
+template <class P28>
+__device__ __forceinline__ Fr28<P28> load40(const void* __restrict__ base, uint64_t idx) {
+    const uint2* p = reinterpret_cast<const uint2*>(base) + 5 * idx;
+    Fr28<P28> r;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint2 v = p[k];
+        r.l[2 * k] = v.x;
+        r.l[2 * k + 1] = v.y;
+    }
+    return r;
+}
+template <class P28>
+__device__ __forceinline__ void store40(void* __restrict__ base, uint64_t idx, const Fr28<P28>& x) {
+    uint2* p = reinterpret_cast<uint2*>(base) + 5 * idx;
+#pragma unroll
+    for (int k = 0; k < 5; k++) p[k] = make_uint2(x.l[2 * k], x.l[2 * k + 1]);
+}
 template <class P28>
 __device__ __forceinline__ Fr28<P28> twiddle2_28(const void* lo, const void* hi, uint32_t L, uint64_t e) {
     return zl::mul(load28<P28>(lo, e & ((1ull << L) - 1)), load28<P28>(hi, e >> L));
@@ -355,7 +375,7 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
     const uint32_t tid = threadIdx.x;
     const uint32_t s = a.s, logC = a.logC, R = 1u << s, C = 1u << logC;
     E* sh_w = reinterpret_cast<E*>(smem + (size_t)10 * 4 * NTT28_TILE);         // [2^(s-1)] butterfly roots
-    E* sh_row = sh_w + (R >> 1);                                                // [2^s] per-row twiddles (non-last passes)
+    E* sh_row = sh_w + (R >> 1);                                                // [2^s] per-row twiddles (middle passes without a row table)
     const uint32_t n_log = a.n_log;
 
     // ---- tile addressing (as k_ntt_pass) --------------------------------------------------------------------
@@ -410,9 +430,7 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
         if (!LAST && a.p > 1) {
             // the row twiddles depend on the tile's high index only: tabulated once per (size, direction) (k_ntt_row_table28) -- a tile of 1024 elements
             // would otherwise pay 2^s products for them (measured: the middle pass of 2^24 0.92 ms against 0.85 for the 32-bit kernel's 2048-element tiles)
-            if (a.row_tw) {
-                for (uint32_t r = tid; r < R; r += NTT28_THREADS) sh_row[r] = load28<P28>(a.row_tw, (tile_hi << s) + r);
-            } else {
+            if (!a.row_tw) {
                 const uint32_t shift = n_log - a.S_prev - s;
                 for (uint32_t r = tid; r < R; r += NTT28_THREADS) sh_row[r] = twiddle2_28<P28>(a.t_lo, a.t_hi, a.L, ((uint64_t)r * K0) << shift);
             }
@@ -421,12 +439,14 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
     __syncthreads();
     auto load_elem = [&](uint32_t r, uint32_t col) -> E {
         const uint64_t m = in_base + (uint64_t)r * in_row + (uint64_t)col * in_col;
-        E x = load28<P28>(in, m);
+        E x = a.p == 1 ? load28<P28>(in, m) : load40<P28>(in, m);
         if (a.p == 1) {
             if (a.to_mont) x = zl::mul(x, const28<P28>([](int i) { return P28::to_mont(i); }));
             if (a.pre_coset) x = zl::mul(x, twiddle2_28<P28>(a.g_lo, a.g_hi, a.L, m));
         } else if (!LAST) {
-            x = zl::mul(x, sh_row[r]);
+            // (the tabulated row twiddles come straight from global memory: 8 KB per high index, shared by all its tiles and cache-resident -- the tile
+            // then needs no LDS for them and a middle pass fits three workgroups per CU like the others)
+            x = zl::mul(x, a.row_tw ? load28<P28>(a.row_tw, (tile_hi << s) + r) : sh_row[r]);
         } else if (a.last_tw) {
             x = zl::mul(x, load28<P28>(a.last_tw, m));
         } else {
@@ -448,7 +468,8 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
             if (a.from_mont) x = zl::mul(x, const28<P28>([](int i) { return P28::from_mont(i); }));
             x = zl::canon(x);
         } else {
-            x = zl::wred(x);  // < 2r: fits the 32-byte element of the scratch vector
+            store40<P28>(out, m, x);
+            return;
         }
         uint32_t w[8];
         zl::pack28r<P28>(w, x);
@@ -725,7 +746,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     F* scratch = nullptr;
     if (pl.P > 1) {
         void* p;
-        if ((rc = zl_scratch_get(ctx, 6, N * sizeof(F), &p))) return rc;
+        if ((rc = zl_scratch_get(ctx, 6, N * (lazy ? (size_t)40 : sizeof(F)), &p))) return rc;  // lazy passes: ten limbs per element between passes
         scratch = reinterpret_cast<F*>(p);
     }
     const unsigned L = tw->lo_bits;
@@ -835,8 +856,8 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         const F* src = (p == 1) ? data : scratch;
         F* dst = last ? data : scratch;
         if (lazy) {
-            // tile + butterfly roots (+ the per-row twiddles of a middle pass): 45 KB at s = 8 -> three workgroups per CU (55 KB, two, for a middle pass)
-            const size_t lds28 = (size_t)10 * 4 * NTT28_TILE + (size_t)40 * (((size_t)1 << a.s) / 2 + ((!last && p > 1) ? ((size_t)1 << a.s) : 0));
+            // tile + butterfly roots (+ the per-row twiddles of a middle pass that has no row table): 45 KB at s = 8 -> three workgroups per CU
+            const size_t lds28 = (size_t)10 * 4 * NTT28_TILE + (size_t)40 * (((size_t)1 << a.s) / 2 + ((!last && p > 1 && !a.row_tw) ? ((size_t)1 << a.s) : 0));
             if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
             else hipLaunchKernelGGL((k_ntt_pass28<FrP, false>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
         } else {
