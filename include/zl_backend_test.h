@@ -50,7 +50,8 @@ int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t
 
 /* MEASUREMENT ONLY (bench.py's integer-ALU roofline): chains of the accumulation kernel's 14 x 28-bit Montgomery product on per-lane pseudo-random
  * operands, cu_count x 4 x waves_per_simd wavefronts, `iters` products per lane; returns 10^9 products per second.  This is the live-data ceiling of
- * the multiplier on the box of the run (constant-pattern operands clock 15-20 % higher; profiles/r04_fbench_f64.log). */
+ * the multiplier on the box of the run (constant-pattern operands run 11 % faster, short launches after an idle gap 10-15 % slower: time >= 0.1 s after a
+ * warm-up; profiles/r04_fbench_f64.log). */
 int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_products_per_s);
 
 #ifdef __cplusplus

@@ -239,8 +239,8 @@ static int run_dev(zl_ctx* ctx, const uint32_t* in, size_t in_words, uint32_t* o
 // ------------------------------------------------------------------------------------------------ live-data multiplier rate
 // The ceiling bench.py's integer-ALU roofline is quoted against, measured on the box of the run: every lane chains x <- x * y with the product scan
 // of the accumulation kernel (zl_mul28_gfx950.h) on its OWN pseudo-random operands.  Constant-pattern operands (hipMemset, as tools/fbench28_asm.hip
-// uses) run 15-20 % faster on MI355X -- the chip clocks to its power budget and identical lanes toggle less -- and overstate what a kernel on real
-// field elements can reach (profiles/r04_fbench_f64.log).
+// uses) run 11 % faster on MI355X -- the chip clocks to its power budget and identical lanes toggle less -- and a launch of a few milliseconds after an
+// idle gap runs 10-15 % slower than the steady state (clock ramp): callers warm up and time launches of >= 0.1 s (profiles/r04_fbench_f64.log).
 __global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sink, int iters) {
     using A = BLS12_381_Fq28;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

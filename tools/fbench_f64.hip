@@ -4,8 +4,10 @@
 //   1. GATE: 2^20 random + boundary operand pairs; the FP64 product must equal the product of zl_field28.h bit for bit (same Montgomery radix 2^392,
 //      compared as canonical integers in [0, q) on the host).
 //   2. RATE: chains x <- x * y (and x <- x^2) at 1..5 waves per SIMD, the same harness as tools/fbench28_asm.hip, both multipliers in one binary on one
-//      box, plus the bare issue rates of v_fma_f64 / v_add_f64 / v_mad_u64_u32 on LIVE data (the r01 table's FMA chain saturates to inf, which clocks
-//      higher: MI355X_MICROARCH.md "DVFS give-back").
+//      box, plus the bare issue rates of v_fma_f64 / v_mad_u64_u32 on LIVE data (the r01 table's FMA chain saturates to inf, which clocks
+//      higher: MI355X_MICROARCH.md "DVFS give-back"), the 28-bit scan on CONSTANT operands (what tools/fbench28_asm.hip timed) and the scalar-field
+//      candidates of the NTT (8 x 32 carry chain / 10 x 28 lazy, product and butterfly).  Every timed launch follows three untimed ones of the same
+//      length: steady-state clocks.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/fbench_f64.hip -o tools/fbench_f64
 #include "../openzl_amd/csrc/zl_field28.h"
 #include "mul_f64_gen.h"
@@ -105,6 +107,27 @@ __global__ void k_chain_28(F* a, const F* b, int iters) {
 #endif
     }
     a[i] = x;
+}
+// the same chain with the operands made in the kernel by the hash of zl_test_fq_mul_rate (zl_testhooks.hip): is that data as hard as host-random data?
+__global__ void __launch_bounds__(64) k_chain_28_hash(F* a, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s = 0x9E3779B97F4A7C15ull * (t + 1);
+    F x = F::zero(), y = F::zero();
+    for (int k = 0; k < 14; k++) {
+        s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
+        x.l[k] = (uint32_t)s & 0xFFFFFFFu;
+        y.l[k] = (uint32_t)(s >> 32) & 0xFFFFFFFu;
+    }
+    x.l[13] %= A::mod(13);
+    y.l[13] %= A::mod(13);
+    for (int k = 0; k < iters; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        F r = x;
+        mul28_asm<A>(r.l, x.l, y.l);
+        x = r;
+#endif
+    }
+    a[t] = x;
 }
 struct F10 { uint32_t l[10]; uint32_t pad_[6]; };
 // butterfly-like step on 10 x 28-bit lazy limbs: t = y * w; (x, y) <- (x + t, x - t + 4r) with one carry pass each (values stay far below the 2^25 r the scan takes)
@@ -242,11 +265,10 @@ int main(int argc, char** argv) {
     for (int wps : {1, 2, 4, 8}) {
         int threads = 64, blocks = prop.multiProcessorCount * 4 * wps;
         void* out; CHECK(hipMalloc(&out, (size_t)threads * blocks * 8));
-        const int iters = 2000;
+        const int iters = 20000;
         for (int which = 0; which < 2; which++) {
             hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-            if (which == 0) hipLaunchKernelGGL(k_rate_fma, dim3(blocks), dim3(threads), 0, 0, (double*)out, 10); else hipLaunchKernelGGL(k_rate_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)out, 10);
-            CHECK(hipDeviceSynchronize());
+            for (int warm = 0; warm < 3; warm++) { if (which == 0) hipLaunchKernelGGL(k_rate_fma, dim3(blocks), dim3(threads), 0, 0, (double*)out, iters); else hipLaunchKernelGGL(k_rate_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)out, iters); }
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(k_rate_fma, dim3(blocks), dim3(threads), 0, 0, (double*)out, iters); else hipLaunchKernelGGL(k_rate_mad, dim3(blocks), dim3(threads), 0, 0, (uint64_t*)out, iters);
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
@@ -258,7 +280,9 @@ int main(int argc, char** argv) {
     // ---- multiplier chains
     struct Leg { const char* name; int kind; };
     const Leg legs[] = {{"Fq mul  FP64 8x49      ", 0}, {"Fq sqr  FP64 8x49      ", 1}, {"Fq mul  28-bit mad scan", 2}, {"Fq sqr  28-bit mad scan", 3}, {"Fr mul  FP64 6x44      ", 4}, {"Fr mul  8x32 carry     ", 5},
-                        {"Fr mul  10x28 mad scan ", 6}, {"Fr bfly 8x32 carry     ", 7}, {"Fr bfly 10x28 lazy     ", 8}};
+                        {"Fr mul  10x28 mad scan ", 6}, {"Fr bfly 8x32 carry     ", 7}, {"Fr bfly 10x28 lazy     ", 8},
+                        {"Fq mul  28-bit, CONSTANT operands (hipMemset 0x05 / 0x03, as tools/fbench28_asm.hip)", 9},
+                        {"Fq mul  28-bit, operands hashed in the kernel (zl_test_fq_mul_rate)", 10}, {"Fq mul  28-bit mad scan (again)", 2}};
     for (const Leg& leg : legs) for (int wps : {1, 2, 3, 4, 5}) {
         int threads = 64, blocks = prop.multiProcessorCount * 4 * wps;
         size_t n = (size_t)threads * blocks;
@@ -272,6 +296,10 @@ int main(int argc, char** argv) {
                 double* d = reinterpret_cast<double*>((side ? hb : ha).data() + i * (size_t)L * 8);
                 for (int k = 0; k < L; k++) d[k] = (double)((int64_t)(sm64(seed) >> (64 - w)) - (1ll << (w - 1))) * (k == L - 1 ? 0x1p-14 : 1.0);
             }
+        } else if (leg.kind == 10) {
+        } else if (leg.kind == 9) {
+            memset(ha.data(), 0x05, ha.size());
+            memset(hb.data(), 0x03, hb.size());
         } else if (leg.kind <= 3) {
             for (size_t i = 0; i < n; i++) for (int side = 0; side < 2; side++) {
                 uint32_t* l = reinterpret_cast<uint32_t*>((side ? hb : ha).data() + i * 64);
@@ -296,7 +324,8 @@ int main(int argc, char** argv) {
             switch (leg.kind) {
                 case 0: hipLaunchKernelGGL(k_chain_f64<0>, dim3(blocks), dim3(threads), 0, 0, (D8*)a, (const D8*)b, it); break;
                 case 1: hipLaunchKernelGGL(k_chain_f64<1>, dim3(blocks), dim3(threads), 0, 0, (D8*)a, (const D8*)b, it); break;
-                case 2: hipLaunchKernelGGL(k_chain_28<0>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
+                case 10: hipLaunchKernelGGL(k_chain_28_hash, dim3(blocks), dim3(threads), 0, 0, (F*)a, it); break;
+                case 2: case 9: hipLaunchKernelGGL(k_chain_28<0>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
                 case 3: hipLaunchKernelGGL(k_chain_28<1>, dim3(blocks), dim3(threads), 0, 0, (F*)a, (const F*)b, it); break;
                 case 4: hipLaunchKernelGGL(k_chain_fr, dim3(blocks), dim3(threads), 0, 0, (D6*)a, (const D6*)b, it); break;
                 case 5: hipLaunchKernelGGL(k_chain_fr32, dim3(blocks), dim3(threads), 0, 0, (Fr*)a, (const Fr*)b, it); break;
@@ -305,8 +334,10 @@ int main(int argc, char** argv) {
                 default: hipLaunchKernelGGL(k_chain_fr28, dim3(blocks), dim3(threads), 0, 0, (F10*)a, (const F10*)b, it, 1); break;
             }
         };
-        launch(4);
-        CHECK(hipDeviceSynchronize());
+        // steady state: MI355X clocks ramp up over tens of milliseconds after an idle gap (the allocation and the copies above), so a 12-ms launch timed
+        // on its own under-reads by 10-15 % (found in round 4: zl_test_fq_mul_rate 63 -> 69 -> 73 -> 75 -> 77.6 G/s over consecutive launches);
+        // three untimed launches of the same length run first, the timed one follows them without a gap
+        launch(iters); launch(iters); launch(iters);
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         CHECK(hipEventRecord(e0));
         launch(iters);
