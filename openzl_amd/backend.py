@@ -68,7 +68,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ZL_BACKEND_LIB") or LIB_PATH  # ZL_BACKEND_LIB: developer A/B of two builds in one gpurun call
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(p)

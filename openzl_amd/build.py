@@ -52,7 +52,8 @@ def _digest(paths, extra="") -> str:
 
 
 def _units():
-    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", []), ("zl_multi", "zl_multi.hip", [])]
+    units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", []), ("zl_multi", "zl_multi.hip", []),
+             ("zl_msm_sort", "zl_msm_sort.hip", [])]  # the curve-independent sort kernels of the MSM: once, not per group
     for g in GROUPS:
         # Fq2 accumulators: 1 wave/SIMD register budget avoids scratch spills
         extra = ["-DZL_ACC_WAVES=1"] if g.endswith("G2") else []
@@ -62,7 +63,9 @@ def _units():
         if g == "BlsG1":
             # three waves per SIMD (<= 168 registers): what the accumulation kernel needs anyway (162); without the cap the compiler spreads to 185 = two waves
             extra = extra + ["-DZL_ACC_WAVES=3"]
-        units.append((f"zl_msm_{g}", "zl_msm.hip", [f"-DZL_G={g}"] + extra))
+        # three units per group: the host side + light kernels, the accumulation kernels, the merge / reduction kernels (zl_msm.hip's header)
+        for part in ("zl_msm", "zl_msm_acc", "zl_msm_tail"):
+            units.append((f"{part}_{g}", part + ".hip", [f"-DZL_G={g}"] + extra))
     return [u for u in units if os.path.exists(os.path.join(CSRC, u[1]))]
 
 

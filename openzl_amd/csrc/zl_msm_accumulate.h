@@ -1,0 +1,121 @@
+// zl_msm_accumulate.h -- step 3 of the MSM (zl_msm.hip): the bucket accumulation kernels, one lane (or one DPP quad) per chunk of the
+// bucket-sorted entry list.  Instantiated per group in zl_msm_acc.hip; zl_msm.hip only launches them (ZL_MSM_ACCUMULATE_KERNELS(extern, G)).
+#pragma once
+#include "zl_ctx.h"
+#include "zl_quad.h"
+#include "zl_msm_common.h"
+
+// ------------------------------------------------------------------------------------------------ accumulate
+__device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ a, uint32_t n, uint32_t key) {
+    // first index with a[idx] > key
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] <= key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+#ifndef ZL_ACC_WAVES
+#define ZL_ACC_WAVES 2  // waves per SIMD the accumulate kernel is register-budgeted for
+#endif
+#ifndef ZL_ACC_BLOCK
+#define ZL_ACC_BLOCK 64
+#endif
+// one lane, one chunk: entries [t * ZL_CHUNK, (t + 1) * ZL_CHUNK) of the bucket-sorted list
+template <class G, bool QUAD = false>
+__device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_t E, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ bases,
+                                                    XYZZ<typename HotField<typename G::F>::type>* __restrict__ bucket_sums,
+                                                    XYZZ<typename HotField<typename G::F>::type>* __restrict__ partials, uint32_t ZL_CHUNK,
+                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ phib, uint32_t n_real) {
+    using F = typename HotField<typename G::F>::type;  // same layout as G::F; Fq2 on 28-bit limbs: the inlining flavour (zl_curve.h)
+    const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
+    if (start64 >= E) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (uint32_t)min((uint64_t)E, start64 + ZL_CHUNK);
+    uint32_t b = zl_upper_bound(offsets, NB + 1, start) - 1;  // bucket holding entry `start`
+    uint32_t b_start = offsets[b], b_end = offsets[b + 1];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    // ONE flat loop of exactly (end - start) mixed additions per lane: a per-segment inner loop would make the
+    // wave run max-over-lanes iterations per segment (measured 2.4x slower).  Bucket boundaries only flush.
+    for (uint32_t e = start; e < end; e++) {
+        while (e == b_end) {  // lane crosses into the next bucket (empty buckets: zero-length, skipped here)
+            if (b_end > b_start) {
+                if (!QUAD || sub == 0) {
+                    if (b_start >= start) bucket_sums[b] = acc;  // bucket lies inside this chunk (b_end <= e < end)
+                    else partials[(size_t)2 * t] = acc;          // head bucket started in an earlier chunk
+                }
+                acc = XYZZ<F>::inf();
+            }
+            b++;
+            b_start = b_end;
+            b_end = offsets[b + 1];
+        }
+        const uint32_t ent = entries[e];
+        const uint32_t idx = ent & 0x7fffffffu;
+        const Affine<F> P = (G::GLV && idx >= n_real ? phib : bases)[idx];
+        if (!P.is_inf()) {
+            if constexpr (QUAD) zl::add_mixed_quad(acc, P.x, P.y, (ent >> 31) != 0, sub);
+            else zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+        }
+    }
+    // last segment [max(b_start,start), end) of bucket b
+    const bool complete = (b_start >= start) && (b_end <= end);
+    if (QUAD && sub != 0) return;
+    if (complete) bucket_sums[b] = acc;
+    else partials[(size_t)2 * t + (b_start <= start ? 0 : 1)] = acc;
+}
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+    using F = typename HotField<typename G::F>::type;
+    static_assert(sizeof(F) == sizeof(typename G::F), "hot flavour must share the layout");
+    // GLV: virtual point n_real + i = phi(P_i); else n_real = 2^32 - 1 (never selected)
+    zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+                           reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
+                           reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+}
+// The same chunks with FOUR lanes per chunk (zl_quad.h): for lists that do not fill the machine (small MSMs), where the time of the launch is
+// the latency of one lane's chain of mixed additions -- 4 product slots per addition instead of 10.5.
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate_quad(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+    using F = typename HotField<typename G::F>::type;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    zl_accumulate_chunk<G, true>(gt >> 2, (int)(gt & 3u), offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+                                 reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
+                                 reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+}
+// The same chunks on a grid that does NOT fill the register file (pipelined batches): k_msm_accumulate at three waves per SIMD holds 498 of
+// the 512 registers of every SIMD for as long as it runs, so the sort of the next MSM and the tail of the previous one only get onto the
+// machine when it ends (rocprofv3 of a batch, profiles/r03_glv_ab.log: 3.5 ms between consecutive accumulations in which those two run alone).
+// Here `wg_per_cu` workgroups of 256 lanes per CU (2: two waves per SIMD, 332 registers) loop over the chunks, which leaves a wave slot of
+// ~180 registers per SIMD and all of the LDS to the side streams for the whole accumulation.  Measured and NOT used by default (see
+// msm_run_jobs_t): the overlap happens, but both co-resident field-arithmetic kernels slow down far more than the gap was worth.
+#define ZL_ACC_PERSIST_BLOCK 256
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accumulate_persist(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, uint32_t nchunks) {
+    using F = typename HotField<typename G::F>::type;
+    const uint32_t E = offsets[NB];
+    // lanes of one wave take consecutive chunks (neighbouring entries), the grid strides over the list
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += gridDim.x * blockDim.x)
+        zl_accumulate_chunk<G>(t, 0, E, entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_), reinterpret_cast<XYZZ<F>*>(bucket_sums_),
+                               reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK, reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+}
+
+// every instantiation MsmJob<G>::accumulate launches: X = empty defines them (zl_msm_acc.hip), X = extern only declares them
+#define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
+    X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);

@@ -1,0 +1,273 @@
+// zl_msm_reduce.h -- steps 4 and 5 of the MSM (zl_msm.hip): merge of the buckets cut by chunk boundaries, the sum of the scalar-1 bases and the
+// bucket reduction sum_k k B_k (level-0 running sums + the channel tree).  Instantiated per group in zl_msm_tail.hip.
+#pragma once
+#include "zl_ctx.h"
+#include "zl_quad.h"
+#include "zl_msm_common.h"
+
+// The merge / level-0 / tree kernels of an Fq2 group can compute in the inlining flavour of the field like the accumulation kernel
+// (-DZL_HOT_TAILS): their out-of-line Fq2 product routines take 56 scalar arguments, 24 of which travel on the stack (236 - 1260 B of
+// scratch per lane in round 2's G2 tails).
+#ifdef ZL_HOT_TAILS
+template <class F> using TailF = typename HotField<F>::type;
+#else
+template <class F> using TailF = F;
+#endif
+// one lane per bucket: empty -> infinity; cut into <= ZL_BIG_SPAN chunks -> fold partials; else defer to a block
+template <class G, bool QUAD = false>
+__global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 256) ? 3 : 1) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                   const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
+                                                   uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
+                                                   uint32_t ZL_CHUNK, uint32_t big_span) {
+    ZL_SIDE_PRIO();
+    using F = TailF<typename G::F>;
+    XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
+    const XYZZ<F>* __restrict__ partials = reinterpret_cast<const XYZZ<F>*>(partials_);
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per bucket (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
+    if (b >= NB) return;
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    if (s == e) { if (sub == 0) bucket_sums[b] = XYZZ<F>::inf(); return; }
+    const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+    if (t0 == t1) return;  // written directly by msm_accumulate
+    if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (sub == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
+    if (t1 - t0 + 1 > big_span) { if (sub == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t t = t0; t <= t1; t++) {
+        const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+        if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
+        else zl::add_full(acc, p);
+    }
+    if (sub == 0) bucket_sums[b] = acc;
+}
+// lanes of the block-tree kernels: 256 for G1, 128 for G2 (384-B points: a 256-lane block is capped at 256 VGPRs and spills)
+template <class G>
+struct TreeLanes { static constexpr int N = sizeof(XYZZ<typename G::F>) > 256 ? 128 : 256; };
+template <class G>
+__device__ __forceinline__ void zl_block_tree(XYZZ<typename G::F>* sh, XYZZ<typename G::F>& acc) {
+    using F = typename G::F;
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x];
+            const XYZZ<F> o = sh[threadIdx.x + off];
+            zl::add_full(a, o);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    acc = sh[0];
+    __syncthreads();
+}
+// one block per big bucket (ZL_BIG_SPAN < chunks <= ZL_GIANT_SPAN)
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                        const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    for (uint32_t item = blockIdx.x; item < *big_count; item += gridDim.x) {
+        const uint32_t b = big_list[item];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+            const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+            zl::add_full(acc, p);
+        }
+        zl_block_tree<G>(sh, acc);
+        if (threadIdx.x == 0) bucket_sums[b] = acc;
+    }
+}
+// giant buckets (> ZL_GIANT_SPAN chunks: many equal scalars), stage 1: block (item, part) tree-sums its share of the bucket's
+// chunk partials -> giant_tmp[item * ZL_GIANT_PARTS + part]; stage 2: one lane per giant bucket folds the ZL_GIANT_PARTS sums
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ giant_list,
+                                                          const uint32_t* __restrict__ giant_count, uint32_t ZL_CHUNK) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t part = blockIdx.x % ZL_GIANT_PARTS;
+    for (uint32_t item = blockIdx.x / ZL_GIANT_PARTS; item < *giant_count; item += gridDim.x / ZL_GIANT_PARTS) {
+        const uint32_t b = giant_list[item];
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+        const uint32_t per = (t1 - t0 + ZL_GIANT_PARTS) / ZL_GIANT_PARTS;  // ceil((t1 - t0 + 1) / parts)
+        const uint32_t lo = t0 + part * per, hi = min(t1 + 1, lo + per);
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+            const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
+            zl::add_full(acc, p);
+        }
+        zl_block_tree<G>(sh, acc);
+        if (threadIdx.x == 0) giant_tmp[(size_t)item * ZL_GIANT_PARTS + part] = acc;
+    }
+}
+template <class G>
+__global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __restrict__ bucket_sums, const XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *giant_count) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t k = 0; k < ZL_GIANT_PARTS; k++) {
+        const XYZZ<F> p = giant_tmp[(size_t)item * ZL_GIANT_PARTS + k];
+        zl::add_full(acc, p);
+    }
+    bucket_sums[giant_list[item]] = acc;
+}
+// sum of the bases whose scalar is 1 (list built by the recoder): strided mixed adds per lane, block tree -> out[block]
+#define ZL_ONES_BLOCKS 128
+
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __restrict__ ones_list, const uint32_t* __restrict__ ones_count,
+                                                   const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out,
+                                                   const Affine<typename G::F>* __restrict__ phib, uint32_t n_real) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t cnt = *ones_count;
+    if (cnt == 0) {  // the usual case for uniform scalars: no block tree over 128 / 256 points at infinity (15 us of the tail of a small G2 MSM)
+        if (threadIdx.x == 0) out[blockIdx.x] = XYZZ<F>::inf();
+        return;
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+        const uint32_t idx = ones_list[j];
+        const Affine<F> P = (G::GLV && idx >= n_real) ? phib[idx - n_real] : bases[idx];  // GLV: a half-scalar k2 = 1 names phi(P)
+        if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, false);
+    }
+    zl_block_tree<G>(sh, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ bucket reduction
+// sum_{k=1..H} k * B_k per bucket set without any scalar multiple and with a dependent chain of only ~log2(H) additions:
+//   level 0   one lane per block of g0 consecutive buckets (bucket index i <-> weight i + 1): running sums in registers give
+//             T = sum B_i and A = sum (i - i0 + 1) B_i   (2 additions per bucket, the classic trick inside the block)
+//   tree      the remaining weight of block j is g0 * j.  sum_j j T_j = sum_b 2^b S_b with S_b = sum of the T_j whose index has bit b
+//             set.  A binary tree over the block index carries, per node, the channels (T, A, S_0 .. S_(level-1)): combining children
+//             (L, R) adds channel-wise, and the new top channel is S_(level-1) = T_R.  Every (node, channel) pair is ONE independent
+//             addition (one lane), so a tree level is one launch of depth 1 and the whole reduction is log2(H / g0) dependent
+//             additions -- no lane runs a double-and-add ladder for its offset and nothing is multiplied by a power of two on the
+//             device.  Total work stays ~2 additions per bucket + ~3 per block.
+//   host      the root's channels of every set, folded into the window Horner it runs anyway: position c w + log2 g0 + b receives
+//             S_(w,b), position c w receives A_w (one extra addition per bit position, no extra doublings).
+// flat_set: the spread top window (k_msm_recode_wide): its buckets are weighted by their low spread_t bits only; level 0 is weightless
+// for it when spread_t == 0, and the host skips its S_b from bit spread_t on.
+template <class G, bool QUAD = false>
+__global__ void __launch_bounds__(64, TreeLanes<G>::N == 128 ? 1 : 2) k_msm_reduce_level0(const XYZZ<typename G::F>* __restrict__ buckets_, uint32_t H, uint32_t group, uint32_t blocks_per_set,
+                                                           uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log,
+                                                           XYZZ<typename G::F>* __restrict__ out_ /* [set][block][2]: T, A */) {
+    ZL_SIDE_PRIO();
+    using X = XYZZ<TailF<typename G::F>>;
+    const X* __restrict__ buckets = reinterpret_cast<const X*>(buckets_);
+    X* __restrict__ out = reinterpret_cast<X*>(out_);
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per block of buckets (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
+    if (t >= total_blocks) return;
+    const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
+    const uint32_t i0 = blk * group, i1 = min(H, i0 + group);
+    const size_t base = (size_t)set * H;
+    const bool flat = set == flat_set && flat_log == 0;
+    X run = X::inf(), wsum = X::inf();
+    for (uint32_t i = i1; i > i0; i--) {
+        const X B = buckets[base + (i - 1)];
+        if constexpr (QUAD) {
+            zl::add_full_quad(run, B, sub);
+            if (!flat) zl::add_full_quad(wsum, run, sub);
+        } else {
+            zl::add_full(run, B);
+            if (!flat) zl::add_full(wsum, run);
+        }
+    }
+    if (sub != 0) return;
+    out[(size_t)2 * t] = run;
+    // (two stores, not `flat ? run : wsum`: the conditional operator on the two structs becomes a select of their ADDRESSES, which pins both in scratch --
+    // that was the whole of this kernel's 528 B of private memory in rounds 2-3)
+    if (flat) out[(size_t)2 * t + 1] = run;
+    else out[(size_t)2 * t + 1] = wsum;
+}
+// one tree level: nodes of `level` (1-based) from the nodes of level - 1.  Node layout: [set][node][channel], ch_in = level + 1 channels
+// in (T, A, S_0 .. S_(level-2)), ch_out = level + 2 out.  One lane per (set, node, out channel).
+template <class G, bool QUAD = false>
+__global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F>* __restrict__ in_, XYZZ<typename G::F>* __restrict__ out_, uint32_t level,
+                                                         uint32_t nodes_out_per_set, uint32_t total_lanes) {
+    ZL_SIDE_PRIO();
+    using X = XYZZ<TailF<typename G::F>>;
+    const X* __restrict__ in = reinterpret_cast<const X*>(in_);
+    X* __restrict__ out = reinterpret_cast<X*>(out_);
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = QUAD ? gt >> 2 : gt;  // QUAD: four lanes per (set, node, channel) (zl_quad.h)
+    const int sub = QUAD ? (int)(gt & 3u) : 0;
+    if (t >= total_lanes) return;
+    const uint32_t ch_out = level + 2, ch_in = level + 1;
+    const uint32_t ch = t % ch_out, node = (t / ch_out) % nodes_out_per_set, set = t / (ch_out * nodes_out_per_set);
+    const size_t left = ((size_t)set * nodes_out_per_set * 2 + (size_t)2 * node) * ch_in, right = left + ch_in;
+    if (ch == ch_out - 1) {  // the new top channel: blocks of the right child have this bit set
+        if (sub == 0) out[t] = in[right];
+        return;
+    }
+    X acc = in[left + ch];
+    const X o = in[right + ch];
+    if constexpr (QUAD) zl::add_full_quad(acc, o, sub);
+    else zl::add_full(acc, o);
+    if (sub == 0) out[t] = acc;
+}
+// tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
+// set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
+// two-stage sum for sets with many segments.
+template <class G>
+__global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<typename G::F>* __restrict__ seg_out, uint32_t count, uint32_t set_stride,
+                                                         uint32_t parts, XYZZ<typename G::F>* __restrict__ out, const uint32_t* __restrict__ zero_if_zero) {
+    ZL_SIDE_PRIO();
+    using F = typename G::F;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    if (zero_if_zero && *zero_if_zero == 0) {  // nothing was listed: every part is the point at infinity
+        if (threadIdx.x == 0) out[blockIdx.x] = XYZZ<F>::inf();
+        return;
+    }
+    const uint32_t set = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint32_t lo = part * count, hi = min(set_stride, lo + count);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) {
+        const XYZZ<F> p = seg_out[(size_t)set * set_stride + s];
+        zl::add_full(acc, p);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = TreeLanes<G>::N / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            XYZZ<F> a = sh[threadIdx.x];
+            const XYZZ<F> o = sh[threadIdx.x + off];
+            zl::add_full(a, o);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// every instantiation MsmJob<G>::tail launches (X as in zl_msm_accumulate.h)
+#define ZL_MSM_TAIL_KERNELS(X, G) \
+    X template __global__ void k_msm_merge<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
+    X template __global__ void k_msm_merge_giant<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
+    X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*); \
+    X template __global__ void k_msm_ones<G>(const uint32_t*, const uint32_t*, const Affine<typename G::F>*, XYZZ<typename G::F>*, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_reduce_level0<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
+    X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
+    X template __global__ void k_msm_reduce_tree<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_reduce_tree<G, true>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_window_sum<G>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*, const uint32_t*);
