@@ -239,9 +239,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     const auto jt0 = std::chrono::steady_clock::now();
     // issue of one job: sort | accumulate | tail with the events between them.  pipelined: three phases on three streams; side by side: the
     // whole job on the stream of its buffer set (the waits are then between operations of one stream, i.e. no-ops)
-    auto issue_job = [&](size_t i) -> int {
-        hipStream_t js_sort = side ? ctx->stream_lane[i % NS] : s_sort, js_acc = side ? ctx->stream_lane[i % NS] : s_acc;
-        hipStream_t s_tail = side ? ctx->stream_lane[i % NS] : s_tails[i % 3];
+    auto issue_sort = [&](size_t i) -> int {
+        hipStream_t js_sort = side ? ctx->stream_lane[i % NS] : s_sort;
         hipError_t e = hipSuccess;
         if (i >= NS) e = hipStreamWaitEvent(js_sort, ev_tail[i - NS], 0);  // buffer set i % NS is free again
         if (recorded && specs[i].wait) {
@@ -253,9 +252,16 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         int r;
         if ((r = jobs[i].sort(ctx, js_sort))) return r;
         e = hipEventRecord(ev_sorted[i], js_sort);
-        if (e == hipSuccess) e = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+        return ZL_OK;
+    };
+    auto issue_acc_tail = [&](size_t i) -> int {
+        hipStream_t js_acc = side ? ctx->stream_lane[i % NS] : s_acc;
+        hipStream_t s_tail = side ? ctx->stream_lane[i % NS] : s_tails[i % 3];
+        hipError_t e = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
         if (e == hipSuccess && ctx->timing_on) e = hipEventRecord(ev_acc0[i], js_acc);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+        int r;
         if ((r = jobs[i].accumulate(ctx, js_acc, acc_wg_per_cu))) return r;
         e = hipEventRecord(ev_acc[i], js_acc);
         if (e == hipSuccess) e = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
@@ -267,6 +273,19 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
                             (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
         return ZL_OK;
     };
+    auto issue_job = [&](size_t i) -> int {
+        const int r = issue_sort(i);
+        return r ? r : issue_acc_tail(i);
+    };
+    // Side by side, LARGE jobs (Groth16's four G1 MSMs of a big circuit): the streams of the lanes share hardware queues (two of them for four lanes
+    // with the runtime's default of four queues per process), and a hardware queue runs its packets in order -- job-major issue puts the sort of
+    // job 2 behind the accumulation and the tail of job 0 (rocprofv3 of the 958 465-constraint proof, round 4: the l MSM's sort ran 1.5 ms after
+    // the machine had gone idle for it).  Phase-major issue instead: the sorts of all jobs that wait for nothing, then their accumulations and
+    // tails, then the jobs that wait for an event (the h MSM behind the witness map): 18.1 -> 17.8 ms (profiles/r04_g16_gate_ab.log).  Built on top and
+    // removed: the G2 accumulation held back until those sorts had finished (the sort kernels need 104 - 160 registers per SIMD and stall beside the
+    // 416-register G2 wave): the a accumulation then starts 3 ms earlier, the G2 accumulation 3 ms later, and the proof takes the same 18.1 ms --
+    // the proof is bound by the sum of its group additions, whatever their order.
+    const bool phased = side && count <= NS && biggest >= ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_LANE_THREADS", 0) == 0;
     // issued[i]: 0 not yet, 1 issued, < 0 failed (-code).  Side by side, every lane stream CAN be fed by its own persistent host thread
     // (ZL_TUNE_LANE_THREADS=1): the ~25 launches of a small job are ~80 us of host time, four jobs 0.3 ms.  Measured (k = 1 proof, 40 runs): all
     // four jobs then reach the device within 0.15 ms, but finish together and later than the staggered jobs of a single issuing thread
@@ -285,9 +304,19 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
                 }
             });
     } else {
+        if (phased) {
+            for (size_t i = 0; i < count; i++)
+                if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_sort(i);
+            for (size_t i = 0; i < count; i++)
+                if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_acc_tail(i);
+            for (size_t i = 0; i < count; i++)
+                if (specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
+            for (size_t i = 0; i < count; i++) issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
+        } else {
         for (size_t i = 0; i < count; i++) {
             if (he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
             issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
+        }
         }
     }
     auto lanes_join = [&]() {
