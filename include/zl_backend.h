@@ -245,8 +245,16 @@ int zl_point_from_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const u
 int zl_groth16_keys_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len);
 int zl_groth16_keys_from_bytes(zl_ctx* ctx, zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags, zl_g16_keys** out);
 /* ark_groth16::VerifyingKey<E>::serialize (compressed points): alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (u64 length first).
- * (The reference's VerifyingContext wire format additionally carries ark's prepared-G2 line coefficients and e(alpha, beta); those are
- * internal to ark-ec's Miller loop and are not restated.) */
+ * The reference's VerifyingContext (/root/reference/plugins/arkworks/src/groth16.rs:181-396) frames a PreparedVerifyingKey as
+ *     vk | alpha_g1_beta_g2 (one Fqk) | gamma_g2_neg_pc | delta_g2_neg_pc
+ * where the last two are written through `<E::G2Prepared as HasSerialization>::Serialize` (groth16.rs:208-211).  HasSerialization /
+ * HasDeserialization are hook traits (plugins/arkworks/src/serialize.rs:21-30) that NO file of the reference implements for any curve
+ * (grep: no `impl ... HasSerialization`): the bytes of a prepared G2 point (ark-ec's Miller-loop line coefficients) are left to a
+ * downstream crate, so the reference defines no layout for two of the four fields and VerifyingContext: Encode / Decode cannot even be
+ * instantiated from the reference alone.  alpha_g1_beta_g2 is the pairing value ark's final exponentiation produces; this backend's
+ * pairing (csrc/zl_pairing.h) takes the exact (q^12 - 1)/r power in a tower-free basis, and whether ark-ec 0.3's hard part returns that
+ * power or a fixed multiple of it cannot be checked without the crate.  What IS defined and restated is the first field, vk, below; a
+ * verifier built from it recomputes the other three (zl_groth16_verify does). */
 int zl_groth16_vk_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len);
 
 /* ---- per-call device timing (HIP events on the ctx's stream) -------------------------------------------- */
