@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timelines (per-launch start / duration / gap) of the small and mid-size calls: 2^16 / 2^20 MSM, Groth16 k = 1 and k = 64.
-#   gpurun --timeout 900 -- 'bash tools/r3_profile_small.sh <tag>'
+#   gpurun --timeout 900 -- 'bash tools/ab/r3_profile_small.sh <tag>'
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r3small}

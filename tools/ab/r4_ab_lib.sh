@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds of the library on ONE box: ZL_BACKEND_LIB=tools/libzl_old.so against the in-tree build, interleaved
-#   gpurun --timeout 900 -- 'bash tools/r4_ab_lib.sh'
+#   gpurun --timeout 900 -- 'bash tools/ab/r4_ab_lib.sh'
 O=gpurun_out/ab; mkdir -p $O; : > $O/ab.log
 for rep in 1 2; do
   for lib in tools/libzl_old.so openzl_amd/libzl_backend.so; do

@@ -22,4 +22,4 @@ done
 done
 unset ZL_TUNE_G2_GATE_MIN_LOG ZL_TUNE_PHASED_MIN_LOG
 cat $out
-TL_MIN_US=150 bash tools/r4_g16_tl.sh
+TL_MIN_US=150 bash tools/ab/r4_g16_tl.sh
