@@ -293,7 +293,6 @@ struct MsmJob {
         }  // plain c >= 21 (more than 255 sort groups): the global-atomics sort needs no temporaries
     }
     int sort(zl_ctx* ctx, hipStream_t st) {
-        const zl_bases& bs = *bsp;
         int rc;
         // the bucket counters are written in full by the LDS path (k_msm_slice_prefix) and by the wide path (k_msm_fine_hist); only the
         // global-atomics sort counts into them
@@ -327,110 +326,125 @@ struct MsmJob {
         // per call, not once per process: the attribute is per device and a process may own several contexts
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_scatter_range), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (wide) {
-            // ---- three-level counting sort over (window, bucket) ids: the merged set of a table, or W sets of plain wide windows ------
-            uint32_t nslices = 64;
-            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
-            if (nslices > max_slices) nslices = max_slices;
-            const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
-            const uint32_t P = Gn * W * nslices;  // partition counters, order (group, window, slice)
-            const uint32_t pscan_blocks = (P + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-            const size_t b_lo = (((size_t)n * W * 2 + 255) / 256) * 256, b_hi = (((size_t)n * W + 255) / 256) * 256;
-            const size_t b_plo = b_lo, b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
-            const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256;
-            void* pd;
-            if ((rc = zl_scratch_get(ctx, slotA, b_lo + b_hi + b_plo + b_pidx + b_pc + 256, &pd))) return rc;
-            unsigned char* q = (unsigned char*)pd;
-            uint16_t* d_lo16 = (uint16_t*)q; q += b_lo;
-            uint8_t* d_hi8 = (uint8_t*)q; q += b_hi;
-            uint16_t* d_part_lo = (uint16_t*)q; q += b_plo;
-            uint32_t* d_part_idx = (uint32_t*)q; q += b_pidx;
-            uint32_t* d_pcounts = (uint32_t*)q;
-            uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
-            uint32_t* d_pblock = d_poff + P + 1;
-            hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, glv_i, d_lo16, d_hi8, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
-            hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P, (const uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
-            hipLaunchKernelGGL(k_msm_part_scatter_st, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
-                               pre ? (uint32_t)bs.n : 0u, pre ? (uint32_t)first : 0u, d_part_lo, d_part_idx);  // plain: d_bases already starts at `first`
-            const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
-            // level 2: 128 sub-groups (256 buckets each) per group; level 3: LDS-staged sort per sub-group
-            const uint32_t SG = Gn * 128;
-            uint32_t fsl = 16;
-            while (fsl * Gn < 2048 && fsl < 128) fsl *= 2;
-            const uint32_t P2 = SG * fsl;
-            const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-            void* pd2;
-            const size_t b2_lo = b_plo, b2_idx = b_pidx, b2_c = (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256;
-            if ((rc = zl_scratch_get(ctx, slotB, b2_lo + b2_idx + b2_c + 256, &pd2))) return rc;  // slot 6 is otherwise the NTT's scratch vector
-            unsigned char* q2 = (unsigned char*)pd2;
-            uint16_t* d_lo2 = (uint16_t*)q2; q2 += b2_lo;
-            uint32_t* d_idx2 = (uint32_t*)q2; q2 += b2_idx;
-            uint32_t* d_c2 = (uint32_t*)q2;
-            uint32_t* d_off2 = d_c2 + P2;  // P2 + 1
-            uint32_t* d_blk2 = d_off2 + P2 + 1;
-            hipLaunchKernelGGL(k_msm_sub_hist, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fsl, d_c2);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2, (const uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_scan_apply, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2, d_off2, d_c2);
-            hipLaunchKernelGGL(k_msm_sub_scatter_st, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
-                               d_idx2);
-            hipLaunchKernelGGL(k_msm_fine_hist, dim3(SG), dim3(256), 0, st, d_lo2, d_off2, SG, fsl, d_off2 + P2, d_counts);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
-            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            // staged entries per block: at most 144 KiB + 1 KiB of cursors (1 block per CU); sub-groups average n*W/SG entries, so many small
-            // sub-groups (plain wide windows) get a smaller stage and two blocks per CU
-            uint32_t cap = (uint32_t)std::min<uint64_t>(36 * 1024, std::max<uint64_t>(4096, (maxE / SG) * 22 / 10));
-            cap = (uint32_t)std::max(1024, zl_tune("ZL_TUNE_FS_CAP", (int)cap));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(zl_tune("ZL_TUNE_FS", 1024)), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
-                               d_entries, d_bigsg_head, d_bigsg_items);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize, ZL_BT * 4);
-            hipLaunchKernelGGL(k_msm_fine_sort_big, dim3(512), dim3(1024), (size_t)ZL_BT * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_bigsg_head,
-                               d_bigsg_items, d_cursor, d_entries);
-        } else if (c <= 16) {
-            // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
-            uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
-            const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
-            if (nslices > max_slices) nslices = max_slices;
-            if (nslices < 1) nslices = 1;
-            const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
-            void* pd;
-            if ((rc = zl_scratch_get(ctx, slotA, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
-            uint16_t* d_digits = (uint16_t*)pd;
-            uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
-            hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
-            hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
-            if (NB <= 16384 && nslices <= 64) {
-                hipLaunchKernelGGL(k_msm_prefix_small, dim3(1), dim3(1024), 0, st, d_slice_counts, NB, nslices, d_offsets, d_cursor, (const uint32_t*)d_bad_scalar);
-            } else {
-            hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
-            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            }
-            // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
-            uint32_t ranges = 1;
-            while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
-            ranges = (uint32_t)std::max(1, zl_tune("ZL_TUNE_RANGES", (int)ranges));
-            const uint32_t RB = (H + ranges - 1) / ranges;
-            // (the digit row of a window can be walked by `parts` blocks, slice-aligned: measured 1 = 2 = 4 = 8 at 2^18 .. 2^21 -- the kernel is bound by
-            // its 4-byte scattered stores, 16.8 M of them in 0.19 ms at 2^20, not by the length of the row, the load latency or the LDS atomics)
-            const uint32_t parts = (uint32_t)std::max(1, std::min<int>((int)nslices, zl_tune("ZL_TUNE_SCATTER_PARTS", 1)));
-            hipLaunchKernelGGL(k_msm_scatter_range, dim3(8 * ((W + 7) / 8), ranges, parts), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries,
-                               (const uint32_t*)d_slice_counts, NB, nslices, per_slice, parts, (uint32_t)W);
-        } else {
-            // wide windows without a table: histogram / scatter with global atomics
-            hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
-            hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
-            hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
-            hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
-        }
+        if (wide) rc = sort_wide(ctx, st, sc_eff, inf_eff, bad_eff, nblk, glv_i);
+        else if (c <= 16) rc = sort_lds(ctx, st, sc_eff, inf_eff, bad_eff, nblk, glv_i);
+        else rc = sort_atomics(ctx, st, nblk);
+        if (rc) return rc;
         ZL_HIP(ctx, hipGetLastError());
+        return ZL_OK;
+    }
+    // ---- three-level counting sort over (window, bucket) ids: the merged set of a table, or W sets of plain wide windows (c = 17 .. 20; GLS quarter-scalars at c = 16)
+    int sort_wide(zl_ctx* ctx, hipStream_t st, const uint32_t* sc_eff, const uint8_t* inf_eff, uint32_t* bad_eff, uint32_t nblk, int glv_i) {
+        const zl_bases& bs = *bsp;
+        int rc;
+        uint32_t nslices = 64;
+        const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+        if (nslices > max_slices) nslices = max_slices;
+        const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
+        const uint32_t P = Gn * W * nslices;  // partition counters, order (group, window, slice)
+        const uint32_t pscan_blocks = (P + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+        const size_t b_lo = (((size_t)n * W * 2 + 255) / 256) * 256, b_hi = (((size_t)n * W + 255) / 256) * 256;
+        const size_t b_plo = b_lo, b_pidx = (((size_t)n * W * 4 + 255) / 256) * 256;
+        const size_t b_pc = (((size_t)(2 * P + pscan_blocks + 8) * 4 + 255) / 256) * 256;
+        void* pd;
+        if ((rc = zl_scratch_get(ctx, slotA, b_lo + b_hi + b_plo + b_pidx + b_pc + 256, &pd))) return rc;
+        unsigned char* q = (unsigned char*)pd;
+        uint16_t* d_lo16 = (uint16_t*)q; q += b_lo;
+        uint8_t* d_hi8 = (uint8_t*)q; q += b_hi;
+        uint16_t* d_part_lo = (uint16_t*)q; q += b_plo;
+        uint32_t* d_part_idx = (uint32_t*)q; q += b_pidx;
+        uint32_t* d_pcounts = (uint32_t*)q;
+        uint32_t* d_poff = d_pcounts + P;            // P + 1 entries (total at [P])
+        uint32_t* d_pblock = d_poff + P + 1;
+        hipLaunchKernelGGL(k_msm_recode_wide, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, pre ? 0u : (H >> 15), spread_t, glv_i, d_lo16, d_hi8, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
+        hipLaunchKernelGGL(k_msm_part_hist, dim3(nslices, W), dim3(256), 0, st, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_pcounts);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_pblock, pscan_blocks, d_poff + P, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_scan_apply, dim3(pscan_blocks), dim3(SCAN_BLOCK), 0, st, d_pcounts, P, d_pblock, d_poff, d_pcounts);
+        hipLaunchKernelGGL(k_msm_part_scatter_st, dim3(nslices, W), dim3(256), 0, st, d_lo16, d_hi8, (uint32_t)n, (uint32_t)W, Gn, per_slice, nslices, d_poff,
+                           pre ? (uint32_t)bs.n : 0u, pre ? (uint32_t)first : 0u, d_part_lo, d_part_idx);  // plain: d_bases already starts at `first`
+        const uint32_t gstride = (uint32_t)W * nslices;  // counters per group
+        // level 2: 128 sub-groups (256 buckets each) per group; level 3: LDS-staged sort per sub-group
+        const uint32_t SG = Gn * 128;
+        uint32_t fsl = 16;
+        while (fsl * Gn < 2048 && fsl < 128) fsl *= 2;
+        const uint32_t P2 = SG * fsl;
+        const uint32_t p2scan_blocks = (P2 + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+        void* pd2;
+        const size_t b2_lo = b_plo, b2_idx = b_pidx, b2_c = (((size_t)(2 * (size_t)P2 + p2scan_blocks + 8) * 4 + 255) / 256) * 256;
+        if ((rc = zl_scratch_get(ctx, slotB, b2_lo + b2_idx + b2_c + 256, &pd2))) return rc;  // slot 6 is otherwise the NTT's scratch vector
+        unsigned char* q2 = (unsigned char*)pd2;
+        uint16_t* d_lo2 = (uint16_t*)q2; q2 += b2_lo;
+        uint32_t* d_idx2 = (uint32_t*)q2; q2 += b2_idx;
+        uint32_t* d_c2 = (uint32_t*)q2;
+        uint32_t* d_off2 = d_c2 + P2;  // P2 + 1
+        uint32_t* d_blk2 = d_off2 + P2 + 1;
+        hipLaunchKernelGGL(k_msm_sub_hist, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_poff, Gn, gstride, d_poff + P, fsl, d_c2);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_blk2, p2scan_blocks, d_off2 + P2, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_scan_apply, dim3(p2scan_blocks), dim3(SCAN_BLOCK), 0, st, d_c2, P2, d_blk2, d_off2, d_c2);
+        hipLaunchKernelGGL(k_msm_sub_scatter_st, dim3(fsl, Gn), dim3(256), 0, st, d_part_lo, d_part_idx, d_poff, Gn, gstride, d_poff + P, fsl, d_off2, d_lo2,
+                           d_idx2);
+        hipLaunchKernelGGL(k_msm_fine_hist, dim3(SG), dim3(256), 0, st, d_lo2, d_off2, SG, fsl, d_off2 + P2, d_counts);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+        // staged entries per block: at most 144 KiB + 1 KiB of cursors (1 block per CU); sub-groups average n*W/SG entries, so many small
+        // sub-groups (plain wide windows) get a smaller stage and two blocks per CU
+        uint32_t cap = (uint32_t)std::min<uint64_t>(36 * 1024, std::max<uint64_t>(4096, (maxE / SG) * 22 / 10));
+        cap = (uint32_t)std::max(1024, zl_tune("ZL_TUNE_FS_CAP", (int)cap));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_msm_fine_sort, dim3(SG), dim3(zl_tune("ZL_TUNE_FS", 1024)), (size_t)(256 + cap) * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_offsets, cap,
+                           d_entries, d_bigsg_head, d_bigsg_items);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msm_fine_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize, ZL_BT * 4);
+        hipLaunchKernelGGL(k_msm_fine_sort_big, dim3(512), dim3(1024), (size_t)ZL_BT * 4, st, d_lo2, d_idx2, d_off2, SG, fsl, d_off2 + P2, d_bigsg_head,
+                           d_bigsg_items, d_cursor, d_entries);
+        return ZL_OK;
+    }
+    // ---- LDS counting sort (c <= 16): recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
+    int sort_lds(zl_ctx* ctx, hipStream_t st, const uint32_t* sc_eff, const uint8_t* inf_eff, uint32_t* bad_eff, uint32_t nblk, int glv_i) {
+        int rc;
+        // LDS counting sort: recode once (u16 digits), per-(slice, window) LDS histograms, slice prefix, scan, range-owned scatter
+        uint32_t nslices = (256 + W - 1) / W;  // ~256+ blocks of 1024 lanes, one per CU (<= 128 KiB LDS each)
+        const uint32_t max_slices = (uint32_t)((n + 4095) / 4096);
+        if (nslices > max_slices) nslices = max_slices;
+        if (nslices < 1) nslices = 1;
+        const uint32_t per_slice = (uint32_t)((n + nslices - 1) / nslices);
+        void* pd;
+        if ((rc = zl_scratch_get(ctx, slotA, (size_t)n * W * 2 + (size_t)nslices * NB * 4 + 256, &pd))) return rc;
+        uint16_t* d_digits = (uint16_t*)pd;
+        uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
+        hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
+        hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
+        if (NB <= 16384 && nslices <= 64) {
+            hipLaunchKernelGGL(k_msm_prefix_small, dim3(1), dim3(1024), 0, st, d_slice_counts, NB, nslices, d_offsets, d_cursor, (const uint32_t*)d_bad_scalar);
+        } else {
+        hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+        }
+        // scatter: one block per (bucket range, window); ranges sized so that W * ranges ~ 256..512 blocks
+        uint32_t ranges = 1;
+        while (ranges * W < 256 && (H / (ranges * 2)) >= 64) ranges *= 2;
+        ranges = (uint32_t)std::max(1, zl_tune("ZL_TUNE_RANGES", (int)ranges));
+        const uint32_t RB = (H + ranges - 1) / ranges;
+        // (the digit row of a window can be walked by `parts` blocks, slice-aligned: measured 1 = 2 = 4 = 8 at 2^18 .. 2^21 -- the kernel is bound by
+        // its 4-byte scattered stores, 16.8 M of them in 0.19 ms at 2^20, not by the length of the row, the load latency or the LDS atomics)
+        const uint32_t parts = (uint32_t)std::max(1, std::min<int>((int)nslices, zl_tune("ZL_TUNE_SCATTER_PARTS", 1)));
+        hipLaunchKernelGGL(k_msm_scatter_range, dim3(8 * ((W + 7) / 8), ranges, parts), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries,
+                           (const uint32_t*)d_slice_counts, NB, nslices, per_slice, parts, (uint32_t)W);
+        return ZL_OK;
+    }
+    // ---- wide windows without a table beyond 255 sort groups (forced plain c >= 21): histogram / scatter with global atomics
+    int sort_atomics(zl_ctx* ctx, hipStream_t st, uint32_t nblk) {
+        // wide windows without a table: histogram / scatter with global atomics
+        hipLaunchKernelGGL((k_msm_digits<0>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_counts, (uint32_t*)nullptr, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, d_block_sums, scan_blocks, d_offsets + NB, (const uint32_t*)d_bad_scalar);
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums, d_offsets, d_cursor);
+        hipLaunchKernelGGL((k_msm_digits<1>), dim3(nblk), dim3(256), 0, st, sc, (uint32_t)n, c, W, d_cursor, d_entries, d_ones_list, d_ones_count, d_inf, (int)G::SC_BITS, d_bad_scalar);
+        (void)ctx;
         return ZL_OK;
     }
     // wg_per_cu > 0: the persistent form (pipelined batches) on wg_per_cu x CUs workgroups

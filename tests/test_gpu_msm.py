@@ -399,6 +399,45 @@ def test_msm_pipelined_batch_equals_single_calls(backend, curve, table):
     assert inf == einf and (got == exp).all()
 
 
+@pytest.mark.parametrize("table", [False, True], ids=["plain", "table"])
+def test_msm_side_by_side_large_jobs_phase_major(backend, table):
+    """Four jobs of 2^17 points in one batch take the phase-major issue order of msm_run_jobs_t (csrc/zl_msm.hip: jobs side by side on the lanes,
+    at most four of them, the biggest >= 2^17 points: all sorts first, then accumulations and tails -- Groth16's four G1 MSMs of a large circuit).
+    Every job against a single call and against (sum s_i k_i) G; one job is witness-like (zeros and ones), one is all zeros."""
+    import torch
+
+    curve = po.BLS12_381
+    n, r = 1 << 17, curve.fr.p
+    rng = np.random.Generator(np.random.PCG64(4242))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    h = backend.bases_generate(curve.cid, k)
+    if table:
+        backend.bases_precompute(h, 16)
+    vecs = []
+    for j in range(4):
+        S = ol.random_scalars(curve, n, 4300 + j)
+        if j == 1:
+            S[: n // 2] = 0
+            S[n // 2: 3 * n // 4] = ol.ints_to_limbs([1], 4)[0]
+        if j == 2:
+            S[:] = 0
+        vecs.append(S)
+    dev = [torch.from_numpy(S.view(np.int64)).cuda() for S in vecs]
+    torch.cuda.synchronize()
+    G = po.g1_generator(curve)
+    for rep in range(2):  # the second batch reuses the lanes' buffers and the ctx's event pool
+        batch = backend.msm_batch_partial_dev(h, [t.data_ptr() for t in dev], n)
+        for j in range(4):
+            single = backend.msm_partial_dev(h, dev[j].data_ptr(), n)
+            a, ai = backend.partials_sum(curve.cid, batch[j:j + 1])
+            b, bi = backend.partials_sum(curve.cid, single.reshape(1, -1))
+            assert ai == bi and (a == b).all(), (rep, j)
+            assert ol.limbs_to_point(curve, a, ai) == po.g1_mul(curve, _dot_mod_r_u64k(vecs[j], k64, r), G), (rep, j)
+    backend.bases_free(h)
+
+
 def test_msm_glv_edge_scalars(backend):
     """BLS12-381 G1 plain MSMs split every scalar with the endomorphism (k = k1 + k2 lambda, both halves balanced to 127 bits; csrc/zl_msm.hip
     k_glv_split).  Scalars that sit on the decision boundaries of the split -- multiples of lambda, lambda / 2 and its neighbours, 0, 1, r - 1 --
