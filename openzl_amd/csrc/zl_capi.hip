@@ -254,7 +254,15 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
         step <<= 2;
     }
     const size_t K = off.size();
-    if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+    if (!ctx->stream_copy) {
+        // In the priority class of the sort / tail streams, NOT the default one: the runtime spreads the default-priority streams of a process over a few
+        // hardware queues in creation order, and one more of them changes which streams of a later Groth16 proof share a queue (its G2 MSM and one of the four
+        // G1 lanes: +1 ms on the 958 465-constraint proof after a single zl_msm call with host scalars, profiles/r04_g16_hwq_ab.log).  The stream only carries
+        // H2D copies; priority means nothing to them.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) ? prio_hi : 0));
+    }
     std::vector<hipEvent_t> ev(K, nullptr);
     for (size_t j = 0; j < K; j++) {
         const hipError_t e = hipEventCreateWithFlags(&ev[j], hipEventDisableTiming);

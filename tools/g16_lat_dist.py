@@ -16,6 +16,9 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 be = Backend(0)
 be.enable_timing(True)
+if os.environ.get("PRE_LEGS"):
+    from pre_legs import run_pre_legs
+    run_pre_legs(be)
 circ = Circuit(ZL_BLS12_381, k)
 keys = Groth16Keys(be, circ, seed=1)
 ts = []

@@ -14,21 +14,8 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 be = Backend(0)
 be.enable_timing(True)
 if os.environ.get("PRE_LEGS"):
-    # what bench.py does in front of its Groth16 leg: a pipelined batch (sort / tail streams) and an MSM with host scalars (copy stream) -- the streams
-    # they create take part in the runtime's stream -> hardware-queue assignment of everything created later
-    import numpy as np
-    from bench import random_scalars_lt_r
-    n = 1 << 22
-    rng = np.random.Generator(np.random.PCG64(1))
-    kk = np.zeros((n, 4), dtype=np.uint64)
-    kk[:, 0] = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-    h = be.bases_generate(ZL_BLS12_381, kk)
-    sc = random_scalars_lt_r(n, 2)
-    d = torch.from_numpy(sc.view(np.int64)).cuda()
-    be.msm_batch_partial_dev(h, [d.data_ptr()] * 3, n)
-    be.msm(h, sc)
-    be.bases_free(h)
-    del d
+    from pre_legs import run_pre_legs
+    run_pre_legs(be)
 t0 = time.perf_counter(); circ = Circuit(ZL_BLS12_381, k); t1 = time.perf_counter()
 keys = Groth16Keys(be, circ, seed=1); t2 = time.perf_counter()
 print(f"synthesis {t1 - t0:.2f} s  setup {t2 - t1:.2f} s", flush=True)
