@@ -42,16 +42,20 @@ struct BnG1 {
     static constexpr int ID = 1;
     using FqP = BN254_Fq;
     using FrP = BN254_Fr;
-    using F = Fp<FqP>;
+#ifdef ZL_BN_FIELD32
+    using F = Fp<FqP>;  // rounds 1-3: 8 x 32-bit carry-chain limbs (developer A/B switch)
+#else
+    using F = Fp28<BN254_Fq28, BN254_Fq>;  // round 4: 10 x 28-bit lazily reduced limbs like BLS12-381 (zl_field28.h)
+#endif
     using C = BN254_G1;
     static constexpr int SC_BITS = 254;
     static constexpr int FQ64 = 4;
     static constexpr int COORDS = 1;
     static constexpr bool GLV = false;
     static constexpr int ENDO_K = 1;
-    ZL_HD static F gen_x() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gx(i); return r; }
-    ZL_HD static F gen_y() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::gy(i); return r; }
-    ZL_HD static F coeff_b() { F r; for (int i = 0; i < F::N; i++) r.l[i] = C::b(i); return r; }
+    ZL_HD static F gen_x() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gx(i); return FieldIO<F>::load_mont32(w); }
+    ZL_HD static F gen_y() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gy(i); return FieldIO<F>::load_mont32(w); }
+    ZL_HD static F coeff_b() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::b(i); return FieldIO<F>::load_mont32(w); }
 };
 template <class C2, class FqP_, class FrP_, class F_, int SCB, int FQ64_, int ID_>
 struct G2Cfg {

@@ -1,4 +1,6 @@
-// zl_field28.h -- BLS12-381 base field on 14 unsaturated 28-bit limbs with lazy reduction (gfx950 MSM kernels).
+// zl_field28.h -- base fields on unsaturated 28-bit limbs with lazy reduction (gfx950 MSM kernels): BLS12-381 Fq on 14 limbs (R' = 2^392), and from
+// round 4 BN254 Fq on 10 limbs (R' = 2^280: the same contracts hold a fortiori -- q < 2^254 leaves 26 spare bits, gen_params.py asserts the limits the
+// bound proofs of zl_bounds.h assume).  The text below speaks of the 14-limb instance.
 //
 // Why: v_mad_u64_u32 accumulates 64 bits; with 28-bit limbs a column of <= 28 products (< 2^56 each) never overflows, so the
 // Montgomery product is a pure chain of 392 mads with no carry handling at all (the 32-bit-limb multiplier needs a
@@ -15,7 +17,8 @@
 // intermediate.  Memory / ABI formats are unchanged: load_* / store_* convert from / to arkworks' 32-bit-word layouts.
 #pragma once
 #include "zl_field.h"
-#include "zl_mul28_gfx950.h"  // single-chain inline-asm product scans for 14 limbs (device only; gen_mul28.py)
+#include "zl_mul28_gfx950.h"   // single-chain inline-asm product scans for 14 limbs (device only; gen_mul28.py)
+#include "zl_mul28r_gfx950.h"  // ... and for 10 limbs
 
 template <class P28, class P32>
 struct alignas(16) Fp28 {
@@ -261,6 +264,7 @@ ZL_HD Fp28<A, B> muladd4_body28(const Fp28<A, B>& a, const Fp28<A, B>& b, const 
 #if !defined(__HIP_DEVICE_COMPILE__)
 template <class A>
 struct Host56 {
+    static constexpr int H = A::L / 2;  // limbs of 56 bits (7 for BLS12-381, 5 for BN254)
     static constexpr uint64_t M56 = (1ull << 56) - 1;
     static uint64_t q(int j) { return (uint64_t)A::mod(2 * j) | ((uint64_t)A::mod(2 * j + 1) << 28); }
     static uint64_t inv() {  // -q^-1 mod 2^56 from the 28-bit constant by one Newton step
@@ -271,7 +275,7 @@ struct Host56 {
     }
     template <class F>
     static void load(const F& a, uint64_t* o) {
-        for (int j = 0; j < 7; j++) o[j] = (uint64_t)a.l[2 * j] | ((uint64_t)a.l[2 * j + 1] << 28);  // top limb may exceed 28 bits: < 2^58 here
+        for (int j = 0; j < H; j++) o[j] = (uint64_t)a.l[2 * j] | ((uint64_t)a.l[2 * j + 1] << 28);  // top limb may exceed 28 bits: < 2^58 here
     }
     // r = (a*b [+ c*d]) / 2^392 mod q (+ multiple of q): product scan in base 2^56, one 128-bit column accumulator (a column holds at most
     // 7 + 7 products of < 2^116 and 7 of m q < 2^112: < 2^120), no per-product masking; SQ = a is b (28 distinct products instead of 49)
@@ -279,16 +283,16 @@ struct Host56 {
     static F mac_t(const F& a, const F& b, const F* c, const F* d) {
         typedef unsigned __int128 u128;
         static const uint64_t ninv = inv();
-        uint64_t qa[7], x[7], y[7], u[7], v[7], m[7], t[8];
+        uint64_t qa[H], x[H], y[H], u[H], v[H], m[H], t[H + 1];
 #pragma unroll
-        for (int j = 0; j < 7; j++) qa[j] = q(j);
+        for (int j = 0; j < H; j++) qa[j] = q(j);
         load(a, x);
         if (!SQ) load(b, y);
         if (CD) { load(*c, u); load(*d, v); }
         u128 acc = 0;
 #pragma unroll
-        for (int k = 0; k < 14; k++) {
-            const int lo = k < 7 ? 0 : k - 6, hi = k < 7 ? k : 6;
+        for (int k = 0; k < 2 * H; k++) {
+            const int lo = k < H ? 0 : k - (H - 1), hi = k < H ? k : H - 1;
             if (SQ) {
                 u128 cross = 0;
 #pragma unroll
@@ -303,26 +307,26 @@ struct Host56 {
 #pragma unroll
                 for (int i = lo; i <= hi; i++) acc += (u128)u[i] * v[k - i];
             }
-            if (k < 7) {
+            if (k < H) {
 #pragma unroll
                 for (int i = 0; i < k; i++) acc += (u128)m[i] * qa[k - i];
                 m[k] = ((uint64_t)acc * ninv) & M56;
                 acc += (u128)m[k] * qa[0];
             } else {
 #pragma unroll
-                for (int i = lo; i <= 6; i++) acc += (u128)m[i] * qa[k - i];
-                t[k - 7] = (uint64_t)acc & M56;
+                for (int i = lo; i <= H - 1; i++) acc += (u128)m[i] * qa[k - i];
+                t[k - H] = (uint64_t)acc & M56;
             }
             acc >>= 56;
         }
-        t[7] = (uint64_t)acc;
+        t[H] = (uint64_t)acc;
         F r = a;
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
+        for (int j = 0; j < H; j++) {
             r.l[2 * j] = (uint32_t)(t[j] & 0xFFFFFFFull);
             r.l[2 * j + 1] = (uint32_t)(t[j] >> 28);
         }
-        r.l[13] += (uint32_t)(t[7] << 28);  // zero for in-contract operands (result < 2q)
+        r.l[A::L - 1] += (uint32_t)(t[H] << 28);  // zero for in-contract operands (result < 2q)
         return r;
     }
     template <class F>
@@ -336,7 +340,7 @@ struct Host56 {
 template <class A, class B>
 ZL_NOINLINE_HD Fp28<A, B> muladd_call28(Fp28<A, B> a, Fp28<A, B> b, Fp28<A, B> c, Fp28<A, B> d) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (A::L == 14) return Host56<A>::mac(a, b, &c, &d);
+    if constexpr (A::L % 2 == 0) return Host56<A>::mac(a, b, &c, &d);
 #endif
     return muladd_body28(a, b, c, d);
 }
@@ -347,6 +351,10 @@ ZL_HD Fp28<A, B> muladd(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, 
     if constexpr (A::L == 14) {
         Fp28<A, B> r = a;
         muladd28_asm<A>(r.l, a.l, b.l, c.l, d.l);
+        return r;
+    } else if constexpr (A::L == 10) {
+        Fp28<A, B> r = a;
+        muladd28r_asm<A>(r.l, a.l, b.l, c.l, d.l);
         return r;
     }
 #endif
@@ -359,7 +367,7 @@ ZL_HD Fp28<A, B> muladd(const Fp28<A, B>& a, const Fp28<A, B>& b, const Fp28<A, 
 template <class A, class B>
 ZL_NOINLINE_HD Fp28<A, B> mul_call28(Fp28<A, B> a, Fp28<A, B> b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (A::L == 14) return Host56<A>::mac(a, b, (const Fp28<A, B>*)nullptr, (const Fp28<A, B>*)nullptr);
+    if constexpr (A::L % 2 == 0) return Host56<A>::mac(a, b, (const Fp28<A, B>*)nullptr, (const Fp28<A, B>*)nullptr);
 #endif
     return mul_body28(a, b);
 }
@@ -375,6 +383,10 @@ ZL_HD Fp28<A, B> mul(const Fp28<A, B>& a, const Fp28<A, B>& b) {
     if constexpr (A::L == 14) {
         Fp28<A, B> r = a;
         mul28_asm<A>(r.l, a.l, b.l);
+        return r;
+    } else if constexpr (A::L == 10) {
+        Fp28<A, B> r = a;
+        mul28r_asm<A>(r.l, a.l, b.l);
         return r;
     }
 #endif
@@ -397,18 +409,25 @@ ZL_HD Fp28<A, B> sqr(const Fp28<A, B>& a) {
         Fp28<A, B> r = a;
         sqr28_asm<A>(r.l, a.l);
         return r;
+    } else if constexpr (A::L == 10) {
+        Fp28<A, B> r = a;
+        sqr28r_asm<A>(r.l, a.l);
+        return r;
     }
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (A::L == 14) return sqr_host28<A, B>(a);
+    if constexpr (A::L % 2 == 0) return sqr_host28<A, B>(a);
 #endif
     return mul(a, a);
 }
-// weak reduction: value < 2000 q -> < 4q.  t = floor(top_limb * floor(2^44 / (qtop+1)) / 2^44) <= floor(a / q), short by <= 2
+// weak reduction: value < 2000 q -> < 4q.  t = floor(top * floor(2^K / (qtop+1)) / 2^K) <= floor(a / q), short by <= 2 (a carried: the limb below the top < 2^28)
 template <class A, class B>
 ZL_HD Fp28<A, B> wred(const Fp28<A, B>& a) {
     constexpr int L = A::L;
-    const uint32_t t = (uint32_t)(((uint64_t)a.l[L - 1] * A::QTOP_RECIP) >> 44);
+    // quotient estimate from the top limb (BLS12-381: q >> 364 has 17 bits) or the top two (BN254: the top limb of q has 2 bits, q >> 224 has 30)
+    uint64_t top = a.l[L - 1];
+    if constexpr (A::QTOP_LIMBS == 2) top = (top << 28) + a.l[L - 2];
+    const uint32_t t = (uint32_t)((top * A::QTOP_RECIP) >> A::QTOP_K);
     Fp28<A, B> r = a;
     int64_t c = 0;
 #pragma unroll
