@@ -29,6 +29,9 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
  *     scan-only operand forms (un-carried on the device, zl_field28.h subk_scan / negk_scan / x3_of; b, c, d carried, c, d < 8q in op 19, a < 2q in op 20):
  *     19 muladd(a, b - c + 16q, 16q - d, a)   20 mul(4q - a, b)   21 a - b - 2c + 6q (b, c < 2^28 per limb) */
 int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out);
+/* The same operations on the 10-limb BN254 base field (round 4: Fp28<BN254_Fq28, BN254_Fq>, R' = 2^280): records of 4 operands x 10 u32 limbs -> 10 limbs;
+ * ops 17 / 18 move 8 canonical words.  (muladd4 and the Fq2 helpers are not used by BN254 G1; op 15 still computes.) */
+int zl_test_fp28_bn_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out);
 
 /* Point formulas of zl_curve.h over that field.  group: ZL_G1 (coordinate = 14 words) or ZL_G2 (coordinate = 2 x 14 words);
  * hot != 0 selects, for G2, the flavour with inlined product scans that the bucket accumulation kernel uses.

@@ -145,6 +145,7 @@ def load_library(path: Optional[str] = None):
     u32p = C.POINTER(C.c_uint32)
     L.zl_test_poseidon_permute_dev.argtypes = [vp, C.c_int, u64p]
     L.zl_test_fp28_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_fp28_bn_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_circuit_tweak.argtypes = [vp]
     L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -398,7 +399,7 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
 
 
 def _p32(a: np.ndarray):
@@ -413,15 +414,17 @@ def hook_poseidon_permute_dev(be: "Backend", curve: int, state: np.ndarray) -> n
     return st
 
 
-def hook_fp28_op(be: Optional["Backend"], op: int, operands: np.ndarray) -> np.ndarray:
-    """operands: (n, 4, 14) uint32 raw limbs -> (n, 14); be = None runs the host code path"""
+def hook_fp28_op(be: Optional["Backend"], op: int, operands: np.ndarray, bn254: bool = False) -> np.ndarray:
+    """operands: (n, 4, L) uint32 raw limbs -> (n, L), L = 14 (BLS12-381 Fq) or 10 (bn254=True: BN254 Fq); be = None runs the host code path"""
     a = np.ascontiguousarray(operands, dtype=np.uint32)
-    n = a.shape[0]
-    out = np.zeros((n, 14), dtype=np.uint32)
+    n, limbs = a.shape[0], (10 if bn254 else 14)
+    assert a.shape[1:] == (4, limbs)
+    out = np.zeros((n, limbs), dtype=np.uint32)
     L = load_library()
-    rc = L.zl_test_fp28_op(be._ctx if be is not None else None, op, _p32(a), n, _p32(out))
+    fn = L.zl_test_fp28_bn_op if bn254 else L.zl_test_fp28_op
+    rc = fn(be._ctx if be is not None else None, op, _p32(a), n, _p32(out))
     if rc:
-        raise BackendError(rc, "zl_test_fp28_op")
+        raise BackendError(rc, "zl_test_fp28_bn_op" if bn254 else "zl_test_fp28_op")
     return out
 
 

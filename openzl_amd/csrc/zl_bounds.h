@@ -8,6 +8,8 @@
 // to_affine -- over the base field (G1) and over Fq2 in both flavours (inlined four-product scans / called dual scans) (G2) -- with
 // every coordinate at the contract's maximum (8q), plus the closure property: results are <= 8q again, so any sequence of group
 // operations stays inside the contracts.  tests/test_field28_bounds.py drives the real arithmetic at the same bounds (host + device).
+// The constants below are those of the 14-limb BLS12-381 instance, the tighter one; the 10-limb BN254 instance (round 4) has 26 spare bits instead of 11, and
+// gen_params.py asserts for every instance it emits that 2500 q < R' and that the top limb of 40000 q fits 32 bits, so one proof covers both.
 #pragma once
 
 namespace zl {

@@ -89,17 +89,22 @@ static int poseidon_dev_t(zl_ctx* ctx, uint64_t* state) {
 using F28 = BlsG1::F;
 static_assert(F28::L == 14, "test hooks are written for the 14-limb field");
 
-ZL_HD static F28 raw_load(const uint32_t* w) {
-    F28 r = F28::zero();
-    for (int i = 0; i < 14; i++) r.l[i] = w[i];
+template <class F = F28>
+ZL_HD static F raw_load(const uint32_t* w) {
+    F r = F::zero();
+    for (int i = 0; i < F::L; i++) r.l[i] = w[i];
     return r;
 }
-ZL_HD static void raw_store(uint32_t* w, const F28& a) {
-    for (int i = 0; i < 14; i++) w[i] = a.l[i];
+template <class F = F28>
+ZL_HD static void raw_store(uint32_t* w, const F& a) {
+    for (int i = 0; i < F::L; i++) w[i] = a.l[i];
 }
+// one field operation on raw limbs; F = the 14-limb BLS12-381 field (zl_test_fp28_op) or the 10-limb BN254 field (zl_test_fp28_bn_op, round 4)
+template <class F>
 ZL_HD static void fp28_op(int op, const uint32_t* in, uint32_t* out) {
-    const F28 a = raw_load(in), b = raw_load(in + 14), c = raw_load(in + 28), d = raw_load(in + 42);
-    F28 r = F28::zero();
+    constexpr int L = F::L, CW = F::CANON_WORDS;
+    const F a = raw_load<F>(in), b = raw_load<F>(in + L), c = raw_load<F>(in + 2 * L), d = raw_load<F>(in + 3 * L);
+    F r = F::zero();
     switch (op) {
     case 0: r = zl::mul(a, b); break;
     case 1: r = zl::sqr(a); break;
@@ -120,21 +125,22 @@ ZL_HD static void fp28_op(int op, const uint32_t* in, uint32_t* out) {
     case 19: r = zl::muladd(a, zl::subk_scan<4>(b, c), zl::negk_scan<4>(d), a); break;  // a (b - c + 16q) + (16q - d) a: scan-only operands (un-carried on the device)
     case 20: r = zl::mul(zl::negk_scan<2>(a), b); break;                                  // (4q - a) b
     case 21: r = zl::x3_of(a, b, c); break;                                               // a - b - 2c + 6q in one pass (device), b, c carried
-    case 17: r = FieldIO<F28>::load_canon(in); break;
+    case 17: r = FieldIO<F>::load_canon(in); break;
     case 18: {
-        uint32_t w[12];
-        FieldIO<F28>::store_canon(w, a);
-        for (int i = 0; i < 12; i++) r.l[i] = w[i];
+        uint32_t w[CW];
+        FieldIO<F>::store_canon(w, a);
+        for (int i = 0; i < CW; i++) r.l[i] = w[i];
         break;
     }
     default: break;
     }
-    raw_store(out, r);
+    raw_store<F>(out, r);
 }
+template <class F>
 static __global__ void __launch_bounds__(64) k_test_fp28(int op, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fp28_op(op, in + (size_t)i * 56, out + (size_t)i * 14);
+    fp28_op<F>(op, in + (size_t)i * 4 * F::L, out + (size_t)i * F::L);
 }
 
 
@@ -265,6 +271,21 @@ __global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sin
     sink[t] = acc;
 }
 
+template <class F>
+static int test_fp28_op_t(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) {
+    if ((!in || !out) && n) return ZL_EINVAL;
+    if (op < 0 || op > 21 || op == 16 || n >= (1u << 24)) return ZL_EINVAL;
+    if (!n) return ZL_OK;
+    constexpr size_t L = F::L;
+    if (!ctx) {
+        for (size_t i = 0; i < n; i++) fp28_op<F>(op, in + i * 4 * L, out + i * L);
+        return ZL_OK;
+    }
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return run_dev(ctx, in, n * 4 * L, out, n * L, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
+        hipLaunchKernelGGL((k_test_fp28<F>), dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, op, d_in, (uint32_t)n, d_out);
+    });
+}
 extern "C" {
 
 int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state) {
@@ -275,19 +296,12 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
     return ZL_EINVAL;
 }
 
-int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) {
-    if ((!in || !out) && n) return ZL_EINVAL;
-    if (op < 0 || op > 21 || op == 16 || n >= (1u << 24)) return ZL_EINVAL;
-    if (!n) return ZL_OK;
-    if (!ctx) {
-        for (size_t i = 0; i < n; i++) fp28_op(op, in + i * 56, out + i * 14);
-        return ZL_OK;
-    }
-    ZL_HIP(ctx, hipSetDevice(ctx->device));
-    return run_dev(ctx, in, n * 56, out, n * 14, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
-        hipLaunchKernelGGL(k_test_fp28, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, st, op, d_in, (uint32_t)n, d_out);
-    });
-}
+int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) { return test_fp28_op_t<F28>(ctx, op, in, n, out); }
+#ifndef ZL_BN_FIELD32
+int zl_test_fp28_bn_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) { return test_fp28_op_t<BnG1::F>(ctx, op, in, n, out); }
+#else
+int zl_test_fp28_bn_op(zl_ctx*, int, const uint32_t*, size_t, uint32_t*) { return ZL_EINVAL; }  // (the A/B build keeps BN254 on the 32-bit field)
+#endif
 
 int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint32_t* in, size_t n, uint32_t* out) {
     if ((!in || !out) && n) return ZL_EINVAL;

@@ -5,7 +5,8 @@ for the formulas at compile time (csrc/zl_bounds.h, static_asserts over an abstr
 operands AT the contract bounds -- values a random MSM never produces -- and compared with Python big integers:
   host path   (-m "not gpu"): the 7 x 56-bit fast path + C++ scans that the host tails use,
   device path (-m gpu):       the single-chain inline-asm product scans the kernels use.
-Montgomery radix of the 28-bit field: R' = 2^392.
+Montgomery radix of the 28-bit field: R' = 2^392.  Round 4: the field arithmetic is driven the same way for the BN254 instance (10 limbs, R' = 2^280; the point
+formulas are the same templates, proved once over the abstract bound domain, and gen_params.py asserts that BN254's limits are at least the abstract ones).
 """
 import numpy as np
 import pytest
@@ -20,14 +21,27 @@ RP_INV = pow(RP, -1, Q)
 M28 = (1 << 28) - 1
 
 
-def to_limbs(v: int) -> np.ndarray:
-    """value < 2^396 -> 14 limbs, limbs 0..12 < 2^28, the top limb absorbs the rest (as carry28 leaves it)"""
-    out = np.zeros(14, dtype=np.uint32)
-    for i in range(13):
+class _FieldCfg:
+    """one instance of zl_field28.h: modulus, limb count, Montgomery radix R' = 2^(28 L), canonical 32-bit words, which test hook"""
+    def __init__(self, q: int, L: int, bn254: bool):
+        self.Q, self.L, self.bn254 = q, L, bn254
+        self.RP = 1 << (28 * L)
+        self.RP_INV = pow(self.RP, -1, q)
+        self.words = (q.bit_length() + 31) // 32
+
+
+BLS_FQ = _FieldCfg(po.BLS12_381.fq.p, 14, False)
+BN_FQ = _FieldCfg(po.BN254.fq.p, 10, True)   # round 4: BN254 G1 on the same lazily reduced limbs (10 of them, R' = 2^280)
+
+
+def to_limbs(v: int, L: int = 14) -> np.ndarray:
+    """value < 2^(28 L + 4) -> L limbs, limbs 0..L-2 < 2^28, the top limb absorbs the rest (as carry28 leaves it)"""
+    out = np.zeros(L, dtype=np.uint32)
+    for i in range(L - 1):
         out[i] = (v >> (28 * i)) & M28
-    top = v >> (28 * 13)
+    top = v >> (28 * (L - 1))
     assert top < (1 << 32)
-    out[13] = top
+    out[L - 1] = top
     return out
 
 
@@ -35,7 +49,7 @@ def from_limbs(l) -> int:
     return sum(int(x) << (28 * i) for i, x in enumerate(l))
 
 
-def edge_values(bound: int, rng, count: int):
+def edge_values(bound: int, rng, count: int, Q: int = Q):
     """values <= bound*q concentrated at the edges: k*q - 1, k*q, k*q + 1 for the top multiples, 0, 1, random residues + (bound-1)*q"""
     vals = [0, 1, Q - 1, Q, bound * Q - 1, bound * Q, max(0, (bound - 1)) * Q + 1]
     vals += [bound * Q - int(rng.integers(1, 1 << 62)) for _ in range(4)]
@@ -44,119 +58,122 @@ def edge_values(bound: int, rng, count: int):
     return [v for v in vals if 0 <= v <= bound * Q][:count]
 
 
-def _run_field(be, op, rows):
-    arr = np.zeros((len(rows), 4, 14), dtype=np.uint32)
+def _run_field(be, op, rows, cfg=BLS_FQ):
+    arr = np.zeros((len(rows), 4, cfg.L), dtype=np.uint32)
     for i, row in enumerate(rows):
         for j, v in enumerate(row):
-            arr[i, j] = to_limbs(v)
-    return hook_fp28_op(be, op, arr)
+            arr[i, j] = to_limbs(v, cfg.L)
+    return hook_fp28_op(be, op, arr, bn254=cfg.bn254)
 
 
-def _check_field(be):
+def _check_field(be, cfg=BLS_FQ):
+    Q, RP, RP_INV, L, NW = cfg.Q, cfg.RP, cfg.RP_INV, cfg.L, cfg.words
+    _ev = edge_values
+    edge_values_q = lambda bound, rng_, count: _ev(bound, rng_, count, Q)
     rng = np.random.Generator(np.random.PCG64(28))
     # mul / sqr / muladd: every split of the product budget B(a)*B(b) <= 2500
     for ba, bb in [(1, 1), (2, 2), (8, 2), (10, 10), (16, 16), (50, 50), (2500, 1), (1, 2500), (1250, 2), (100, 25)]:
-        A, Bv = edge_values(ba, rng, 24), edge_values(bb, rng, 24)
+        A, Bv = edge_values_q(ba, rng, 24), edge_values_q(bb, rng, 24)
         n = min(len(A), len(Bv))
         rows = [(A[i], Bv[(i * 7) % n], 0, 0) for i in range(n)] + [(A[0 if i else -1], Bv[i], 0, 0) for i in range(n)]
-        out = _run_field(be, 0, rows)
+        out = _run_field(be, 0, rows, cfg)
         for (a, b, _, _), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == a * b * RP_INV % Q, (ba, bb)
         if ba == bb:
-            out = _run_field(be, 1, [(a, 0, 0, 0) for a in A])
+            out = _run_field(be, 1, [(a, 0, 0, 0) for a in A], cfg)
             for a, o in zip(A, out):
                 v = from_limbs(o)
                 assert v < 2 * Q and (o <= M28).all() and v % Q == a * a * RP_INV % Q, ba
     for (ba, bb, bc, bd) in [(10, 10, 8, 2), (6, 10, 2, 8), (4, 10, 2, 2), (16, 16, 16, 16), (35, 35, 35, 35), (2400, 1, 100, 1), (1, 1250, 1250, 1)]:
-        A, Bv, Cv, D = (edge_values(b, rng, 20) for b in (ba, bb, bc, bd))
+        A, Bv, Cv, D = (edge_values_q(b, rng, 20) for b in (ba, bb, bc, bd))
         n = min(map(len, (A, Bv, Cv, D)))
         rows = [(A[i], Bv[(3 * i) % n], Cv[(5 * i) % n], D[(7 * i) % n]) for i in range(n)] + [(A[4], Bv[4], Cv[4], D[4])]
-        out = _run_field(be, 2, rows)
+        out = _run_field(be, 2, rows, cfg)
         for (a, b, c, d), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (a * b + c * d) * RP_INV % Q, (ba, bb, bc, bd)
     # muladd4(a,b,c,d,a,d,c,b): four products, budget 2500 in total (Fq2 components: operands <= 16q)
     for b4 in (16, 25):
-        A, Bv, Cv, D = (edge_values(b4, rng, 16) for _ in range(4))
+        A, Bv, Cv, D = (edge_values_q(b4, rng, 16) for _ in range(4))
         n = min(map(len, (A, Bv, Cv, D)))
         rows = [(A[i], Bv[i], Cv[i], D[i]) for i in range(n)]
-        out = _run_field(be, 15, rows)
+        out = _run_field(be, 15, rows, cfg)
         for (a, b, c, d), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (a * b + c * d + a * d + c * b) * RP_INV % Q
     if True:
         # scan-only operand forms (subk_scan / negk_scan / x3_of: un-carried on the device, carried on the host).  19: a (b - c + 16q) + (16q - d) a with b, c, d carried,
         # c, d < 8q (the bias is one step larger than the carried form's, so that the top limb never wraps); 20: (4q - a) b with a < 2q
-        A, Bv, Cv, D = edge_values(10, rng, 24), edge_values(2, rng, 24), edge_values(8, rng, 24), edge_values(8, rng, 24)
+        A, Bv, Cv, D = edge_values_q(10, rng, 24), edge_values_q(2, rng, 24), edge_values_q(8, rng, 24), edge_values_q(8, rng, 24)
         Cv = [min(c, 8 * Q - 1) for c in Cv]
         D = [min(d, 8 * Q - 1) for d in D]
         n = min(map(len, (A, Bv, Cv, D)))
         rows = [(A[i], Bv[(3 * i) % n], Cv[(5 * i) % n], D[(7 * i) % n]) for i in range(n)]
         rows += [(10 * Q - 1, 2 * Q - 1, 0, 0), (10 * Q - 1, 0, 8 * Q - 1, 8 * Q - 1), (10 * Q - 1, 2 * Q - 1, 8 * Q - 1, 0), (1, 0, 8 * Q - 1, 8 * Q - 1)]
-        out = _run_field(be, 19, rows)
+        out = _run_field(be, 19, rows, cfg)
         for (a, b, c, d), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (a * (b - c + 16 * Q) + (16 * Q - d) * a) * RP_INV % Q, (a // Q, b // Q, c // Q, d // Q)
-        A2 = [min(a, 2 * Q - 1) for a in edge_values(2, rng, 24)]
-        B2 = edge_values(8, rng, len(A2))
+        A2 = [min(a, 2 * Q - 1) for a in edge_values_q(2, rng, 24)]
+        B2 = edge_values_q(8, rng, len(A2))
         rows = [(a, b, 0, 0) for a, b in zip(A2, B2)] + [(2 * Q - 1, 8 * Q, 0, 0), (0, 8 * Q, 0, 0)]
-        out = _run_field(be, 20, rows)
+        out = _run_field(be, 20, rows, cfg)
         for (a, b, _, _), o in zip(rows, out):
             v = from_limbs(o)
             assert v < 2 * Q and (o <= M28).all() and v % Q == (4 * Q - a) * b * RP_INV % Q
         # 21: x3 = a - b - 2c + 6q in one pass; b, c carried values (scan outputs < 2q in the formulas; any carried value is admissible)
-        A3, B3, C3 = edge_values(2, rng, 24), edge_values(2, rng, 24), edge_values(2, rng, 24)
+        A3, B3, C3 = edge_values_q(2, rng, 24), edge_values_q(2, rng, 24), edge_values_q(2, rng, 24)
         rows = [(a, b, c, 0) for a, b, c in zip(A3, B3, C3)] + [(0, 2 * Q - 1, 2 * Q - 1, 0), (2 * Q - 1, 0, 0, 0), (0, 0, 0, 0)]
-        out = _run_field(be, 21, rows)
+        out = _run_field(be, 21, rows, cfg)
         for (a, b, c, _), o in zip(rows, out):
-            assert from_limbs(o) == a - b - 2 * c + 6 * Q and (o[:13] <= M28).all()
+            assert from_limbs(o) == a - b - 2 * c + 6 * Q and (o[:L - 1] <= M28).all()
     # add / dbl: exact integer results, normalised limbs
-    A, Bv = edge_values(1000, rng, 24), edge_values(1000, rng, 24)
-    out = _run_field(be, 3, [(a, b, 0, 0) for a, b in zip(A, Bv)])
+    A, Bv = edge_values_q(1000, rng, 24), edge_values_q(1000, rng, 24)
+    out = _run_field(be, 3, [(a, b, 0, 0) for a, b in zip(A, Bv)], cfg)
     for a, b, o in zip(A, Bv, out):
-        assert from_limbs(o) == a + b and (o[:13] <= M28).all()
-    out = _run_field(be, 4, [(a, 0, 0, 0) for a in A])
+        assert from_limbs(o) == a + b and (o[:L - 1] <= M28).all()
+    out = _run_field(be, 4, [(a, 0, 0, 0) for a in A], cfg)
     for a, o in zip(A, out):
-        assert from_limbs(o) == 2 * a and (o[:13] <= M28).all()
+        assert from_limbs(o) == 2 * a and (o[:L - 1] <= M28).all()
     # subk<J>: a - b + 2^J q exactly, for b up to (and at) 2^J q and a from 0 up to a large bound
     for J in range(1, 7):
-        Bv = edge_values(1 << J, rng, 24)
-        A = edge_values(64, rng, len(Bv))
+        Bv = edge_values_q(1 << J, rng, 24)
+        A = edge_values_q(64, rng, len(Bv))
         rows = [(a, b, 0, 0) for a, b in zip(A, Bv)] + [(0, b, 0, 0) for b in Bv]
-        out = _run_field(be, 4 + J, rows)
+        out = _run_field(be, 4 + J, rows, cfg)
         for (a, b, _, _), o in zip(rows, out):
-            assert from_limbs(o) == a - b + (Q << J) and (o[:13] <= M28).all(), J
+            assert from_limbs(o) == a - b + (Q << J) and (o[:L - 1] <= M28).all(), J
     # wred (<= 2000 q -> < 4q, same residue), canon, is_zero, ==
-    A = edge_values(2000, rng, 40) + [k * Q for k in (2, 3, 4, 5, 100, 1999, 2000)] + [k * Q + 1 for k in (3, 4, 1999)] + [k * Q - 1 for k in (1, 4, 2000)]
-    out = _run_field(be, 11, [(a, 0, 0, 0) for a in A])
+    A = edge_values_q(2000, rng, 40) + [k * Q for k in (2, 3, 4, 5, 100, 1999, 2000)] + [k * Q + 1 for k in (3, 4, 1999)] + [k * Q - 1 for k in (1, 4, 2000)]
+    out = _run_field(be, 11, [(a, 0, 0, 0) for a in A], cfg)
     for a, o in zip(A, out):
         v = from_limbs(o)
         assert v < 4 * Q and v % Q == a % Q and (o <= M28).all()
-    out = _run_field(be, 12, [(a, 0, 0, 0) for a in A])
+    out = _run_field(be, 12, [(a, 0, 0, 0) for a in A], cfg)
     for a, o in zip(A, out):
         assert from_limbs(o) == a % Q
-    out = _run_field(be, 13, [(a, 0, 0, 0) for a in A])
+    out = _run_field(be, 13, [(a, 0, 0, 0) for a in A], cfg)
     for a, o in zip(A, out):
         assert int(o[0]) == (1 if a % Q == 0 else 0), a // Q
     Bv = [a + Q * int(rng.integers(0, 3)) if i % 2 else a + 1 for i, a in enumerate(A)]
-    out = _run_field(be, 14, [(a, b, 0, 0) for a, b in zip(A, Bv)])
+    out = _run_field(be, 14, [(a, b, 0, 0) for a, b in zip(A, Bv)], cfg)
     for a, b, o in zip(A, Bv, out):
         assert int(o[0]) == (1 if (a - b) % Q == 0 else 0)
     # ABI conversions: canonical 32-bit words -> Montgomery limbs -> canonical words
     canon = [0, 1, Q - 1, Q - 2, int.from_bytes(rng.bytes(48), "little") % Q]
-    arr = np.zeros((len(canon), 4, 14), dtype=np.uint32)
+    arr = np.zeros((len(canon), 4, L), dtype=np.uint32)
     for i, v in enumerate(canon):
-        arr[i, 0, :12] = np.array([(v >> (32 * k)) & 0xFFFFFFFF for k in range(12)], dtype=np.uint32)
-    mont = hook_fp28_op(be, 17, arr)
+        arr[i, 0, :NW] = np.array([(v >> (32 * k)) & 0xFFFFFFFF for k in range(NW)], dtype=np.uint32)
+    mont = hook_fp28_op(be, 17, arr, bn254=cfg.bn254)
     for v, o in zip(canon, mont):
         assert from_limbs(o) == v * RP % Q
-    arr2 = np.zeros((len(canon), 4, 14), dtype=np.uint32)
+    arr2 = np.zeros((len(canon), 4, L), dtype=np.uint32)
     for i, v in enumerate(canon):
-        arr2[i, 0] = to_limbs(v * RP % Q + 3 * Q)  # store_canon accepts a lazily reduced value
-    back = hook_fp28_op(be, 18, arr2)
+        arr2[i, 0] = to_limbs(v * RP % Q + 3 * Q, L)  # store_canon accepts a lazily reduced value
+    back = hook_fp28_op(be, 18, arr2, bn254=cfg.bn254)
     for v, o in zip(canon, back):
-        assert sum(int(x) << (32 * k) for k, x in enumerate(o[:12])) == v
+        assert sum(int(x) << (32 * k) for k, x in enumerate(o[:NW])) == v
 
 
 # ---- points ------------------------------------------------------------------------------------------------------------------------
@@ -337,8 +354,9 @@ def _check_points(be, group, hot):
                 assert f.maxval(o[0]) < Q and f.maxval(o[1]) < Q
 
 
-def test_fp28_contract_edges_host():
-    _check_field(None)
+@pytest.mark.parametrize("cfg", [BLS_FQ, BN_FQ], ids=["bls12_381", "bn254"])
+def test_fp28_contract_edges_host(cfg):
+    _check_field(None, cfg)
 
 
 @pytest.mark.parametrize("group,hot", [(ZL_G1, False), (ZL_G2, False), (ZL_G2, True)], ids=["g1", "g2-called", "g2-inlined"])
@@ -347,8 +365,9 @@ def test_point_formulas_at_bounds_host(group, hot):
 
 
 @pytest.mark.gpu
-def test_fp28_contract_edges_device(backend):
-    _check_field(backend)
+@pytest.mark.parametrize("cfg", [BLS_FQ, BN_FQ], ids=["bls12_381", "bn254"])
+def test_fp28_contract_edges_device(backend, cfg):
+    _check_field(backend, cfg)
 
 
 @pytest.mark.gpu
