@@ -82,9 +82,13 @@ struct G2Cfg {
     ZL_HD static F gen_y() { return mk(C2::gy0, C2::gy1); }
     ZL_HD static F coeff_b() { return mk(C2::b0, C2::b1); }
 };
-// BLS12-381 G2 on the lazily reduced 28-bit field (Fq2 products as dual scans, zl_field28.h); BN254 G2 on 32-bit limbs
+// G2 on the lazily reduced 28-bit fields (Fq2 products as dual scans, zl_field28.h): 14 limbs per component for BLS12-381, 10 for BN254
 using BlsG2 = G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2L<Fp28<BLS12_381_Fq28, BLS12_381_Fq>>, 255, 6, 2>;
+#ifdef ZL_BN_FIELD32
 using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2<BN254_Fq>, 254, 4, 3>;
+#else
+using BnG2 = G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2L<Fp28<BN254_Fq28, BN254_Fq>>, 254, 4, 3>;  // round 4: like BLS12-381 G2, on 10 limbs
+#endif
 
 // ---- context ----------------------------------------------------------------------------------------------
 struct zl_bases {

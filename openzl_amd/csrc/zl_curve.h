@@ -105,12 +105,14 @@ template <class F> ZL_HD constexpr F x3_of(const F& rr, const F& ppp, const F& q
 // out-of-line Fq2 products (the INL = false flavour): one call per product, operands as scalar words (zl_field28.h)
 template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_mul_called(const Fp2LT<Fp28<A, P>, false>& a, const Fp2LT<Fp28<A, P>, false>& b) {
     Fp2LT<Fp28<A, P>, false> r;
-    unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
+    if constexpr (A::L == 14) unpair28(fq2_mul_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1), ZL_A14(b.c0), ZL_A14(b.c1)), r.c0, r.c1);
+    else unpair28(fq2_mul_call28x10<A, P>(ZL_A10(a.c0), ZL_A10(a.c1), ZL_A10(b.c0), ZL_A10(b.c1)), r.c0, r.c1);
     return r;
 }
 template <class A, class P> ZL_HD Fp2LT<Fp28<A, P>, false> fq2_sqr_called(const Fp2LT<Fp28<A, P>, false>& a) {
     Fp2LT<Fp28<A, P>, false> r;
-    unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
+    if constexpr (A::L == 14) unpair28(fq2_sqr_call28<A, P>(ZL_A14(a.c0), ZL_A14(a.c1)), r.c0, r.c1);
+    else unpair28(fq2_sqr_call28x10<A, P>(ZL_A10(a.c0), ZL_A10(a.c1)), r.c0, r.c1);
     return r;
 }
 // (a0 + a1 u)(b0 + b1 u): each component ONE dual product scan; operand components <= 16q, result components < 2q; -b1 is a scan-only

@@ -544,35 +544,63 @@ ZL_CONST28(const28_from_m32, from_m32)
 #define ZL_P14(x) uint32_t x##0, uint32_t x##1, uint32_t x##2, uint32_t x##3, uint32_t x##4, uint32_t x##5, uint32_t x##6, uint32_t x##7, uint32_t x##8, uint32_t x##9, uint32_t x##10, uint32_t x##11, uint32_t x##12, uint32_t x##13
 #define ZL_A14(v) v.l[0], v.l[1], v.l[2], v.l[3], v.l[4], v.l[5], v.l[6], v.l[7], v.l[8], v.l[9], v.l[10], v.l[11], v.l[12], v.l[13]
 #define ZL_S14(v, x) v.l[0] = x##0; v.l[1] = x##1; v.l[2] = x##2; v.l[3] = x##3; v.l[4] = x##4; v.l[5] = x##5; v.l[6] = x##6; v.l[7] = x##7; v.l[8] = x##8; v.l[9] = x##9; v.l[10] = x##10; v.l[11] = x##11; v.l[12] = x##12; v.l[13] = x##13
-struct Pair28 { uint32_t l[28]; };  // two 14-limb components, returned in registers
+// ... and the 10-limb instance (BN254 G2, round 4)
+#define ZL_P10(x) uint32_t x##0, uint32_t x##1, uint32_t x##2, uint32_t x##3, uint32_t x##4, uint32_t x##5, uint32_t x##6, uint32_t x##7, uint32_t x##8, uint32_t x##9
+#define ZL_A10(v) v.l[0], v.l[1], v.l[2], v.l[3], v.l[4], v.l[5], v.l[6], v.l[7], v.l[8], v.l[9]
+#define ZL_S10(v, x) v.l[0] = x##0; v.l[1] = x##1; v.l[2] = x##2; v.l[3] = x##3; v.l[4] = x##4; v.l[5] = x##5; v.l[6] = x##6; v.l[7] = x##7; v.l[8] = x##8; v.l[9] = x##9
+template <int L> struct PairL { uint32_t l[2 * L]; };  // two L-limb components, returned in registers
+using Pair28 = PairL<14>;
 namespace zl {
 template <class A, class B>
-ZL_HD Pair28 pair28(const Fp28<A, B>& c0, const Fp28<A, B>& c1) {
-    Pair28 r;
+ZL_HD PairL<A::L> pair28(const Fp28<A, B>& c0, const Fp28<A, B>& c1) {
+    PairL<A::L> r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) { r.l[i] = c0.l[i]; r.l[14 + i] = c1.l[i]; }
+    for (int i = 0; i < A::L; i++) { r.l[i] = c0.l[i]; r.l[A::L + i] = c1.l[i]; }
     return r;
 }
 template <class A, class B>
-ZL_HD void unpair28(const Pair28& p, Fp28<A, B>& c0, Fp28<A, B>& c1) {
+ZL_HD void unpair28(const PairL<A::L>& p, Fp28<A, B>& c0, Fp28<A, B>& c1) {
     c0 = Fp28<A, B>::zero();
     c1 = Fp28<A, B>::zero();
 #pragma unroll
-    for (int i = 0; i < 14; i++) { c0.l[i] = p.l[i]; c1.l[i] = p.l[14 + i]; }
+    for (int i = 0; i < A::L; i++) { c0.l[i] = p.l[i]; c1.l[i] = p.l[A::L + i]; }
 }
 template <class A, class B>
-ZL_NOINLINE_HD Pair28 fq2_mul_call28(ZL_P14(wa), ZL_P14(wb), ZL_P14(wc), ZL_P14(wd)) {  // (a + b u)(c + d u), components < 16q
-    static_assert(A::L == 14, "Fq2 helpers are written for 14 limbs");
-    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
-    ZL_S14(a0, wa); ZL_S14(a1, wb); ZL_S14(b0, wc); ZL_S14(b1, wd);
+ZL_HD PairL<A::L> fq2_mul_body28(const Fp28<A, B>& a0, const Fp28<A, B>& a1, const Fp28<A, B>& b0, const Fp28<A, B>& b1) {  // (a + b u)(c + d u), components < 16q
     const Fp28<A, B> nb1 = negk_scan<5>(b1);  // scan-only operand: 32q - b1, un-carried on the device (b1 <= 16q)
     return pair28(muladd(a0, b0, a1, nb1), muladd(a0, b1, a1, b0));
 }
 template <class A, class B>
-ZL_NOINLINE_HD Pair28 fq2_sqr_call28(ZL_P14(wa), ZL_P14(wb)) {  // (a + b u)^2 = (a + b)(a - b) + 2ab u, components < 16q
+ZL_HD PairL<A::L> fq2_sqr_body28(const Fp28<A, B>& a0, const Fp28<A, B>& a1) {  // (a + b u)^2 = (a + b)(a - b) + 2ab u, components < 16q
+    return pair28(mul(add(a0, a1), subk<4>(a0, a1)), mul(dbl(a0), a1));
+}
+template <class A, class B>
+ZL_NOINLINE_HD Pair28 fq2_mul_call28(ZL_P14(wa), ZL_P14(wb), ZL_P14(wc), ZL_P14(wd)) {
+    static_assert(A::L == 14, "the 14-limb entry");
+    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
+    ZL_S14(a0, wa); ZL_S14(a1, wb); ZL_S14(b0, wc); ZL_S14(b1, wd);
+    return fq2_mul_body28(a0, a1, b0, b1);
+}
+template <class A, class B>
+ZL_NOINLINE_HD Pair28 fq2_sqr_call28(ZL_P14(wa), ZL_P14(wb)) {
+    static_assert(A::L == 14, "the 14-limb entry");
     Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0;
     ZL_S14(a0, wa); ZL_S14(a1, wb);
-    return pair28(mul(add(a0, a1), subk<4>(a0, a1)), mul(dbl(a0), a1));
+    return fq2_sqr_body28(a0, a1);
+}
+template <class A, class B>
+ZL_NOINLINE_HD PairL<10> fq2_mul_call28x10(ZL_P10(wa), ZL_P10(wb), ZL_P10(wc), ZL_P10(wd)) {
+    static_assert(A::L == 10, "the 10-limb entry");
+    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0, b0 = a0, b1 = a0;
+    ZL_S10(a0, wa); ZL_S10(a1, wb); ZL_S10(b0, wc); ZL_S10(b1, wd);
+    return fq2_mul_body28(a0, a1, b0, b1);
+}
+template <class A, class B>
+ZL_NOINLINE_HD PairL<10> fq2_sqr_call28x10(ZL_P10(wa), ZL_P10(wb)) {
+    static_assert(A::L == 10, "the 10-limb entry");
+    Fp28<A, B> a0 = Fp28<A, B>::zero(), a1 = a0;
+    ZL_S10(a0, wa); ZL_S10(a1, wb);
+    return fq2_sqr_body28(a0, a1);
 }
 }  // namespace zl
 

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 torch.cuda.init()
-from openzl_amd import Backend, ZL_BLS12_381, Circuit, Groth16Keys
+from openzl_amd import Backend, ZL_BLS12_381, ZL_BN254, Circuit, Groth16Keys
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 be = Backend(0)
@@ -16,7 +16,7 @@ be.enable_timing(True)
 if os.environ.get("PRE_LEGS"):
     from pre_legs import run_pre_legs
     run_pre_legs(be)
-t0 = time.perf_counter(); circ = Circuit(ZL_BLS12_381, k); t1 = time.perf_counter()
+t0 = time.perf_counter(); circ = Circuit(ZL_BN254 if os.environ.get("CURVE") == "bn254" else ZL_BLS12_381, k); t1 = time.perf_counter()
 keys = Groth16Keys(be, circ, seed=1); t2 = time.perf_counter()
 print(f"synthesis {t1 - t0:.2f} s  setup {t2 - t1:.2f} s", flush=True)
 ts = []
