@@ -5,6 +5,17 @@ import sqlite3
 import sys
 
 
+import re
+
+
+def short(name: str) -> str:
+    """kernel name without its argument list; the G2 group configurations abbreviated (BlsG2 / BnG2) so that the columns stay aligned"""
+    n = name.split("(")[0].replace("void ", "")
+    n = re.sub(r"G2Cfg<BLS12_381_G2,.*?, 255, 6, 2> ?", "BlsG2", n)
+    n = re.sub(r"G2Cfg<BN254_G2,.*?, 254, 4, 3> ?", "BnG2", n)
+    return n.replace(" >", ">")
+
+
 def main(path):
     db = sqlite3.connect(path)
     cur = db.cursor()
@@ -25,7 +36,7 @@ def main(path):
           "(checked against hipcc -S: k_msm_accumulate<BlsG1> NumVgprs 166 -> rocprofv3 84; <BlsG2> 256 + 172 AGPRs -> 216); waves per SIMD = floor(512 / regs)")
     print(f"{'kernel':<70} {'calls':>6} {'total_us':>12} {'avg_us':>11} {'min_us':>11} {'max_us':>11} {'big_n':>5} {'big_avg_us':>11} {'%':>6} {'regs':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7} {'scratch':>7} {'grid':>10} {'wg':>5}")
     for r in rows:
-        name = r[0].split("(")[0].replace("void ", "")
+        name = short(r[0])
         print(f"{name:<70} {r[1]:>6} {r[2]/1e3:>12.1f} {r[3]/1e3:>11.1f} {r[4]/1e3:>11.1f} {r[5]/1e3:>11.1f} {big[r[0]][0]:>5} {big[r[0]][1]/1e3:>11.1f} {100*r[2]/total:>6.2f} {2*r[6]:>5} {r[7]:>5} {r[8]:>5} {r[9]:>7} {r[10]:>7} {r[11]:>10} {r[12]:>5}")
 
 
@@ -35,7 +46,7 @@ def launches(path, substr, limit=40):
     rows = db.cursor().execute("select name, start, duration, grid_x, workgroup_x from kernels where name like ? order by start limit ?", (f"%{substr}%", limit)).fetchall()
     print(f"# launches of *{substr}* in start order")
     for name, start, dur, grid, wg in rows:
-        print(f"{name.split('(')[0].replace('void ', ''):<60} {dur/1e3:>10.1f} us  grid {grid:>9} wg {wg}")
+        print(f"{short(name):<60} {dur/1e3:>10.1f} us  grid {grid:>9} wg {wg}")
 
 
 if __name__ == "__main__":

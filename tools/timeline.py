@@ -32,6 +32,7 @@ def main(path, gap_us=300.0, which=1, min_us=0.0):
     for name, s, e, grid, wg, q in b:
         nm = name.split("(")[0].replace("void ", "")
         nm = nm.replace("G2Cfg<BLS12_381_G2, BLS12_381_Fq, BLS12_381_Fr, Fp2LT<Fp28<BLS12_381_Fq28, BLS12_381_Fq>, false>, 255, 6, 2>", "BlsG2")
+        nm = nm.replace("G2Cfg<BN254_G2, BN254_Fq, BN254_Fr, Fp2LT<Fp28<BN254_Fq28, BN254_Fq>, false>, 254, 4, 3>", "BnG2")
         gap = (s - prev_end) / 1e3
         if (e - s) / 1e3 >= min_us:
             print(f"{nm[:52]:<52} {q:>3} {(s - t0) / 1e3:>10.1f} {(e - s) / 1e3:>9.1f} {gap:>8.1f} {grid:>9} {wg:>5}")
