@@ -52,6 +52,29 @@ struct Engine {
         for (int i = 0; i < 12; i++) r.c[i] = t[i];
         return r;
     }
+    // a^2: 78 products instead of 144 (cross terms once, doubled) -- two thirds of the final exponentiation's work are squarings
+    static Fq12 sqr(const Fq12& a) {
+        F t[23];
+        for (auto& x : t) x = F::zero();
+        for (int i = 0; i < 12; i++) {
+            if (a.c[i].is_zero()) continue;
+            t[2 * i] = zl::add(t[2 * i], zl::sqr(a.c[i]));
+            for (int j = i + 1; j < 12; j++) {
+                if (a.c[j].is_zero()) continue;
+                const F p = zl::mul(a.c[i], a.c[j]);
+                t[i + j] = zl::add(t[i + j], zl::add(p, p));
+            }
+        }
+        static const F m6 = small(PP::M6), m0 = small(PP::M0_NEG);
+        for (int k = 22; k >= 12; k--) {
+            if (t[k].is_zero()) continue;
+            t[k - 6] = zl::add(t[k - 6], zl::mul(t[k], m6));
+            t[k - 12] = zl::sub(t[k - 12], zl::mul(t[k], m0));
+        }
+        Fq12 r;
+        for (int i = 0; i < 12; i++) r.c[i] = t[i];
+        return r;
+    }
     static bool eq(const Fq12& a, const Fq12& b) {
         for (int i = 0; i < 12; i++) if (a.c[i] != b.c[i]) return false;
         return true;
@@ -144,7 +167,7 @@ struct Engine {
         Fq12 f = one();
         G2Aff R = Q;
         for (int i = PP::LOOP_BITS - 2; i >= 0; i--) {
-            f = mul(mul(f, f), line_and_add(R, R, xP, yP));
+            f = mul(sqr(f), line_and_add(R, R, xP, yP));
             if (PP::loop_bit(i)) f = mul(f, line_and_add(R, Q, xP, yP));
         }
         if (PP::BN_TAIL) {
@@ -156,14 +179,20 @@ struct Engine {
         }
         return f;
     }
+    // f^((q^12 - 1) / r) as one power, 4-bit fixed windows: ~4300 squarings + ~1000 products (binary: + ~2150 products)
     static Fq12 final_exp(const Fq12& f) {
         const uint32_t* e = PP::final_exp();
+        Fq12 tab[16];
+        tab[0] = one();
+        tab[1] = f;
+        for (int k = 2; k < 16; k++) tab[k] = (k & 1) ? mul(tab[k - 1], f) : sqr(tab[k >> 1]);
         Fq12 acc = one();
         bool started = false;
-        for (int i = PP::FINAL_EXP_WORDS * 32 - 1; i >= 0; i--) {
-            if (started) acc = mul(acc, acc);
-            if ((e[i >> 5] >> (i & 31)) & 1) {
-                acc = started ? mul(acc, f) : f;
+        for (int i = PP::FINAL_EXP_WORDS * 8 - 1; i >= 0; i--) {
+            const uint32_t nib = (e[i >> 3] >> (4 * (i & 7))) & 15u;
+            if (started) acc = sqr(sqr(sqr(sqr(acc))));
+            if (nib) {
+                acc = started ? mul(acc, tab[nib]) : tab[nib];
                 started = true;
             }
         }
