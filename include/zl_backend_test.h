@@ -57,6 +57,10 @@ int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t
  * warm-up; profiles/r04_fbench_f64.log). */
 int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_products_per_s);
 
+/* prod_i e(P_i, Q_i), n <= 64 pairs (P_i: x || y canonical u64 words, Q_i: x.c0 || x.c1 || y.c0 || y.c1; all-zero = infinity), after ONE final exponentiation:
+ * the lock-step Miller loops of Groth16::verify (csrc/zl_pairing.h miller_multi), 12 canonical Fq coefficients as zl_pairing. */
+int zl_test_pairing_product(zl_curve_t curve, size_t n, const uint64_t* ps_xy, const uint64_t* qs_xy, uint64_t* out12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,7 @@ def load_library(path: Optional[str] = None):
     L.zl_test_poseidon_permute_dev.argtypes = [vp, C.c_int, u64p]
     L.zl_test_fp28_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_fp28_bn_op.argtypes = [vp, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_pairing_product.argtypes = [C.c_int, C.c_size_t, u64p, u64p, u64p]
     L.zl_test_point_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_circuit_tweak.argtypes = [vp]
     L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
@@ -399,7 +400,7 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
 
 
 def _p32(a: np.ndarray):
@@ -425,6 +426,18 @@ def hook_fp28_op(be: Optional["Backend"], op: int, operands: np.ndarray, bn254: 
     rc = fn(be._ctx if be is not None else None, op, _p32(a), n, _p32(out))
     if rc:
         raise BackendError(rc, "zl_test_fp28_bn_op" if bn254 else "zl_test_fp28_op")
+    return out
+
+
+def hook_pairing_product(curve: int, ps: np.ndarray, qs: np.ndarray) -> np.ndarray:
+    """prod_i e(P_i, Q_i) through the lock-step Miller loops (host only): ps (n, 2 FQ64) / qs (n, 4 FQ64) canonical u64 words -> 12 x FQ64 words"""
+    p = np.ascontiguousarray(ps, dtype=np.uint64)
+    q = np.ascontiguousarray(qs, dtype=np.uint64)
+    n = p.shape[0]
+    out = np.zeros((12, p.shape[1] // 2), dtype=np.uint64)
+    rc = load_library().zl_test_pairing_product(curve, n, _p64(p), _p64(q), _p64(out))
+    if rc:
+        raise BackendError(rc, "zl_test_pairing_product")
     return out
 
 

@@ -29,6 +29,34 @@ def test_host_pairing_matches_definition_and_is_bilinear(curve):
     assert ol.limbs_to_ints(pairing(curve.cid, P[0], np.zeros_like(Q[0]))) == one
 
 
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_pairing_product_in_lock_step_equals_product_of_pairings(curve):
+    """Groth16::verify takes its four pairings through ONE lock-step Miller loop (one shared inversion per step, csrc/zl_pairing.h): the product of n pairings
+    equals the product of the single pairings (Python Fq12 arithmetic), a pair at infinity drops out, and e(aP, Q) e(P, -aQ) = 1."""
+    from openzl_amd.backend import hook_pairing_product
+
+    G1 = po.g1_generator(curve)
+    ks, ss = [3, 0xABCDEF12345, 7, 0x1234567], [5, 11, 0xFEDCBA987, 1]
+    P = ol.points_to_limbs(curve, [po.g1_mul(curve, k, G1) for k in ks])
+    Q = gu.g2_mul_gen(curve, ss)
+    ctx = po.Fq12Ctx(curve)
+    singles = [ol.limbs_to_ints(pairing(curve.cid, P[i], Q[i])) for i in range(4)]
+    exp = singles[0]
+    for v in singles[1:]:
+        exp = ctx.mul(exp, v)
+    assert ol.limbs_to_ints(hook_pairing_product(curve.cid, P, Q)) == exp
+    # a pair with the point at infinity contributes 1
+    P2 = P.copy()
+    P2[2] = 0
+    exp2 = ctx.mul(ctx.mul(singles[0], singles[1]), singles[3])
+    assert ol.limbs_to_ints(hook_pairing_product(curve.cid, P2, Q)) == exp2
+    # e(a P, Q) e(P, -a Q) = 1
+    a = 0x5EED5EED5EED
+    Pa = ol.points_to_limbs(curve, [po.g1_mul(curve, a, G1), G1])
+    Qa = gu.g2_mul_gen(curve, [1, curve.fr.p - a])
+    assert ol.limbs_to_ints(hook_pairing_product(curve.cid, Pa, Qa)) == [1] + [0] * 11
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 def test_proof_system_compile_prove_verify(backend, curve):
