@@ -276,6 +276,39 @@ def test_msm_known_discrete_log_2_24(backend, mode):
         assert tm.window_bits == 22
 
 
+@pytest.mark.parametrize("mode", ["plain", "table_c20"])
+def test_msm_known_discrete_log_bn254_2_22(backend, mode):
+    """BN254 G1 at 2^22 points (round 4: its base field moved to 10 x 28-bit lazily reduced limbs): the wide three-level sort, 64-entry chunks, the
+    pipelined batch, plain and with a window table -- exact against (sum s_i k_i mod r) G from the CPU oracle's scalar multiplication."""
+    import torch
+
+    curve = po.BN254
+    n, r = 1 << 22, curve.fr.p
+    rng = np.random.Generator(np.random.PCG64(2254))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    S = ol.random_scalars(curve, n, 2255)
+    S[5] = 0
+    S[6] = ol.ints_to_limbs([1], 4)[0]
+    S[7] = ol.ints_to_limbs([r - 1], 4)[0]
+    S2 = np.ascontiguousarray(S[::-1])
+    h = backend.bases_generate(curve.cid, k)
+    if mode == "table_c20":
+        backend.bases_precompute(h, 20)
+    d1, d2 = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(S2.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    got, inf = backend.msm_dev(h, d1.data_ptr(), n)
+    parts = backend.msm_batch_partial_dev(h, [d1.data_ptr(), d2.data_ptr(), d1.data_ptr()], n)
+    backend.bases_free(h)
+    exp1 = _oracle_point(curve, _dot_mod_r_u64k(S, k64, r))
+    exp2 = _oracle_point(curve, _dot_mod_r_u64k(S2, k64, r))
+    assert not inf and (got == exp1).all()
+    for j, e in enumerate((exp1, exp2, exp1)):
+        xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1])
+        assert not pinf and (xy == e).all(), j
+
+
 @pytest.mark.parametrize("case", ["uniform", "all_equal", "two_values_and_negations"])
 def test_msm_wide_path_unaligned_adversarial(backend, case):
     """The three-level sort over (window, bucket) ids on a size that is a multiple of nothing (unaligned slices, partial tiles) and on

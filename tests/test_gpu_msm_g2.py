@@ -55,6 +55,32 @@ def test_g2_generate_and_known_discrete_log(backend, curve):
 
 
 @pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("table", [False, True], ids=["plain", "table"])
+def test_g2_known_discrete_log_2_18(backend, curve, table):
+    """G2 at 2^18 points (long accumulation chains, the c = 16 table mode of a proving key's b_g2_query): exact against (sum s_i k_i mod r) G2.  BN254 G2 runs on the
+    lazily reduced 10-limb Fq2 since round 4."""
+    n, r = 1 << 18, curve.fr.p
+    rng = np.random.Generator(np.random.PCG64(1822))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    S = ol.random_scalars(curve, n, 1823)
+    S[3] = 0
+    S[4] = ol.ints_to_limbs([1], 4)[0]
+    S[5] = ol.ints_to_limbs([r - 1], 4)[0]
+    h = backend.bases_generate(curve.cid, k, group=ZL_G2)
+    if table:
+        backend.bases_precompute(h, 16)
+    got, inf = backend.msm(h, S)
+    backend.bases_free(h)
+    s32 = np.ascontiguousarray(S).view(np.uint32).reshape(-1, 8).astype(object)
+    dot = 0
+    for a in range(8):  # exact dot product in Python integers, one 32-bit column at a time
+        dot += int((s32[:, a] * k64.astype(object)).sum()) << (32 * a)
+    assert inf == 0 and (got == gu.g2_mul_gen(curve, [dot % r])[0]).all()
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
 def test_g2_precomputed_table_and_skew(backend, curve):
     """zl_bases_precompute on a G2 handle (merged bucket set) + the scalar-1 bypass and a giant bucket, against the oracle."""
     n = 2500
