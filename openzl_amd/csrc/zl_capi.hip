@@ -261,7 +261,7 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
         // H2D copies; priority means nothing to them.
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) ? prio_hi : 0));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, (zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0));
     }
     std::vector<hipEvent_t> ev(K, nullptr);
     for (size_t j = 0; j < K; j++) {

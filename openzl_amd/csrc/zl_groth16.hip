@@ -202,7 +202,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         // highest, h gates the last MSM
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : (zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
         a->stream = a->own_stream;
         *ax = a;  // owned by ctx from here on (zl_ctx_destroy)

@@ -142,8 +142,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         // highest priority: the short sort / tail kernels must get wave slots as the long accumulation kernel frees them
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, prio_hi));
-        for (auto& t : ctx->stream_tail) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prio_hi));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
+        for (auto& t : ctx->stream_tail) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
     }
     std::vector<MsmJob<G>> jobs(count);
     size_t t5 = 0, t6 = 0;
