@@ -30,6 +30,8 @@
 #include <stdio.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "zl_ctx.h"
@@ -328,7 +330,9 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // jobs, which the device finishes faster than the host, get their Horners side by side; `on_done` is delivered in job order.  (The helpers
     // make no HIP calls: a fresh thread's first HIP call costs ~0.1 ms of per-thread runtime setup, per proof.)
     std::atomic<int> frc{ZL_OK};
-    std::atomic<size_t> delivered{0};
+    size_t delivered = 0;  // in-order delivery of the results: a finisher sleeps on the condition variable until its predecessors have delivered (no spinning:
+    std::mutex deliver_mu;  // a batch of many jobs has many finishers alive at once, next to the host pool's workers)
+    std::condition_variable deliver_cv;
     std::vector<std::thread> finishers;
     // every job issued (the lanes issue side by side: about the time of one job), then ev_end behind the last tail of every stream that ran tails
     for (size_t i = 0; i < count; i++) {
@@ -357,9 +361,16 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
                 }
                 if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu Horner done at %.1f us\n", i,
                                     (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
-                while (delivered.load(std::memory_order_acquire) != i) std::this_thread::yield();
+                {
+                    std::unique_lock<std::mutex> lk(deliver_mu);
+                    deliver_cv.wait(lk, [&] { return delivered == i; });
+                }
                 if (ok && on_done && frc.load() == ZL_OK) (*on_done)(i);
-                delivered.store(i + 1, std::memory_order_release);
+                {
+                    std::lock_guard<std::mutex> lk(deliver_mu);
+                    delivered = i + 1;
+                }
+                deliver_cv.notify_all();
             });
         }
     }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 torch.cuda.init()
-from openzl_amd import Backend, ZL_BLS12_381, Circuit, Groth16Keys
+from openzl_amd import Backend, ZL_BLS12_381, ZL_BN254, Circuit, Groth16Keys
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -19,7 +19,7 @@ be.enable_timing(True)
 if os.environ.get("PRE_LEGS"):
     from pre_legs import run_pre_legs
     run_pre_legs(be)
-circ = Circuit(ZL_BLS12_381, k)
+circ = Circuit(ZL_BN254 if os.environ.get("CURVE") == "bn254" else ZL_BLS12_381, k)
 keys = Groth16Keys(be, circ, seed=1)
 ts = []
 for _ in range(iters):
