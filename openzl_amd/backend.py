@@ -151,6 +151,10 @@ def load_library(path: Optional[str] = None):
     L.zl_test_circuit_tweak.argtypes = [vp]
     L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.zl_test_fr28_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_poseidon_permute_dev28r.argtypes = [vp, C.c_int, u64p]
+    L.zl_test_fq_mul_clock.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.zl_test_acc_clock.argtypes = [vp, C.c_int]
+    L.zl_test_acc_clock_read.argtypes = [vp, C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -400,7 +404,8 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op"]
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op",
+                    "zl_test_poseidon_permute_dev28r", "zl_test_fq_mul_clock", "zl_test_acc_clock", "zl_test_acc_clock_read"]
 
 
 def _p32(a: np.ndarray):
@@ -412,6 +417,13 @@ def hook_poseidon_permute_dev(be: "Backend", curve: int, state: np.ndarray) -> n
     """width-3 Poseidon permutation computed on the device with the device Fr arithmetic (canonical (3,4) uint64 in / out)"""
     st = np.ascontiguousarray(state.copy(), dtype=np.uint64)
     be._check(be.L.zl_test_poseidon_permute_dev(be._ctx, curve, _p64(st)), "zl_test_poseidon_permute_dev")
+    return st
+
+
+def hook_poseidon_permute_dev28r(be: "Backend", curve: int, state: np.ndarray) -> np.ndarray:
+    """the same permutation through the lazily reduced 10 x 28-bit Fr multiplier of the NTT passes (zl_field28r.h)"""
+    st = np.ascontiguousarray(state.copy(), dtype=np.uint64)
+    be._check(be.L.zl_test_poseidon_permute_dev28r(be._ctx, curve, _p64(st)), "zl_test_poseidon_permute_dev28r")
     return st
 
 
@@ -470,6 +482,30 @@ def hook_fq_mul_rate(be: "Backend", waves_per_simd: int = 3, iters: int = 3000) 
     v = C.c_double(0.0)
     be._check(be.L.zl_test_fq_mul_rate(be._ctx, waves_per_simd, iters, C.byref(v)), "zl_test_fq_mul_rate")
     return v.value
+
+
+_CLOCK_KEYS = ("effective_clock_ghz", "span_ms_by_100mhz_counter", "waves", "mean_wave_life_ms", "min_wave_ghz", "max_wave_ghz")
+
+
+def hook_fq_mul_clock(be: "Backend", waves_per_simd: int = 3, iters: int = 50000) -> dict:
+    """effective shader clock of the multiplier chain (s_memtime / s_memrealtime per wave) + its rate in the same launch (measurement hook)"""
+    v = (C.c_double * 8)()
+    be._check(be.L.zl_test_fq_mul_clock(be._ctx, waves_per_simd, iters, v), "zl_test_fq_mul_clock")
+    d = {k: float(v[i]) for i, k in enumerate(_CLOCK_KEYS)}
+    d["g_products_per_s"] = float(v[6])
+    d["ms_by_hip_events"] = float(v[7])
+    return d
+
+
+def hook_acc_clock(be: "Backend", on: bool) -> None:
+    """arm / disarm the clock-reading build of the large G1 accumulation kernel on this ctx (measurement hook)"""
+    be._check(be.L.zl_test_acc_clock(be._ctx, 1 if on else 0), "zl_test_acc_clock")
+
+
+def hook_acc_clock_read(be: "Backend") -> dict:
+    v = (C.c_double * 6)()
+    be._check(be.L.zl_test_acc_clock_read(be._ctx, v), "zl_test_acc_clock_read")
+    return {k: float(v[i]) for i, k in enumerate(_CLOCK_KEYS)}
 
 
 # ---- host mirror (openzl::R1CS / poseidon / Groth16<E>, csrc/zl_host.h) through its C hooks ---------------------------

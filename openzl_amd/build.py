@@ -17,6 +17,21 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 FLAGS += [f for f in os.environ.get("ZL_EXTRA_FLAGS", "").split() if f]
 GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
+# Developer A/B builds: ZL_BUILD_TAG=x writes objects *.x.o and libzl_backend.x.so beside the product build (load it with ZL_BACKEND_LIB, tools/ab/*.sh)
+TAG = os.environ.get("ZL_BUILD_TAG", "")
+if TAG:
+    LIB = os.path.join(HERE, f"libzl_backend.{TAG}.so")
+# Round 5: hipcc pads EVERY inline-asm statement whose result the next instruction reads with `s_nop 0` (GCNHazardRecognizer treats an inline-asm def as a
+# possible dst_sel / opsel partial write on gfx940+).  The product scans (zl_mul28*_gfx950.h) are chains of such statements holding only v_mad_u64_u32:
+# 515 of the 5 150 instructions of one mixed addition are those pads, and they are not free (tools/ubench2.hip: a pad costs ~0.7 SIMD cycles at three waves per
+# SIMD, 3.5 for a lone wave).  The units below are therefore compiled to device assembly, the pads that sit between one of OUR asm statements and an
+# instruction that cannot carry that hazard are removed, and the result is assembled, linked, bundled and embedded exactly as hipcc does itself
+# (hipcc -### shows the same five steps).  ZL_KEEP_ASM_NOPS=1 keeps hipcc's own output (A/B).
+STRIP_NOPS = os.environ.get("ZL_KEEP_ASM_NOPS", "") == ""
+STRIP_VERSION = "strip-nops-v1"
+_LLVM = "/opt/rocm/lib/llvm/bin"
+STRIP_UNITS = ("zl_msm_acc_",)  # unit-name prefixes compiled that way
+_SAFE_NEXT = re.compile(r"^(;;#ASMSTART|v_mul_lo_u32|v_lshrrev_b64|v_and_b32_e32|v_and_b32_e64)\b")
 _INC = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
 
 
@@ -51,6 +66,43 @@ def _digest(paths, extra="") -> str:
     return h.hexdigest()
 
 
+def strip_asm_nops(text: str) -> tuple[str, int]:
+    """Remove `s_nop 0` lines that directly follow `;;#ASMEND` and directly precede another of our asm statements or one of the plain VALU instructions
+    the product scans place there (m_k = lo * INV, the 28-bit mask, the column shift).  Every asm statement of this code base holds v_mad_u64_u32 only
+    (gen_mul*.py; DPP moves of zl_quad.h are builtins, not asm), which writes full 32-bit registers: the forwarding hazard hipcc guards against cannot occur."""
+    lines = text.split("\n")
+    out, n = [], 0
+    for i, l in enumerate(lines):
+        if l.strip() == "s_nop 0" and i > 0 and lines[i - 1].strip() == ";;#ASMEND" and i + 1 < len(lines) and _SAFE_NEXT.match(lines[i + 1].strip()):
+            n += 1
+            continue
+        out.append(l)
+    return "\n".join(out), n
+
+
+def _compile_stripped(name: str, src: str, defs: list[str], obj: str, verbose: bool) -> None:
+    """hipcc's own pipeline for one HIP unit with the device assembly edited in between."""
+    work = os.path.join(CSRC, ".asm")
+    os.makedirs(work, exist_ok=True)
+    base = os.path.join(work, name + (f".{TAG}" if TAG else ""))
+    cuid = "-cuid=zl" + hashlib.sha256(name.encode()).hexdigest()[:14]
+    common = [_hipcc()] + FLAGS + defs + [cuid]
+    run = lambda cmd: (print("[build]", " ".join(cmd), flush=True) if verbose else None, subprocess.check_call(cmd, stderr=subprocess.DEVNULL if "-S" in cmd else None))
+    run(common + ["--cuda-device-only", "-S", src, "-o", base + ".raw.s"])
+    text, n = strip_asm_nops(open(base + ".raw.s").read())
+    open(base + ".s", "w").write(text)
+    os.remove(base + ".raw.s")
+    if verbose:
+        print(f"[build] {name}: removed {n} inline-asm pads", flush=True)
+    run([os.path.join(_LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + ARCH, "-c", base + ".s", "-o", base + ".dev.o"])
+    run([os.path.join(_LLVM, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", base + ".out", base + ".dev.o"])
+    run([os.path.join(_LLVM, "clang-offload-bundler"), "-type=o", "-bundle-align=4096", f"-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--{ARCH}",
+         "-input=/dev/null", "-input=" + base + ".out", "-output=" + base + ".hipfb"])
+    run(common + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", base + ".hipfb", "-o", obj])
+    for ext in (".dev.o", ".out", ".hipfb"):
+        os.remove(base + ext)
+
+
 def _units():
     units = [("zl_capi", "zl_capi.hip", []), ("zl_ntt", "zl_ntt.hip", ["-DZL_INLINE_MUL"]), ("zl_groth16", "zl_groth16.hip", []), ("zl_host", "zl_host.hip", []), ("zl_testhooks", "zl_testhooks.hip", []), ("zl_multi", "zl_multi.hip", []),
              ("zl_msm_sort", "zl_msm_sort.hip", [])]  # the curve-independent sort kernels of the MSM: once, not per group
@@ -76,20 +128,24 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
         subprocess.check_call([sys.executable, gen])
     todo, objs = [], []
     for name, src, defs in _units():
-        obj = os.path.join(CSRC, name + ".o")
+        strip = STRIP_NOPS and name.startswith(STRIP_UNITS)
+        obj = os.path.join(CSRC, name + (f".{TAG}" if TAG else "") + ".o")
         stamp = obj + ".sha"
-        d = _digest(_deps(os.path.join(CSRC, src)), " ".join(FLAGS + defs))
+        d = _digest(_deps(os.path.join(CSRC, src)), " ".join(FLAGS + defs) + (STRIP_VERSION if strip else ""))
         objs.append(obj)
         if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == d:
             continue
-        todo.append((name, src, defs, obj, stamp, d))
+        todo.append((name, src, defs, obj, stamp, d, strip))
 
     def compile_one(t):
-        name, src, defs, obj, stamp, d = t
-        cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print("[build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        name, src, defs, obj, stamp, d, strip = t
+        if strip:
+            _compile_stripped(name, os.path.join(CSRC, src), defs, obj, verbose)
+        else:
+            cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
         with open(stamp, "w") as f:
             f.write(d)
 

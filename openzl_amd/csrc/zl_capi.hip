@@ -80,6 +80,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     for (auto& kv : ctx->r1cs) if (kv.second.d_base) (void)hipFree(kv.second.d_base);
     for (auto& s : ctx->scratch) if (s.p) (void)hipFree(s.p);
     for (auto& t : ctx->fb_table) if (t) (void)hipFree(t);
+    if (ctx->acc_clk) (void)hipFree(ctx->acc_clk);
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
     for (auto& t : ctx->stream_tail) if (t) (void)hipStreamDestroy(t);
     for (auto& t : ctx->stream_lane) if (t) (void)hipStreamDestroy(t);

@@ -79,6 +79,29 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
                            reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
                            reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
 }
+// MEASUREMENT ONLY (zl_test_acc_clock, include/zl_backend_test.h): the same kernel with four scalar clock reads per WAVE -- s_memtime (shader cycles) and
+// s_memrealtime (the constant 100 MHz counter) at its start and at its end -- so that the effective shader clock of the accumulation (the chip clocks
+// dense VALU bodies to its power budget, MI355X_MICROARCH.md "DVFS give-back") is read from the kernel itself: sum of cycle deltas / sum of tick deltas.
+// One record of four u64 per workgroup (= wave).  G1 groups only; never launched by the product path unless the hook armed ctx->acc_clk.
+template <class G>
+__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate_clk(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, unsigned long long* __restrict__ clk) {
+    if constexpr (G::COORDS == 1) {
+        using F = typename HotField<typename G::F>::type;
+        const unsigned long long c0 = __builtin_readcyclecounter(), w0 = __builtin_amdgcn_s_memrealtime();
+        zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
+                               reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
+                               reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* o = clk + (size_t)4 * blockIdx.x;
+            o[0] = c0; o[1] = c1; o[2] = w0; o[3] = w1;
+        }
+    }
+}
 // The same chunks with FOUR lanes per chunk (zl_quad.h): for lists that do not fill the machine (small MSMs), where the time of the launch is
 // the latency of one lane's chain of mixed additions -- 4 product slots per addition instead of 10.5.
 template <class G>
@@ -118,4 +141,5 @@ __global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accu
 #define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
     X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*); \
     X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);

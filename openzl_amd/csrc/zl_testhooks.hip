@@ -1,6 +1,7 @@
 // zl_testhooks.hip -- the TEST-ONLY hooks declared in include/zl_backend_test.h: device Poseidon known-answer run, raw-limb access to the
 // lazily reduced 28-bit field and to the point formulas (host and device).  Nothing in the product path calls into this file.
 #include <string.h>
+#include <type_traits>
 #include <vector>
 #include "../../include/zl_backend_test.h"
 #include "zl_ctx.h"
@@ -56,7 +57,79 @@ __global__ void __launch_bounds__(64) k_test_poseidon(const uint32_t* __restrict
     if (bad) atomicOr(disagree, 1u);
 }
 
-template <class FrP>
+// The same permutation on the lazily reduced 10 x 28-bit Fr of the NTT passes (zl_field28r.h, round 4): since that round the hot NTT multiplies with
+// mul28r_asm, not with the 8 x 32 carry chain above, so the one reference-held vector is run through THIS multiplier too.
+// Everything stays in the multiplier's own Montgomery form x R' (R' = 2^280): to_mont = mul(x, R'^2), products mul(a R', b R') = a b R', lazy additions
+// (bounds: an MDS row sum of three products < 6r, plus a round key < 8r; 8 * 8 << 2^25), Fermat inversion for the Cauchy entries with the same
+// multiplier, from_mont = mul(x R', 1), canon, pack.  No value is ever compared with r before the final canon.
+template <class FrP, class P28>
+__global__ void __launch_bounds__(64) k_test_poseidon28r(const uint32_t* __restrict__ keys_canon, int full_rounds, int partial_rounds, uint32_t* __restrict__ state,
+                                                          uint32_t* __restrict__ disagree) {
+    using E = Fr28<P28>;
+    uint32_t w[8];
+    for (int k = 0; k < 8; k++) w[k] = P28::rp2(k);
+    const E rp2 = zl::unpack28r<P28>(w);
+    for (int k = 0; k < 8; k++) w[k] = k == 0 ? 1u : 0u;
+    const E plain_one = zl::unpack28r<P28>(w);
+    const E one_m = zl::mul(plain_one, rp2);  // R' mod r (< 2r)
+    // exponent r - 2 from the 32-bit-word modulus
+    uint32_t e[8];
+    {
+        uint32_t borrow = 2;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t m = FrP::mod(i);
+            e[i] = m - borrow;
+            borrow = m < borrow ? 1u : 0u;
+        }
+    }
+    E st[3], mds[3][3];
+    for (int i = 0; i < 3; i++) {
+        for (int k = 0; k < 8; k++) w[k] = state[i * 8 + k];
+        st[i] = zl::mul(zl::unpack28r<P28>(w), rp2);
+        for (int j = 0; j < 3; j++) {
+            for (int k = 0; k < 8; k++) w[k] = k == 0 ? (uint32_t)(i + 3 + j) : 0u;
+            const E a = zl::mul(zl::unpack28r<P28>(w), rp2);
+            E acc = one_m;
+            for (int b = 255; b >= 0; b--) {
+                acc = zl::mul(acc, acc);
+                if ((e[b >> 5] >> (b & 31)) & 1) acc = zl::mul(acc, a);
+            }
+            mds[i][j] = acc;
+        }
+    }
+    const int half = full_rounds / 2;
+    for (int rnd = 0; rnd < full_rounds + partial_rounds; rnd++) {
+        for (int i = 0; i < 3; i++) {
+            for (int k = 0; k < 8; k++) w[k] = keys_canon[(3 * rnd + i) * 8 + k];
+            st[i] = zl::add(st[i], zl::mul(zl::unpack28r<P28>(w), rp2));  // < 6r + 2r
+        }
+        const int lanes = (rnd < half || rnd >= half + partial_rounds) ? 3 : 1;
+        for (int i = 0; i < lanes; i++) {
+            const E x2 = zl::mul(st[i], st[i]), x4 = zl::mul(x2, x2);
+            st[i] = zl::mul(x4, st[i]);
+        }
+        E nx[3];
+        for (int i = 0; i < 3; i++) {
+            E acc = zl::mul(mds[i][0], st[0]);
+            acc = zl::add(acc, zl::mul(mds[i][1], st[1]));
+            nx[i] = zl::add(acc, zl::mul(mds[i][2], st[2]));  // < 6r
+        }
+        for (int i = 0; i < 3; i++) st[i] = nx[i];
+    }
+    uint32_t bad = 0;
+    for (int i = 0; i < 3; i++) {
+        const E c = zl::canon(zl::mul(st[i], plain_one));
+        zl::pack28r<P28>(w, c);
+        for (int k = 0; k < 8; k++) {
+            const uint32_t v0 = __shfl(w[k], 0);
+            bad |= v0 ^ w[k];
+        }
+        if (threadIdx.x == 0) for (int k = 0; k < 8; k++) state[i * 8 + k] = w[k];
+    }
+    if (bad) atomicOr(disagree, 1u);
+}
+
+template <class FrP, class P28 = void>
 static int poseidon_dev_t(zl_ctx* ctx, uint64_t* state) {
     using C = poseidon::Constants<FrP>;
     static const C cst;  // host mirror: Grain LFSR stream -> canonical integers are recovered below
@@ -76,7 +149,8 @@ static int poseidon_dev_t(zl_ctx* ctx, uint64_t* state) {
     ZL_HIP(ctx, hipMemcpyAsync(d_keys, keys.data(), kb, hipMemcpyHostToDevice, st));
     ZL_HIP(ctx, hipMemcpyAsync(d_state, state, sb, hipMemcpyHostToDevice, st));
     ZL_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, st));
-    hipLaunchKernelGGL((k_test_poseidon<FrP>), dim3(1), dim3(64), 0, st, d_keys, C::FULL_ROUNDS, C::PARTIAL_ROUNDS, d_state, d_bad);
+    if constexpr (std::is_void<P28>::value) hipLaunchKernelGGL((k_test_poseidon<FrP>), dim3(1), dim3(64), 0, st, d_keys, C::FULL_ROUNDS, C::PARTIAL_ROUNDS, d_state, d_bad);
+    else hipLaunchKernelGGL((k_test_poseidon28r<FrP, P28>), dim3(1), dim3(64), 0, st, d_keys, C::FULL_ROUNDS, C::PARTIAL_ROUNDS, d_state, d_bad);
     ZL_HIP(ctx, hipGetLastError());
     uint32_t bad = 0;
     ZL_HIP(ctx, hipMemcpyAsync(state, d_state, sb, hipMemcpyDeviceToHost, st));
@@ -247,7 +321,7 @@ static int run_dev(zl_ctx* ctx, const uint32_t* in, size_t in_words, uint32_t* o
 // of the accumulation kernel (zl_mul28_gfx950.h) on its OWN pseudo-random operands.  Constant-pattern operands (hipMemset, as tools/fbench28_asm.hip
 // uses) run 11 % faster on MI355X -- the chip clocks to its power budget and identical lanes toggle less -- and a launch of a few milliseconds after an
 // idle gap runs 10-15 % slower than the steady state (clock ramp): callers warm up and time launches of >= 0.1 s (profiles/r04_fbench_f64.log).
-__global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sink, int iters) {
+__global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sink, int iters, unsigned long long* __restrict__ clk = nullptr) {
     using A = BLS12_381_Fq28;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t s = 0x9E3779B97F4A7C15ull * (t + 1);
@@ -259,12 +333,19 @@ __global__ void __launch_bounds__(64) k_test_mul_rate(uint32_t* __restrict__ sin
     }
     x.l[13] %= A::mod(13);
     y.l[13] %= A::mod(13);
+    // clk != nullptr: shader-cycle (s_memtime) and 100-MHz (s_memrealtime) counters around the chain, one record per wave (zl_test_fq_mul_clock)
+    unsigned long long c0 = 0, w0 = 0;
+    if (clk) { c0 = __builtin_readcyclecounter(); w0 = __builtin_amdgcn_s_memrealtime(); }
     for (int k = 0; k < iters; k++) {
 #if defined(__HIP_DEVICE_COMPILE__)
         F28 r = x;
         mul28_asm<A>(r.l, x.l, y.l);
         x = r;
 #endif
+    }
+    if (clk) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) { clk[4 * blockIdx.x] = c0; clk[4 * blockIdx.x + 1] = c1; clk[4 * blockIdx.x + 2] = w0; clk[4 * blockIdx.x + 3] = w1; }
     }
     uint32_t acc = 0;
     for (int k = 0; k < 14; k++) acc ^= x.l[k];
@@ -293,6 +374,14 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     if (curve == ZL_BLS12_381) return poseidon_dev_t<BLS12_381_Fr>(ctx, state);
     if (curve == ZL_BN254) return poseidon_dev_t<BN254_Fr>(ctx, state);
+    return ZL_EINVAL;
+}
+
+int zl_test_poseidon_permute_dev28r(zl_ctx* ctx, zl_curve_t curve, uint64_t* state) {
+    if (!ctx || !state) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    if (curve == ZL_BLS12_381) return poseidon_dev_t<BLS12_381_Fr, BLS12_381_Fr28>(ctx, state);
+    if (curve == ZL_BN254) return poseidon_dev_t<BN254_Fr, BN254_Fr28>(ctx, state);
     return ZL_EINVAL;
 }
 
@@ -355,9 +444,9 @@ int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_pr
     hipEvent_t e0, e1;
     ZL_HIP(ctx, hipEventCreate(&e0));
     ZL_HIP(ctx, hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, 8);
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, 8, (unsigned long long*)nullptr);
     ZL_HIP(ctx, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, iters);
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, iters, (unsigned long long*)nullptr);
     ZL_HIP(ctx, hipEventRecord(e1, st));
     ZL_HIP(ctx, hipStreamSynchronize(st));
     ZL_HIP(ctx, hipGetLastError());
@@ -366,6 +455,93 @@ int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_pr
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *g_products_per_s = (double)blocks * 64.0 * (double)iters / ((double)ms * 1e-3) / 1e9;
+    return ZL_OK;
+}
+
+// Reduces `waves` records {cycles at start, cycles at end, 100-MHz ticks at start, ticks at end} (one per wave) to
+// out[0] effective shader clock in GHz = sum of cycle deltas / sum of tick deltas * 0.1, out[1] span of the launch in ms by the tick counter (last end - first start),
+// out[2] waves, out[3] mean life of a wave in ms, out[4] / out[5] smallest / largest per-wave clock in GHz
+static void clock_reduce(const std::vector<unsigned long long>& r, size_t waves, double* out) {
+    double sc = 0, sw = 0, lo = 1e30, hi = 0;
+    unsigned long long wmin = ~0ull, wmax = 0;
+    size_t used = 0;
+    for (size_t i = 0; i < waves; i++) {
+        const unsigned long long c0 = r[4 * i], c1 = r[4 * i + 1], w0 = r[4 * i + 2], w1 = r[4 * i + 3];
+        if (w1 <= w0 || c1 <= c0) continue;  // (a wave whose lanes all returned at once)
+        used++;
+        sc += (double)(c1 - c0);
+        sw += (double)(w1 - w0);
+        const double g = (double)(c1 - c0) / (double)(w1 - w0) * 0.1;
+        if (w1 - w0 > 1000) { lo = g < lo ? g : lo; hi = g > hi ? g : hi; }  // per-wave extremes only over waves that lived > 10 us (tick granularity)
+        wmin = w0 < wmin ? w0 : wmin;
+        wmax = w1 > wmax ? w1 : wmax;
+    }
+    out[0] = sw > 0 ? sc / sw * 0.1 : 0;
+    out[1] = used ? (double)(wmax - wmin) / 1e5 : 0;
+    out[2] = (double)used;
+    out[3] = used ? sw / (double)used / 1e5 : 0;
+    out[4] = lo > 1e29 ? 0 : lo;
+    out[5] = hi;
+}
+
+int zl_test_fq_mul_clock(zl_ctx* ctx, int waves_per_simd, int iters, double* out) {
+    if (!ctx || !out || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 20)) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t blocks = (uint32_t)ctx->cu_count * 4u * (uint32_t)waves_per_simd;
+    void* d = nullptr;
+    int rc = zl_scratch_get(ctx, 9, (size_t)blocks * 64 * 4 + (size_t)blocks * 32, &d);
+    if (rc) return rc;
+    unsigned long long* d_clk = (unsigned long long*)((char*)d + (size_t)blocks * 64 * 4);
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    ZL_HIP(ctx, hipEventCreate(&e0));
+    ZL_HIP(ctx, hipEventCreate(&e1));
+    ZL_HIP(ctx, hipMemsetAsync(d_clk, 0, (size_t)blocks * 32, st));
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, 8, (unsigned long long*)nullptr);
+    ZL_HIP(ctx, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_test_mul_rate, dim3(blocks), dim3(64), 0, st, (uint32_t*)d, iters, d_clk);
+    ZL_HIP(ctx, hipEventRecord(e1, st));
+    std::vector<unsigned long long> r((size_t)blocks * 4);
+    ZL_HIP(ctx, hipMemcpyAsync(r.data(), d_clk, (size_t)blocks * 32, hipMemcpyDeviceToHost, st));
+    ZL_HIP(ctx, hipStreamSynchronize(st));
+    ZL_HIP(ctx, hipGetLastError());
+    float ms = 0;
+    ZL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    clock_reduce(r, blocks, out);
+    out[6] = (double)blocks * 64.0 * (double)iters / ((double)ms * 1e-3) / 1e9;
+    out[7] = (double)ms;
+    return ZL_OK;
+}
+
+int zl_test_acc_clock(zl_ctx* ctx, int on) {
+    if (!ctx) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    ZL_HIP(ctx, hipDeviceSynchronize());
+    if (!on) {
+        if (ctx->acc_clk) (void)hipFree(ctx->acc_clk);
+        ctx->acc_clk = nullptr;
+        ctx->acc_clk_cap = ctx->acc_clk_waves = 0;
+        return ZL_OK;
+    }
+    if (!ctx->acc_clk) {
+        const size_t cap = (size_t)(1u << 18) * 32;  // 2^18 waves of 64 chunks: 2^24 chunks
+        ZL_HIP(ctx, hipMalloc(&ctx->acc_clk, cap));
+        ctx->acc_clk_cap = cap;
+    }
+    ctx->acc_clk_waves = 0;
+    return ZL_OK;
+}
+
+int zl_test_acc_clock_read(zl_ctx* ctx, double* out) {
+    if (!ctx || !out) return ZL_EINVAL;
+    if (!ctx->acc_clk || !ctx->acc_clk_waves) return ZL_EINVAL;  // not armed, or no large G1 accumulation ran since
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    ZL_HIP(ctx, hipDeviceSynchronize());
+    std::vector<unsigned long long> r(ctx->acc_clk_waves * 4);
+    ZL_HIP(ctx, hipMemcpy(r.data(), ctx->acc_clk, r.size() * 8, hipMemcpyDeviceToHost));
+    clock_reduce(r, ctx->acc_clk_waves, out);
     return ZL_OK;
 }
 
