@@ -260,7 +260,7 @@ def distributed_ntt_leg(be, dist, torch, dev, rank, world, log_m):
     from openzl_amd import ZL_BLS12_381
     from openzl_amd.sharded import DeviceNttEngine, sharded_ntt
 
-    log_g = world.bit_length() - 1
+    log_g = world.bit_length() - 1  # (world == 1 under ZL_FORCE_COLLECTIVE=1: log_g = 0, the exchange is a one-rank all_to_all_single)
     log_n = log_m + log_g
     eng = DeviceNttEngine(be, ZL_BLS12_381)
     x = random_scalars_lt_r(1 << log_m, 5000 + rank)  # this rank's block-column slice (any residues < r are valid Montgomery limbs)
@@ -321,14 +321,16 @@ class Run:
         self.args, self.torch, self.dist, self.be, self.dev, self.rank, self.world = args, torch, dist, be, dev, rank, world
         self.is_nccl = os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl"
         self.coll_dev = dev if self.is_nccl else None  # tensors of collectives: device memory over RCCL, host memory over gloo
+        # ZL_FORCE_COLLECTIVE=1 at N = 1: a ONE-rank process group whose barriers / all_reduce / all_gather / all_to_all really run (first contact with RCCL on a one-GPU box)
+        self.collective = world > 1 or (dist.is_available() and dist.is_initialized())
 
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, vals):
-        if self.world == 1:
+        if not self.collective:
             return [float(v) for v in vals]
         tt = self.torch.tensor([float(v) for v in vals], dtype=self.torch.float64, device=self.coll_dev)
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
@@ -407,7 +409,7 @@ def msm_leg(R: Run, inp: MsmInputs, steps: int, warmup: int, pipelined: bool, so
         xy_j, inf_j = fold_partials(curve, be.msm_partial_dev(h, d_vecs[j].data_ptr(), n).reshape(1, -1))
         if inf_j or not (np.asarray(xy_j) == inp.exp_xy[j]).all():
             fail("single call")
-    if R.world > 1:  # the folded all-rank result must be (sum over ALL shards of s_i k_i) G
+    if R.collective:  # the folded all-rank result must be (sum over ALL shards of s_i k_i) G
         for j in (0, 1):
             xy_j, inf_j = step(j)
             if inf_j or not (np.asarray(xy_j) == inp.exp_all[j]).all():
@@ -525,6 +527,29 @@ def strong_t1_leg(R: Run, log_total: int, steps: int, warmup: int, pipelined: bo
             li.free()
     R.barrier()
     return R.max_over_ranks([ms])[0]
+
+
+VALU_CYCLES_PER_MIXED_ADD = 17028 + 186  # profiles/r05_acc_instruction_budget.txt (tools/isa_budget.py): VALU issue cycles of one loop iteration per wave + the bucket-boundary blocks x 0.63
+NOMINAL_GHZ = 2.4
+
+
+def int_alu_clock(acc_clock, head, dom_ms):
+    """effective clock of the accumulation (in-kernel s_memtime / s_memrealtime) and what follows from it: SIMD cycles per wave-level mixed addition against
+    the ISA's VALU issue cycles, and the kernel against the same instruction stream at the nominal 2.4 GHz"""
+    if not acc_clock or "error" in acc_clock or not acc_clock.get("effective_clock_ghz"):
+        return {"effective_clock_ghz": None, "effective_clock_note": (acc_clock or {}).get("error", "not measured")}
+    f = acc_clock["effective_clock_ghz"]
+    wave_adds_per_simd = head["entries"] / 64.0 / 1024.0
+    cyc = f * 1e9 * dom_ms * 1e-3 / wave_adds_per_simd
+    t_nominal_ms = wave_adds_per_simd * VALU_CYCLES_PER_MIXED_ADD / (NOMINAL_GHZ * 1e9) * 1e3
+    return {"effective_clock_ghz": f, "effective_clock_min_max_wave_ghz": [acc_clock["min_wave_ghz"], acc_clock["max_wave_ghz"]],
+            "effective_clock_source": "s_memtime / s_memrealtime deltas of every wave of one more launch of the same accumulation (k_msm_accumulate_clk), %.2f ms against %.2f ms un-instrumented"
+                                      % (acc_clock["accumulate_ms_clock_reading_build"], dom_ms),
+            "simd_cycles_per_wave_mixed_add": cyc, "isa_valu_issue_cycles_per_wave_mixed_add": VALU_CYCLES_PER_MIXED_ADD,
+            "valu_issue_efficiency_at_that_clock": VALU_CYCLES_PER_MIXED_ADD / cyc,
+            "frac_vs_nominal_2p4ghz": t_nominal_ms / dom_ms,
+            "clock_note": "the chip clocks this body to its power budget (MI355X_MICROARCH.md, DVFS): frac_vs_nominal_2p4ghz = (the ISA's VALU issue cycles at 2.4 GHz) / kernel time = "
+                          "valu_issue_efficiency x effective_clock / 2.4; the multiplier chain alone (peak) clocks higher than the accumulation (profiles/r05_clock_probe_2_24.log)"}
 
 
 def scaling_model_leg(R: Run, inp: MsmInputs, head: dict):
@@ -800,8 +825,13 @@ def main():
     ap.add_argument("--config4-log-total", type=int, default=26, help="N > 1: total points of the config-4 leg (BASELINE: 2^26 over 8 GPUs)")
     ap.add_argument("--strong-log-total", type=int, default=24, help="N > 1: total points of the strong-scaling leg")
     ap.add_argument("--no-mctx", action="store_true", help="N > 1: skip the child-process run of the one-process transport")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar leg (pcie_inclusive): rocprofv3 runs of the headline keep only the headline's own accumulation launches")
+    ap.add_argument("--dry-run", action="store_true", help="print the legs a `--gpus N` run executes, the per-rank HBM plan and the expected wall time, and exit (no GPU, no process group)")
     args = ap.parse_args()
 
+    if args.dry_run:
+        print(json.dumps(dry_run_plan(args), indent=1))
+        return
     if args.transport == "mctx":
         return main_mctx(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -827,13 +857,21 @@ def main():
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    from openzl_amd.sharded import forced_collective
+
+    forced = world == 1 and forced_collective()
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:
+            # one rank, real backend: every collective of the N > 1 path (barrier, all_reduce, all_gather_into_tensor, all_to_all_single on device tensors) runs
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # nccl = RCCL over xGMI.  ZL_DIST_BACKEND=gloo exists only to exercise the N>1 code path on a single-GPU box.
         if is_nccl:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=os.environ["ZL_DIST_BACKEND"])
+            dist.init_process_group(backend=os.environ["ZL_DIST_BACKEND"], rank=rank, world_size=world)
 
     be = Backend(local_rank)
     be.enable_timing(True)
@@ -865,6 +903,25 @@ def main():
     head = msm_leg(R, inp, args.steps, args.warmup, not args.no_pipeline, True, "headline")
     elapsed, pipelined, single_ms = head["elapsed"], head["pipelined"], head["single_call_latency_ms"]
     tm = be.last_timing()
+    # effective shader clock of the dominant kernel, read from inside it: one more single-call MSM of the same input with the clock-reading build of the
+    # accumulation armed (k_msm_accumulate_clk = the product kernel + four scalar clock reads per wave; include/zl_backend_test.h), checked like every step
+    acc_clock = None
+    if rank == 0:
+        try:
+            from openzl_amd.backend import hook_acc_clock, hook_acc_clock_read
+            hook_acc_clock(be, True)
+            part_c = be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
+            tm_c = be.last_timing()
+            acc_clock = hook_acc_clock_read(be)
+            acc_clock["accumulate_ms_clock_reading_build"] = float(tm_c.dominant_ms)
+            hook_acc_clock(be, False)
+            xy_c, inf_c = fold_partials(inp.curve, part_c.reshape(1, -1))
+            if inf_c or not (np.asarray(xy_c) == exp_xy[0]).all():
+                raise SystemExit("MSM self-check failed (clock-reading build of the accumulation)")
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 -- small inputs run the four-lane kernel, which carries no clock reads
+            acc_clock = {"error": f"{type(e).__name__}: {e}"}
     scaling_model = None
     if rank == 0 and world == 1 and not args.no_configs and args.log_n >= 22:
         def _leg_scaling_model():
@@ -897,7 +954,7 @@ def main():
         pcie_info = {"ms_per_msm": float(np.min(ts)) * 1e3, "points_per_s": n / float(np.min(ts)),
                      "note": "zl_msm: scalars copied from pageable host memory (32 B/point over PCIe) + all kernels + result D2H, bases resident"}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_pcie:
         _guard("pcie_info", _leg_pcie_info)
 
     skew_info = None
@@ -994,6 +1051,20 @@ def main():
         back = dx.cpu().numpy().view(np.uint64)
         if not (back == x).all():
             raise SystemExit("NTT self-check failed: iNTT(NTT(x)) != x")
+        # effective clock while the passes run: a sleeping one-wave-per-XCD probe on its own stream spans 8 more round trips (include/zl_backend_test.h)
+        ntt_clock = None
+        try:
+            from openzl_amd.backend import hook_clock_probe_launch, hook_clock_probe_read
+            span_us = int(0.9 * 8 * (float(np.mean(fwd)) + float(np.mean(inv))) * 1e3)
+            torch.cuda.synchronize()
+            hook_clock_probe_launch(be, max(100, span_us))
+            for _ in range(8):
+                be.ntt_dev(ZL_BLS12_381, dx.data_ptr(), ln, inverse=False, mont=True)
+                be.ntt_dev(ZL_BLS12_381, dx.data_ptr(), ln, inverse=True, mont=True)
+            torch.cuda.synchronize()
+            ntt_clock = hook_clock_probe_read(be)
+        except Exception as e:  # noqa: BLE001
+            ntt_clock = {"error": f"{type(e).__name__}: {e}"}
         ntt_cpu = None
         if not args.no_cpu and rank == 0 and world == 1:
             # CPU oracle on the same vector; its forward transform must equal the GPU's bit for bit (full size)
@@ -1028,6 +1099,10 @@ def main():
             "fwd_plus_inv_elems_per_s": tot / ((f_ms + i_ms) * 1e-3),
             "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": 64.0 * (1 << ln) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
+                         "effective_clock_ghz": (ntt_clock or {}).get("effective_clock_ghz"), "nominal_clock_ghz": NOMINAL_GHZ,
+                         "effective_clock_source": "sleeping clock probe (one wave per XCD on its own stream: s_memtime / s_memrealtime) spanning 8 forward + inverse transforms issued back to back"
+                                                   if ntt_clock and "error" not in ntt_clock else (ntt_clock or {}).get("error"),
+                         "time_at_nominal_clock_ms": (f_ms * ntt_clock["effective_clock_ghz"] / NOMINAL_GHZ) if ntt_clock and ntt_clock.get("effective_clock_ghz") else None,
                          "traffic_unit": f"bytes per transform, all passes, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide; profiles/{ntt_traffic_src or 'r04_pmc_traffic_ntt.json'}; null for other sizes)",
                          "note": "per GPU; 64 B/element algorithmic (32 read + 32 written) per transform, all butterfly passes of one transform together; "
                                  "the last pass also streams its combined twiddles (+32 B/element read, one multiplication less)"},
@@ -1081,6 +1156,9 @@ def main():
             "prove_ms": tp * 1e3, "prove_ms_min": float(np.min(times)) * 1e3, "prove_ms_mean": float(np.mean(times)) * 1e3,
             "prove_ms_samples": [round(t * 1e3, 3) for t in times], "prove_device_ms": float(np.median(devms)), "constraints_per_s": n_c / tp,
             "synthesis_s": t_synth, "setup_s": t_setup, "verify_ms": t_verify * 1e3, "verified": True,
+            # BASELINE config 5 says "end-to-end": circuit synthesis (R1CS + full assignment of the Poseidon chain on the host, openzl::R1CS) + prove; the reference's
+            # prove() boundary (groth16.rs:445-457) starts AFTER synthesis, which is what constraints_per_s prices
+            "end_to_end_s": t_synth + tp, "end_to_end_constraints_per_s": n_c / (t_synth + tp),
             "timing": "prove_ms = median of 7 proofs after three warm-up proofs (prove_ms_mean / _min / _samples beside it)",
             "note": "prove = Groth16<E>::prove: assignment H2D, spmv, 7 NTTs, 4 G1 MSMs + 1 G2 MSM on the device, host assembly; "
                     "the proof is verified here with Groth16::verify (host pairing); bit-exact parity vs the oracle in tests/test_groth16.py, tests/test_host_mirror.py",
@@ -1221,6 +1299,7 @@ def main():
                                      "frac": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / fq_mul_peak_live(be),
                                      "peak_constant_operands": FQ_MUL_PEAK_CONST_G, "frac_vs_constant_operand_peak": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / FQ_MUL_PEAK_CONST_G,
                                      "mads_per_mixed_add": MADS_PER_MIXED_ADD, "muls_per_mixed_add": MULS_PER_MIXED_ADD,
+                                     **int_alu_clock(acc_clock, head, dom),
                                      "note": "the roofline that actually binds: (point, window) pairs x 9.04 multiplication-equivalents per mixed add "
                                              "(6M + 2S + one dual product scan with a shared Montgomery reduction = 6 x 392 + 2 x 301 + 588 = 3542 v_mad_u64_u32, counted in the kernel's ISA) "
                                              "/ kernel time, against the standalone rate of the same 14x28-bit Montgomery multiplier at the kernel's occupancy (3 waves/SIMD) on "
@@ -1315,8 +1394,120 @@ def main():
         dog.cancel()
         print(json.dumps(line), flush=True)
         return
+    if forced:
+        # ZL_FORCE_COLLECTIVE=1: the gates and every timed step above went through all_gather_into_tensor of a one-rank group (msm_leg -> openzl_amd/sharded.py) and
+        # were checked exactly; barriers and the MAX all_reduce ran on the same group.  The NTT exchange: one transform through sharded_ntt with G = 1.
+        coll = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "tensors": "device (RCCL)" if is_nccl else "host (gloo)",
+                "all_gather_into_tensor": "headline gate + every timed step, exact", "barrier_and_all_reduce_max": "timed region"}
+        try:
+            if is_nccl:
+                coll["all_to_all_single"] = distributed_ntt_leg(be, dist, torch, dev, 0, 1, min(args.ntt_log_n, 20))
+        except Exception as e:  # noqa: BLE001
+            coll["all_to_all_single"] = {"error": f"{type(e).__name__}: {e}"}
+        line["collective"] = coll
+        dist.barrier()
+        dist.destroy_process_group()
     print(json.dumps(line), flush=True)
     be.close()
+
+
+# ---- --dry-run: what a `--gpus N` run will do, without a GPU ---------------------------------------------------------------------------------------
+def _msm_scratch_bytes(n: int, c: int, sets: int = 3) -> dict:
+    """HBM of one rank's MSM pipeline for n points at window c, following MsmJob::plan_as / alloc / sort_tmp_sizes (openzl_amd/csrc/zl_msm_job.h): `sets`
+    rotating buffer sets (pipelined batches) + the shared sort temporaries.  An ESTIMATE for planning (grow-only slots add 1/8 of slack)."""
+    W = (255 + 1 + c - 1) // c
+    H = 1 << (c - 1)
+    NB = W * H
+    E = n * W
+    chunk = 128 if (E >> 7) >= (1 << 20) else 64
+    while chunk > 8 and E // chunk < (1 << 18):
+        chunk >>= 1
+    nchunks = (E + chunk - 1) // chunk
+    xyzz = 256  # four 64-byte coordinates
+    per_set = 4 * (3 * NB + n + E // 512) + 4 * E + NB * xyzz + 2 * nchunks * xyzz + (5 * W * max(1, H // 8) + 64) * xyzz
+    gn = max(1, NB >> 15)
+    s5 = 2 * (n * W * 2) + n * W + n * W * 4 + 8 * gn * W * 64
+    s6 = n * W * 2 + n * W * 4 + 8 * gn * 128 * 16
+    return {"window_bits": c, "windows": W, "buckets": NB, "entries": E, "per_buffer_set": per_set, "buffer_sets": sets, "sort_temporaries": s5 + s6,
+            "total": int(1.125 * (sets * per_set + s5 + s6))}
+
+
+def dry_run_plan(args) -> dict:
+    """`python bench.py --gpus N --dry-run`: the legs of that run in order, every rank's HBM plan against 288 GB, and the expected wall time from the last committed
+    single-GPU line under profiles/ (nothing is launched; no GPU and no process group needed)."""
+    N = args.gpus
+    n = 1 << args.log_n
+    ref, ref_name = None, None
+    for cand in ("r05_bench_final.json", "r04_bench_final.json"):
+        try:
+            ref = json.loads(open(os.path.join(ROOT, "profiles", cand)).read().strip().split("\n")[-1])
+            ref_name = cand
+            break
+        except Exception:
+            continue
+    ms24 = ref["ms_per_step"] if ref else 36.9
+    sm = (ref or {}).get("scaling_model", {}) or {}
+    meas = sm.get("measured_ms_per_msm_pipelined", {})
+    ntt_ms = (ref["ntt"]["forward_ms"] + ref["ntt"]["inverse_ms"]) if ref and ref.get("ntt") else 4.5
+    g16_ms = ref["groth16"]["prove_ms"] if ref and ref.get("groth16") else 18.4
+
+    def msm_ms(log_pts):  # pipelined ms per MSM on one GPU: measured where the reference line holds it, else scaled from the nearest size
+        k = f"2^{log_pts}"
+        if k in meas:
+            return float(meas[k])
+        return ms24 * (2.0 ** (log_pts - 24)) * (1.0 + 0.06 * max(0, 24 - log_pts))
+
+    pick_c = lambda lg: 19 if lg >= 24 else (18 if lg >= 23 else (17 if lg >= 21 else 16))  # noqa: E731 -- zl_pick_window's choices at these sizes
+    K, Wm = args.steps, args.warmup
+    legs, hbm = [], {}
+    head_ms = msm_ms(args.log_n)
+    legs.append({"leg": "headline (weak)", "per_gpu_points": n, "steps": K, "warmup": Wm, "collectives": "barrier x2, all_gather_into_tensor of K x 512 B per rank, all_reduce MAX" if N > 1 else "none",
+                 "setup_s": round(0.11 * n / (1 << 24) * 2 + 0.6, 2), "timed_ms": round(K * head_ms, 1), "gate_and_warmup_ms": round((2 + 3 + Wm + (2 if N > 1 else 0)) * head_ms * 1.06, 1),
+                 "solo_reference_on_rank0_ms": round(K * head_ms, 1) if N > 1 else 0})
+    hbm["bases (Affine, 128 B/point)"] = 128 * n
+    hbm["two scalar vectors (32 B/point each)"] = 64 * n
+    hbm["msm pipeline scratch"] = _msm_scratch_bytes(n, args.window or pick_c(args.log_n))
+    if N > 1 and not args.no_configs:
+        for name, log_total in (("config4", args.config4_log_total), ("strong", args.strong_log_total)):
+            lg = max(10, log_total - (N.bit_length() - 1))
+            t = msm_ms(lg)
+            legs.append({"leg": name, "total_points": 1 << log_total, "per_gpu_points": 1 << lg, "steps": K, "collectives": "as the headline", "timed_ms": round(K * t, 1),
+                         "gate_and_warmup_ms": round((7 + Wm) * t * 1.06, 1), "solo_reference_on_rank0_ms": round(K * t, 1),
+                         **({"t1_whole_input_on_rank0_ms": round((K + 4) * msm_ms(log_total), 1), "rank0_extra_hbm": 192 * (1 << log_total)} if name == "strong" else {})})
+    if N == 1 and not args.no_configs:
+        legs.append({"leg": "scaling_model + configs 1 / 2 / 4 (N = 1 only)", "timed_ms": round(8 * (msm_ms(21) + msm_ms(22) + msm_ms(23)) + 400, 1)})
+    if N == 1:
+        legs.append({"leg": "pcie_inclusive, msm_fixed_key (c = %d table: %d x the base memory), msm_skewed_scalars (N = 1 only)" % (args.fixed_key, (256 + args.fixed_key - 1) // max(1, args.fixed_key)),
+                     "timed_ms": round(4 * 44 + 4 * 33 + 3000 + 6 * 40, 1)})
+        hbm["fixed-key table (freed after its leg)"] = 128 * n * ((256 + args.fixed_key - 1) // max(1, args.fixed_key)) if args.fixed_key > 0 else 0
+    if not args.no_ntt:
+        ln = args.ntt_log_n
+        legs.append({"leg": "ntt replicas", "log_n": ln, "transforms": 2 * 16 + 16, "timed_ms": round(24 * ntt_ms * 2.0 ** (ln - 24), 1), "collectives": "all_reduce MAX" if N > 1 else "none"})
+        hbm["ntt vector + scratch (32 + 40 B/element)"] = 72 << ln
+        hbm["ntt last-pass twiddle tables (32 B/element, forward + inverse) + row tables"] = (64 << ln) + (64 << 20)
+        if N > 1 and (N & (N - 1)) == 0:
+            legs.append({"leg": "ntt distributed", "log_n": ln + N.bit_length() - 1, "exchange": "one all_to_all_single per transform: %d MiB sent per GPU" % ((32 << ln) * (N - 1) // N >> 20),
+                         "transforms": 8, "timed_ms": round(8 * (ntt_ms / 2 * 2.0 ** (ln - 24) + (32 << ln) / 50e9 * 1e3 + 0.3), 1)})
+            hbm["distributed ntt: exchange buffer"] = 32 << ln
+    if args.groth16_k > 0:
+        cons = 234 * args.groth16_k + 1  # Poseidon arity-2 chain: 234 constraints per hash (tests/groth16_util.py)
+        dom = 1 << max(1, (cons).bit_length())
+        legs.append({"leg": "groth16 " + ("replicas (one independent proof per GPU)" if N > 1 else "config 5 + small circuits + BN254"), "constraints": cons, "domain": dom,
+                     "host_synthesis_and_setup_s": round(2.0 * cons / 958465 + 0.3, 2), "proofs": 10, "timed_ms": round(10 * g16_ms * cons / 958465 + 5, 1)})
+        hbm["groth16: proving key (5 queries + window tables) + R1CS CSR + witness-map vectors"] = int(cons * (128 * 3 * 14 + 256 * 17 + 3 * 3 * 12 + 7 * 40))
+    if N > 1 and not args.no_mctx:
+        legs.append({"leg": "mctx (child process of rank 0 after the ranks released their GPUs: zl_ctx_create_multi, ncclCommInitAll inside the library)", "timed_ms": round(6 * msm_ms(args.log_n) + 8 * ntt_ms + 3000, 1)})
+    total_hbm = sum(v["total"] if isinstance(v, dict) else v for v in hbm.values())
+    wall = sum(l.get("timed_ms", 0) + l.get("gate_and_warmup_ms", 0) + l.get("solo_reference_on_rank0_ms", 0) + l.get("t1_whole_input_on_rank0_ms", 0) for l in legs) / 1e3
+    wall += sum(l.get("setup_s", 0) + l.get("host_synthesis_and_setup_s", 0) for l in legs)
+    startup = 8.0 + (6.0 if N > 1 else 0.0)  # import torch on a fresh box (1-2 minutes the very first time), library load, RCCL communicator
+    return {"dry_run": True, "n_gpus": N, "launch": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (N, N) if N > 1 else "python bench.py",
+            "backend": os.environ.get("ZL_DIST_BACKEND", "nccl") + (" (RCCL over xGMI)" if os.environ.get("ZL_DIST_BACKEND", "nccl") == "nccl" else ""),
+            "legs_in_order": legs, "hbm_plan_per_rank_bytes": hbm, "hbm_total_per_rank_gb": round(total_hbm / 1e9, 2), "hbm_capacity_gb": 288,
+            "hbm_note": "peak is lower: the fixed-key table, the per-leg inputs and the groth16 keys are freed before the next leg; rank 0 of the strong leg also holds the whole 2^%d input" % args.strong_log_total,
+            "expected_wall_s": round(wall + startup, 1), "expected_wall_note": "legs from the single-GPU numbers of profiles/%s (ms per pipelined MSM at each shard size, NTT, proof) + %.0f s of process start; "
+                                                                                "secondary legs at N > 1 run under a 600-s watchdog" % (ref_name or "(none found: built-in constants)", startup),
+            "nothing_was_run": True}
 
 
 if __name__ == "__main__":

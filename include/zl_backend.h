@@ -33,8 +33,15 @@
 extern "C" {
 #endif
 
-typedef enum { ZL_BLS12_381 = 1, ZL_BN254 = 2 } zl_curve_t;
-typedef enum { ZL_G1 = 1, ZL_G2 = 2 } zl_group_t;
+/* C++ callers / the library itself: a FIXED underlying type, so that an out-of-range value handed in by a foreign caller is a value the entry point rejects
+ * (ZL_EINVAL) and not undefined behaviour at the first load (UBSan -fsanitize=enum on zl_partials_sum(99, ...), round 5).  Same ABI: int. */
+#ifdef __cplusplus
+#define ZL_ENUM_INT : int
+#else
+#define ZL_ENUM_INT
+#endif
+typedef enum ZL_ENUM_INT { ZL_BLS12_381 = 1, ZL_BN254 = 2 } zl_curve_t;
+typedef enum ZL_ENUM_INT { ZL_G1 = 1, ZL_G2 = 2 } zl_group_t;
 typedef struct zl_ctx zl_ctx;
 
 enum {

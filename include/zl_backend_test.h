@@ -72,6 +72,11 @@ int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_pr
 int zl_test_fq_mul_clock(zl_ctx* ctx, int waves_per_simd, int iters, double* out);
 int zl_test_acc_clock(zl_ctx* ctx, int on);
 int zl_test_acc_clock_read(zl_ctx* ctx, double* out);
+/* ... and for kernels without instrumentation (the NTT passes): zl_test_clock_probe_launch starts eight one-wave blocks (one per XCD) on a stream of their
+ * own that sleep-spin on the 100-MHz counter for spin_us microseconds; launch it right before the work to observe, run the work, then
+ * zl_test_clock_probe_read (out: 6 doubles as above) = the effective clock of the chip during that window. */
+int zl_test_clock_probe_launch(zl_ctx* ctx, unsigned spin_us);
+int zl_test_clock_probe_read(zl_ctx* ctx, double* out);
 
 /* prod_i e(P_i, Q_i), n <= 64 pairs (P_i: x || y canonical u64 words, Q_i: x.c0 || x.c1 || y.c0 || y.c1; all-zero = infinity), after ONE final exponentiation:
  * the lock-step Miller loops of Groth16::verify (csrc/zl_pairing.h miller_multi), 12 canonical Fq coefficients as zl_pairing. */

@@ -155,6 +155,8 @@ def load_library(path: Optional[str] = None):
     L.zl_test_fq_mul_clock.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.zl_test_acc_clock.argtypes = [vp, C.c_int]
     L.zl_test_acc_clock_read.argtypes = [vp, C.POINTER(C.c_double)]
+    L.zl_test_clock_probe_launch.argtypes = [vp, C.c_uint]
+    L.zl_test_clock_probe_read.argtypes = [vp, C.POINTER(C.c_double)]
     if path is None:
         _lib = L
     return L
@@ -405,7 +407,7 @@ class MultiBackend:
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
 TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op",
-                    "zl_test_poseidon_permute_dev28r", "zl_test_fq_mul_clock", "zl_test_acc_clock", "zl_test_acc_clock_read"]
+                    "zl_test_poseidon_permute_dev28r", "zl_test_fq_mul_clock", "zl_test_acc_clock", "zl_test_acc_clock_read", "zl_test_clock_probe_launch", "zl_test_clock_probe_read"]
 
 
 def _p32(a: np.ndarray):
@@ -495,6 +497,17 @@ def hook_fq_mul_clock(be: "Backend", waves_per_simd: int = 3, iters: int = 50000
     d["g_products_per_s"] = float(v[6])
     d["ms_by_hip_events"] = float(v[7])
     return d
+
+
+def hook_clock_probe_launch(be: "Backend", spin_us: int) -> None:
+    """start the sleeping clock probe (one wave per XCD, own stream) for spin_us microseconds; launch the work to observe right after"""
+    be._check(be.L.zl_test_clock_probe_launch(be._ctx, int(spin_us)), "zl_test_clock_probe_launch")
+
+
+def hook_clock_probe_read(be: "Backend") -> dict:
+    v = (C.c_double * 6)()
+    be._check(be.L.zl_test_clock_probe_read(be._ctx, v), "zl_test_clock_probe_read")
+    return {k: float(v[i]) for i, k in enumerate(_CLOCK_KEYS)}
 
 
 def hook_acc_clock(be: "Backend", on: bool) -> None:

@@ -21,13 +21,14 @@ GROUPS = ["BlsG1", "BnG1", "BlsG2", "BnG2"]
 TAG = os.environ.get("ZL_BUILD_TAG", "")
 if TAG:
     LIB = os.path.join(HERE, f"libzl_backend.{TAG}.so")
-# Round 5: hipcc pads EVERY inline-asm statement whose result the next instruction reads with `s_nop 0` (GCNHazardRecognizer treats an inline-asm def as a
-# possible dst_sel / opsel partial write on gfx940+).  The product scans (zl_mul28*_gfx950.h) are chains of such statements holding only v_mad_u64_u32:
-# 515 of the 5 150 instructions of one mixed addition are those pads, and they are not free (tools/ubench2.hip: a pad costs ~0.7 SIMD cycles at three waves per
-# SIMD, 3.5 for a lone wave).  The units below are therefore compiled to device assembly, the pads that sit between one of OUR asm statements and an
-# instruction that cannot carry that hazard are removed, and the result is assembled, linked, bundled and embedded exactly as hipcc does itself
-# (hipcc -### shows the same five steps).  ZL_KEEP_ASM_NOPS=1 keeps hipcc's own output (A/B).
-STRIP_NOPS = os.environ.get("ZL_KEEP_ASM_NOPS", "") == ""
+# Round 5 experiment, OFF by default (ZL_STRIP_ASM_NOPS=1 turns it on for an A/B): hipcc pads EVERY inline-asm statement whose result the next instruction reads
+# with `s_nop 0` (GCNHazardRecognizer treats an inline-asm def as a possible dst_sel / opsel partial write on gfx940+).  The product scans (zl_mul28*_gfx950.h) are
+# chains of such statements holding only v_mad_u64_u32: 515 of the 5 150 instructions of one mixed addition are those pads.  With the switch on, the accumulation
+# units are compiled to device assembly, the pads between one of OUR asm statements and an instruction that cannot carry that hazard are removed, and the result is
+# assembled, linked, bundled and embedded exactly as hipcc does itself (hipcc -### shows the same five steps).  Measured (profiles/r05_nop_ab.log, interleaved on
+# one box, all MSM / Groth16 parity tests green on the stripped build): 2^24 accumulation 31.7-32.1 ms with and without the pads, 2^16 / 2^20 / G2 / BN254 equal too --
+# at three waves per SIMD the pads issue beside the other waves' VALU instructions.  The product build is hipcc's own output.
+STRIP_NOPS = os.environ.get("ZL_STRIP_ASM_NOPS", "") == "1"
 STRIP_VERSION = "strip-nops-v1"
 _LLVM = "/opt/rocm/lib/llvm/bin"
 STRIP_UNITS = ("zl_msm_acc_",)  # unit-name prefixes compiled that way
@@ -160,5 +161,59 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
     return LIB
 
 
+# ---- sanitizer build of the HOST side (VERDICT r4 "next" item 7) -----------------------------------------------------------------------------
+# zl_host.hip holds every parser of untrusted bytes (zl_groth16_keys_from_bytes, zl_point_from_bytes*: zl_serialize.h), the host pairing (zl_pairing.h) and the
+# R1CS / Poseidon / Groth16 mirror; zl_capi.hip the handle and argument checks.  `python -m openzl_amd.build --host-asan` compiles the HOST half of those two
+# units with -fsanitize=address,undefined (device code and every other unit: the product objects) and links libzl_backend.asan.so against the shared ASan
+# runtime; tests/test_sanitizers.py runs the serialisation / pairing / host-mirror tests (and, on a GPU box, the key-wire corruption fuzz) against it with
+# the runtime preloaded.  Any report aborts the process (-fno-sanitize-recover=all).
+ASAN_UNITS = ("zl_host", "zl_capi")
+ASAN_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize-recover=all", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-g"]
+ASAN_LIB = os.path.join(HERE, "libzl_backend.asan.so")
+
+
+def asan_runtime() -> str:
+    out = subprocess.check_output([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        cands = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(_LLVM, "..", "lib", "clang")) for f in fs if f == "libclang_rt.asan-x86_64.so"]
+        if not cands:
+            raise RuntimeError("no shared ASan runtime (libclang_rt.asan-x86_64.so) beside hipcc")
+        out = os.path.normpath(cands[0])
+    return out
+
+
+def build_host_asan(verbose: bool = True) -> str:
+    build(verbose=verbose)  # the product objects of every other unit
+    objs, todo = [], []
+    for name, src, defs in _units():
+        if name not in ASAN_UNITS:
+            objs.append(os.path.join(CSRC, name + ".o"))
+            continue
+        obj = os.path.join(CSRC, name + ".asan.o")
+        stamp = obj + ".sha"
+        d = _digest(_deps(os.path.join(CSRC, src)), " ".join(FLAGS + defs + ASAN_FLAGS))
+        objs.append(obj)
+        if not (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == d):
+            todo.append((name, src, defs, obj, stamp, d))
+
+    def one(t):
+        name, src, defs, obj, stamp, d = t
+        cmd = [_hipcc()] + FLAGS + defs + ASAN_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        open(stamp, "w").write(d)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            list(ex.map(one, todo))
+    if todo or not os.path.exists(ASAN_LIB) or os.path.getmtime(ASAN_LIB) < os.path.getmtime(LIB):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libasan", "-o", ASAN_LIB] + objs + ["-ldl"]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
-    print(build())
+    print(build_host_asan() if "--host-asan" in sys.argv else build())

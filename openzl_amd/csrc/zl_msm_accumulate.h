@@ -28,7 +28,7 @@ __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_
                                                     const Affine<typename HotField<typename G::F>::type>* __restrict__ bases,
                                                     XYZZ<typename HotField<typename G::F>::type>* __restrict__ bucket_sums,
                                                     XYZZ<typename HotField<typename G::F>::type>* __restrict__ partials, uint32_t ZL_CHUNK,
-                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ phib, uint32_t n_real) {
+                                                    const Affine<typename HotField<typename G::F>::type>* __restrict__ phib, uint32_t n_real, uint32_t idx_mask = 0x7fffffffu) {
     using F = typename HotField<typename G::F>::type;  // same layout as G::F; Fq2 on 28-bit limbs: the inlining flavour (zl_curve.h)
     const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
     if (start64 >= E) return;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_
             b_end = offsets[b + 1];
         }
         const uint32_t ent = entries[e];
-        const uint32_t idx = ent & 0x7fffffffu;
+        const uint32_t idx = ent & idx_mask;  // (the product kernels pass the literal: the sign bit off; the measurement kernel may fold the gather into a cache-resident prefix)
         const Affine<F> P = (G::GLV && idx >= n_real ? phib : bases)[idx];
         if (!P.is_inf()) {
             if constexpr (QUAD) zl::add_mixed_quad(acc, P.x, P.y, (ent >> 31) != 0, sub);
@@ -83,18 +83,20 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
 // s_memrealtime (the constant 100 MHz counter) at its start and at its end -- so that the effective shader clock of the accumulation (the chip clocks
 // dense VALU bodies to its power budget, MI355X_MICROARCH.md "DVFS give-back") is read from the kernel itself: sum of cycle deltas / sum of tick deltas.
 // One record of four u64 per workgroup (= wave).  G1 groups only; never launched by the product path unless the hook armed ctx->acc_clk.
+// idx_mask: 0x7fffffff = the product's gather; ZL_TUNE_ACC_CLK_IDX_BITS=b folds every base index into the first 2^b points (WRONG sums, measurement only): the
+// same arithmetic with the 128-B gathers served from L2 / MALL instead of HBM -- what the gathers cost in time and in clock (profiles/r05_acc_gather_ab.log).
 template <class G>
 __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate_clk(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases_,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums_,
                                                         XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
-                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, unsigned long long* __restrict__ clk) {
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, unsigned long long* __restrict__ clk, uint32_t idx_mask) {
     if constexpr (G::COORDS == 1) {
         using F = typename HotField<typename G::F>::type;
         const unsigned long long c0 = __builtin_readcyclecounter(), w0 = __builtin_amdgcn_s_memrealtime();
         zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
                                reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
-                               reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
+                               reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real, idx_mask);
         const unsigned long long c1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0) {
             unsigned long long* o = clk + (size_t)4 * blockIdx.x;
@@ -141,5 +143,5 @@ __global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accu
 #define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
     X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
-    X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*); \
+    X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*, uint32_t); \
     X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);

@@ -459,7 +459,8 @@ struct MsmJob {
         else if (G::COORDS == 1 && ctx->acc_clk && (size_t)((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK) * 32 <= ctx->acc_clk_cap) {  // armed by the measurement hook zl_test_acc_clock only
             ctx->acc_clk_waves = (nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK;
             hipLaunchKernelGGL((k_msm_accumulate_clk<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
-                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, (unsigned long long*)ctx->acc_clk);
+                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, (unsigned long long*)ctx->acc_clk,
+                               zl_tune("ZL_TUNE_ACC_CLK_IDX_BITS", 31) >= 31 ? 0x7fffffffu : ((1u << zl_tune("ZL_TUNE_ACC_CLK_IDX_BITS", 31)) - 1u));
         } else
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                            glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);

@@ -515,6 +515,43 @@ int zl_test_fq_mul_clock(zl_ctx* ctx, int waves_per_simd, int iters, double* out
     return ZL_OK;
 }
 
+// A clock probe for kernels that carry no instrumentation (the NTT passes): eight one-wave blocks (one per XCD by the dispatcher's round robin) spin on the
+// 100-MHz counter for `spin_us` microseconds, sleeping between reads, on a stream of their own; each leaves its cycle and tick deltas.  Launched right BEFORE
+// the work to be observed, read after it: the effective clock of the chip while that work ran (the spin itself is one sleeping wave per XCD).
+static __global__ void __launch_bounds__(64) k_clock_spin(unsigned long long* __restrict__ out, unsigned long long ticks) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long w = w0;
+    while (w - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        w = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[4 * blockIdx.x] = c0; out[4 * blockIdx.x + 1] = c1; out[4 * blockIdx.x + 2] = w0; out[4 * blockIdx.x + 3] = w; }
+}
+static hipStream_t g_probe_stream = nullptr;
+static unsigned long long* g_probe_buf = nullptr;
+
+int zl_test_clock_probe_launch(zl_ctx* ctx, unsigned spin_us) {
+    if (!ctx || spin_us < 1 || spin_us > 2000000) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    if (!g_probe_stream) ZL_HIP(ctx, hipStreamCreateWithFlags(&g_probe_stream, hipStreamNonBlocking));
+    if (!g_probe_buf) ZL_HIP(ctx, hipMalloc((void**)&g_probe_buf, 8 * 32));
+    ZL_HIP(ctx, hipMemsetAsync(g_probe_buf, 0, 8 * 32, g_probe_stream));
+    hipLaunchKernelGGL(k_clock_spin, dim3(8), dim3(64), 0, g_probe_stream, g_probe_buf, (unsigned long long)spin_us * 100ull);
+    ZL_HIP(ctx, hipGetLastError());
+    return ZL_OK;
+}
+
+int zl_test_clock_probe_read(zl_ctx* ctx, double* out) {
+    if (!ctx || !out || !g_probe_stream || !g_probe_buf) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    ZL_HIP(ctx, hipStreamSynchronize(g_probe_stream));
+    std::vector<unsigned long long> r(8 * 4);
+    ZL_HIP(ctx, hipMemcpy(r.data(), g_probe_buf, 8 * 32, hipMemcpyDeviceToHost));
+    clock_reduce(r, 8, out);
+    return ZL_OK;
+}
+
 int zl_test_acc_clock(zl_ctx* ctx, int on) {
     if (!ctx) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));

@@ -56,6 +56,8 @@ def lib():
     global _LIB
     if _LIB is None:
         so = build_oracle()
+        if os.environ.get("ZL_ORACLE_LIB"):  # tests/test_sanitizers.py: the -fsanitize=address,undefined build (make -C oracle asan)
+            so = os.environ["ZL_ORACLE_LIB"]
         try:
             _LIB = C.CDLL(os.path.join(ORACLE_DIR, "libzl_oracle_native.so") if _NATIVE else so)
         except OSError:

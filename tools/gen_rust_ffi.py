@@ -102,7 +102,7 @@ def structs(text: str):
 
 def constants(text_raw: str, text: str):
     out = []
-    for m in re.finditer(r"typedef\s+enum\s*\{([^}]*)\}\s*(zl_[a-z_]+)\s*;", text):
+    for m in re.finditer(r"typedef\s+enum\s*(?:ZL_ENUM_INT\s*)?\{([^}]*)\}\s*(zl_[a-z_]+)\s*;", text):
         for item in m.group(1).split(","):
             k, v = [x.strip() for x in item.split("=")]
             out.append((k, "i32", v))
