@@ -63,7 +63,10 @@ enum {
 #define ZL_MONT_IN 16u  /* NTT: only the input is Montgomery (ZL_MONT = both sides); the legs of the distributed transform */
 #define ZL_MONT_OUT 32u /* NTT: only the output is Montgomery */
 
-/* ---- context ------------------------------------------------------------------------------------------- */
+/* ---- context -------------------------------------------------------------------------------------------
+ * A zl_ctx is SINGLE-CALLER: its streams, scratch slots, event pool and staging buffers belong to the one call in flight (like a HIP stream, it orders
+ * work; it is not a lock).  Calls on one ctx from several threads must be serialised by the caller; independent work runs on independent contexts
+ * (several per device are fine).  A second pipelined MSM call entering a ctx that is already inside one returns ZL_EINVAL. */
 int zl_ctx_create(zl_ctx** out, int device_id);
 void zl_ctx_destroy(zl_ctx* ctx);
 /* run all work of this ctx on the caller's HIP stream (e.g. torch's current stream); NULL = the ctx's own */

@@ -145,6 +145,11 @@ struct zl_ctx {
     // events of the job pipelines, created once and reused by every call: a hipEventCreate / hipEventDestroy pair costs ~50 us of host time, and a
     // four-job pipeline used 14 of them per call -- 0.8 ms at the END of every Groth16 proof (round 4 host trace, profiles/r04_g16_share_ab.log)
     std::vector<hipEvent_t> ev_pool[2];  // [0] hipEventDisableTiming, [1] timing
+    // A ctx is SINGLE-CALLER (include/zl_backend.h): the pools above, the scratch slots and the streams belong to the one call in flight.  The job pipeline
+    // holds this flag while it uses pool events (zl_ctx_events returns a pointer into the vector: a second, concurrent pipeline on the same ctx would alias
+    // the events and a growing pool would move them -- ADVICE r4); a second caller gets ZL_EINVAL instead of a race.  Concurrency = one ctx per thread
+    // (Groth16 runs its G2 MSM and witness map on ctx->aux / aux2 for that reason).
+    std::atomic<int> pipeline_busy{0};
     uint64_t ntt_clock = 0;
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
@@ -168,7 +173,8 @@ inline int zl_tune(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-// the first `count` events of the ctx's pool of one kind (grown on demand; owned by the ctx: zl_ctx_destroy)
+// the first `count` events of the ctx's pool of one kind (grown on demand; owned by the ctx: zl_ctx_destroy).  The pointer is valid until the next call for
+// the SAME kind that has to grow the pool: callers take it once per pipeline call, under ctx->pipeline_busy
 inline int zl_ctx_events(zl_ctx* ctx, int timing, size_t count, hipEvent_t** out) {
     std::vector<hipEvent_t>& pool = ctx->ev_pool[timing ? 1 : 0];
     while (pool.size() < count) {

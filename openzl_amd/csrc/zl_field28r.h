@@ -15,7 +15,7 @@
 //     wred(a)          needs B(a) < 2^20                  -> < 2r   (quotient estimate from the top limb)
 //     canon(a)         needs B(a) < 2^20                  -> the canonical residue < r
 //     pack(a)          needs a carried and < 2^256 (any a < 2r)
-// Everything is ZL_HD (the host path exists for the unit test of this header, tests/test_fr28_host.py; the product only uses it on the device).
+// Everything is ZL_HD (the host path exists for the unit test of this header, tests/test_fr28.py; the product only uses it on the device).
 #pragma once
 #include "zl_field.h"
 #include "zl_mul28r_gfx950.h"  // single-chain inline-asm product scan for 10 limbs (device only; gen_mul28.py)

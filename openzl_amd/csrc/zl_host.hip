@@ -864,8 +864,9 @@ int zl_point_from_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const u
 // e(P, Q) after the final exponentiation: 12 canonical Fq coefficients of the w-polynomial (tests vs the oracle)
 int zl_pairing(zl_curve_t curve, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out12) {
     if (!p_xy || !q_xy || !out12) return ZL_EINVAL;
-    if (curve == ZL_BLS12_381) { pairing::BlsEngine::store(out12, pairing::BlsEngine::multi_pairing({p_xy}, {q_xy})); return ZL_OK; }
-    if (curve == ZL_BN254) { pairing::BnEngine::store(out12, pairing::BnEngine::multi_pairing({p_xy}, {q_xy})); return ZL_OK; }
+    bool degenerate = false;  // a zero Miller value (inputs that are not points of the pairing groups): ZL_ENOTCURVE instead of a made-up number
+    if (curve == ZL_BLS12_381) { pairing::BlsEngine::store(out12, pairing::BlsEngine::multi_pairing({p_xy}, {q_xy}, &degenerate)); return degenerate ? ZL_ENOTCURVE : ZL_OK; }
+    if (curve == ZL_BN254) { pairing::BnEngine::store(out12, pairing::BnEngine::multi_pairing({p_xy}, {q_xy}, &degenerate)); return degenerate ? ZL_ENOTCURVE : ZL_OK; }
     return ZL_EINVAL;
 }
 // test hook (include/zl_backend_test.h): prod_i e(P_i, Q_i) through the lock-step Miller loops that Groth16::verify uses for its four pairings
@@ -875,9 +876,10 @@ int zl_test_pairing_product(zl_curve_t curve, size_t n, const uint64_t* ps_xy, c
     const size_t pw = curve == ZL_BLS12_381 ? 12 : 8;  // u64 words of a G1 point; a G2 point has twice as many
     std::vector<const uint64_t*> ps(n), qs(n);
     for (size_t i = 0; i < n; i++) { ps[i] = ps_xy + i * pw; qs[i] = qs_xy + i * 2 * pw; }
-    if (curve == ZL_BLS12_381) pairing::BlsEngine::store(out12, pairing::BlsEngine::multi_pairing(ps, qs));
-    else pairing::BnEngine::store(out12, pairing::BnEngine::multi_pairing(ps, qs));
-    return ZL_OK;
+    bool degenerate = false;
+    if (curve == ZL_BLS12_381) pairing::BlsEngine::store(out12, pairing::BlsEngine::multi_pairing(ps, qs, &degenerate));
+    else pairing::BnEngine::store(out12, pairing::BnEngine::multi_pairing(ps, qs, &degenerate));
+    return degenerate ? ZL_ENOTCURVE : ZL_OK;
 }
 // Groth16::verify: public_inputs = n x 4 u64 canonical (without the leading ONE); *ok = 1 / 0
 int zl_groth16_verify(const zl_g16_keys* k, const uint64_t* public_inputs, size_t n, const zl_g16_proof* proof, int* ok) {

@@ -140,6 +140,14 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         return ZL_OK;
     }
     int rc;
+    // one pipeline per ctx at a time (zl_ctx.h): the event pool, the three buffer sets and the side streams belong to this call
+    struct Busy {
+        std::atomic<int>& f;
+        bool mine;
+        explicit Busy(std::atomic<int>& x) : f(x), mine(x.exchange(1, std::memory_order_acq_rel) == 0) {}
+        ~Busy() { if (mine) f.store(0, std::memory_order_release); }
+    } busy(ctx->pipeline_busy);
+    if (!busy.mine) return ZL_EINVAL;
     if (!ctx->stream_sort) {
         // highest priority: the short sort / tail kernels must get wave slots as the long accumulation kernel frees them
         int prio_lo = 0, prio_hi = 0;

@@ -770,6 +770,25 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     uint32_t S_prev = 0;
+    // byte budget of the per-(size, direction) tables of this ctx -- the last pass's combined twiddles (N x 32 B) and the middle passes' row tables (<= 32 MB each):
+    // least recently used keys go first, with ALL their tables; the stream is drained before a table that may be in flight is freed
+    const size_t table_budget = (size_t)zl_tune("ZL_TUNE_NTT_LAST_MB", 2048) << 20;  // 2^24 forward + inverse = 1 GiB + row tables; a sweep over sizes stays bounded
+    int rc_t = ZL_OK;
+    auto make_room = [&](size_t want) -> int {
+        while (ctx->ntt_last_bytes + want > table_budget) {
+            zl_twiddles* victim = nullptr;
+            for (auto& kv : ctx->twiddles)
+                if (kv.second.last_bytes && &kv.second != tw && (!victim || kv.second.last_used < victim->last_used)) victim = &kv.second;
+            if (!victim) break;
+            ZL_HIP(ctx, hipStreamSynchronize(st));
+            if (victim->d_last) (void)hipFree(victim->d_last);
+            victim->d_last = nullptr;
+            for (auto& r : victim->d_row) { if (r) (void)hipFree(r); r = nullptr; }
+            ctx->ntt_last_bytes -= victim->last_bytes;
+            victim->last_bytes = 0;
+        }
+        return ZL_OK;
+    };
     for (uint32_t p = 1; p <= pl.P; p++) {
         const bool last = p == pl.P;
         NttArgs a{};
@@ -801,27 +820,15 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         // rides on pass 1) and the scaled inverse; the coset inverse (its 1/n lives in the coset table) combines on the fly
         if (last && pl.P > 1 && !(inverse && coset) && n <= 26 && !getenv("ZL_NTT_NO_LAST_TABLE")) {
             const size_t want = N * sizeof(F);
-            const size_t budget = (size_t)zl_tune("ZL_TUNE_NTT_LAST_MB", 2048) << 20;  // 2^24 forward + inverse = 1 GiB; a sweep over sizes stays bounded
-            if (!tw->d_last && want <= budget) {
-                // least recently used tables of other (size, direction) keys go first; the stream is drained before a table in flight is freed
-                while (ctx->ntt_last_bytes + want > budget) {
-                    zl_twiddles* victim = nullptr;
-                    for (auto& kv : ctx->twiddles)
-                        if (kv.second.d_last && &kv.second != tw && (!victim || kv.second.last_used < victim->last_used)) victim = &kv.second;
-                    if (!victim) break;
-                    ZL_HIP(ctx, hipStreamSynchronize(st));
-                    (void)hipFree(victim->d_last);
-                    ctx->ntt_last_bytes -= victim->last_bytes;
-                    victim->d_last = nullptr;
-                    victim->last_bytes = 0;
-                }
+            if (!tw->d_last && want <= table_budget) {
+                if ((rc_t = make_room(want))) return rc_t;
                 void* t = nullptr;
-                if (ctx->ntt_last_bytes + want <= budget && hipMalloc(&t, want) == hipSuccess) {
+                if (ctx->ntt_last_bytes + want <= table_budget && hipMalloc(&t, want) == hipSuccess) {
                     a.last_tw = nullptr;
                     if (lazy) hipLaunchKernelGGL((k_ntt_last_table28<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
                     else hipLaunchKernelGGL((k_ntt_last_table<FrP>), dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
                     tw->d_last = t;
-                    tw->last_bytes = want;
+                    tw->last_bytes += want;
                     ctx->ntt_last_bytes += want;
                 } else {
                     (void)hipGetLastError();  // no room: keep combining on the fly
@@ -832,15 +839,22 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         }
         if (lazy && !last && p > 1 && p <= 4 && S_prev + a.s <= 20) {  // middle pass: its row twiddles per tile high index, <= 32 MB, kept with the tables
             if (!tw->d_row[p - 1]) {
+                //  counted in the same byte budget as the last-pass tables and evicted with them: a sweep over sizes, directions and curves
+                // would otherwise keep up to three 32-MB tables per key for ever
+                const size_t want = (sizeof(F)) << (S_prev + a.s);
                 void* t = nullptr;
-                if (hipMalloc(&t, (sizeof(F)) << (S_prev + a.s)) == hipSuccess) {
+                if ((rc_t = make_room(want))) return rc_t;
+                if (ctx->ntt_last_bytes + want <= table_budget && hipMalloc(&t, want) == hipSuccess) {
                     const uint64_t cnt = 1ull << (S_prev + a.s);
                     hipLaunchKernelGGL((k_ntt_row_table28<FrP>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, st, reinterpret_cast<F*>(t), a);
                     tw->d_row[p - 1] = t;
+                    tw->last_bytes += want;
+                    ctx->ntt_last_bytes += want;
                 } else {
-                    (void)hipGetLastError();
+                    (void)hipGetLastError();  // no room: the pass forms its row twiddles per tile (the LDS size below accounts for it)
                 }
             }
+            if (tw->d_row[p - 1]) tw->last_used = ++ctx->ntt_clock;
             a.row_tw = tw->d_row[p - 1];
         }
         // columns per tile

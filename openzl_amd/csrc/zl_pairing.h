@@ -187,7 +187,10 @@ struct Engine {
         return r;
     }
     // a^-1 by linear algebra over Fq: column j of M is a w^j, solve M g = e_0 (Gauss-Jordan, one Fq inversion per pivot: ~2000 products, once per verification)
-    static Fq12 inverse(const Fq12& a) {
+    // `singular` (optional) reports a == 0: the result is then one() and meaningless (a Miller value is never zero for points of the prime-order subgroups; a caller
+    // that was handed garbage learns it here instead of comparing a made-up value -- ADVICE r4)
+    static Fq12 inverse(const Fq12& a, bool* singular = nullptr) {
+        if (singular) *singular = false;
         F M[12][13];
         for (int j = 0; j < 12; j++) {
             Fq12 b;
@@ -200,7 +203,7 @@ struct Engine {
         for (int c = 0; c < 12; c++) {
             int piv = c;
             while (piv < 12 && M[piv][c].is_zero()) piv++;
-            if (piv == 12) return one();  // a == 0: not a pairing value (callers never pass it)
+            if (piv == 12) { if (singular) *singular = true; return one(); }  // a is a zero divisor (Fq12 is a field: a == 0)
             if (piv != c)
                 for (int k = 0; k < 13; k++) std::swap(M[piv][k], M[c][k]);
             const F inv = zl::inv(M[c][c]);
@@ -217,8 +220,8 @@ struct Engine {
     }
     // f^((q^12 - 1) / r) = (conj6(f) / f)^((q^6 + 1) / r): the easy factor by the Frobenius and one inversion, the rest as one power in 4-bit fixed windows
     // (~2050 squarings + ~500 products for BLS12-381; rounds 2-3 took the whole 4314-bit power bit by bit with general products: 60 ms per verification)
-    static Fq12 final_exp(const Fq12& f0) {
-        const Fq12 f = mul(conj6(f0), inverse(f0));
+    static Fq12 final_exp(const Fq12& f0, bool* singular = nullptr) {
+        const Fq12 f = mul(conj6(f0), inverse(f0, singular));
         const uint32_t* e = PP::final_exp();
         Fq12 tab[16];
         tab[0] = one();
@@ -333,7 +336,10 @@ struct Engine {
         return true;
     }
     // product of pairings prod_i e(P_i, Q_i) with ONE final exponentiation
-    static Fq12 multi_pairing(const std::vector<const uint64_t*>& ps, const std::vector<const uint64_t*>& qs) {
+    // `degenerate` (optional): set when the Miller value came out as zero (only possible for inputs off the curve / outside the subgroups, e.g. a line through
+    // P that vanishes at it); the returned value is then not a pairing
+    static Fq12 multi_pairing(const std::vector<const uint64_t*>& ps, const std::vector<const uint64_t*>& qs, bool* degenerate = nullptr) {
+        if (degenerate) *degenerate = false;
         std::vector<Lane> L;
         for (size_t i = 0; i < ps.size(); i++) {
             Lane ln;
@@ -346,7 +352,7 @@ struct Engine {
             f = one();
             for (auto& ln : L) f = mul(f, miller(ln.xP, ln.yP, ln.Q));
         }
-        return final_exp(f);
+        return final_exp(f, degenerate);
     }
     static void store(uint64_t* out, const Fq12& a) {  // 12 canonical coefficients
         for (int i = 0; i < 12; i++) {

@@ -108,8 +108,15 @@ fn ctx() -> Result<*mut ffi::zl_ctx, Error> {
 /// constraint matrices are uploaded with the first proof and stay on the device.  `shape` records that circuit's (constraints, instance
 /// variables, witness variables, linear combinations): a later compiler with another shape is refused with `Error` instead of being proved
 /// against the resident matrices.  (The C++ mirror of this file, `openzl::Groth16<E>::prove` in `csrc/zl_host.hip`, goes further and compares a
-/// digest of all rows, which it can cache per compiler object; here every proof consumes a fresh compiler, and hashing ~3 * 10^6 non-zeros per proof
-/// would cost half of the 19 ms a 958 465-constraint proof takes.)
+/// digest of all rows, which it can cache per compiler object; here every proof consumes a fresh compiler, and building + hashing ~3 * 10^6 non-zeros per
+/// proof would cost more than the 18 ms a 958 465-constraint proof takes.)
+///
+/// What the shape check cannot see -- a DIFFERENT circuit with the SAME four counts -- is covered three ways:
+/// * `digest` holds an FNV-1a fingerprint of all rows of A, B, C taken at upload; with [`ProvingContext::set_check_binding`]`(true)` -- the default of debug
+///   builds -- every proof rebuilds the matrices of its compiler, fingerprints them and refuses (`Error`) on a mismatch;
+/// * [`ProvingContext::rebind`] drops the resident matrices, so that the next proof uploads (and fingerprints) its own;
+/// * and the contract, as in the reference: `prove` NEVER checks the proof it returns (`Groth16::prove`, groth16.rs:445-457, does not either) -- a caller that
+///   switches circuits on one context without `rebind` in a release build gets `Ok(proof)` that does not verify.  `ProofSystem::verify` is the check.
 pub struct ProvingContext<E>
 where
     E: Mi355xEngine,
@@ -121,6 +128,28 @@ where
     r1cs: Cell<u64>,
     /// shape of that circuit (all zero until the first proof)
     shape: Cell<[usize; 4]>,
+    /// FNV-1a fingerprint of every row of the uploaded A, B, C (0 until the first proof)
+    digest: Cell<u64>,
+    /// fingerprint the compiler of every proof against `digest` (costs one `to_matrices` per proof)
+    check_binding: Cell<bool>,
+}
+
+/// FNV-1a over the CSR arrays of the three matrices, in upload order: row pointers, columns, coefficient limbs
+fn csr_digest(parts: [(&[u32], &[u32], &[u64]); 3]) -> u64 {
+    let mut h = 0xcbf2_9ce4_8422_2325u64;
+    let mut eat = |v: u64| {
+        for b in v.to_le_bytes() {
+            h ^= b as u64;
+            h = h.wrapping_mul(0x0000_0100_0000_01b3);
+        }
+    };
+    for (ptr_, col, val) in parts {
+        eat(ptr_.len() as u64);
+        ptr_.iter().for_each(|x| eat(*x as u64));
+        col.iter().for_each(|x| eat(*x as u64));
+        val.iter().for_each(|x| eat(*x));
+    }
+    h | 1 // never 0: 0 means "nothing bound"
 }
 
 impl<E> ProvingContext<E>
@@ -137,7 +166,27 @@ where
         if rc != ffi::ZL_OK {
             return Err(Error);
         }
-        Ok(Self { key: proving_key, keys, r1cs: Cell::new(0), shape: Cell::new([0; 4]) })
+        Ok(Self { key: proving_key, keys, r1cs: Cell::new(0), shape: Cell::new([0; 4]), digest: Cell::new(0), check_binding: Cell::new(cfg!(debug_assertions)) })
+    }
+
+    /// Fingerprint the compiler of every proof against the circuit whose matrices are resident (default: on in debug builds, off in release builds)
+    pub fn set_check_binding(&self, on: bool) {
+        self.check_binding.set(on);
+    }
+
+    /// Forget the resident constraint matrices: the next proof uploads (and fingerprints) those of its own compiler.  Call it before proving ANOTHER circuit
+    /// of the same shape with this key -- which only makes sense if the key was compiled for that circuit too.
+    pub fn rebind(&self) -> Result<(), Error> {
+        if self.r1cs.get() != 0 {
+            let rc = unsafe { ffi::zl_r1cs_free(ctx()?, self.r1cs.get()) };
+            self.r1cs.set(0);
+            self.shape.set([0; 4]);
+            self.digest.set(0);
+            if rc != ffi::ZL_OK {
+                return Err(Error);
+            }
+        }
+        Ok(())
     }
 }
 
@@ -352,7 +401,7 @@ where
         if context.r1cs.get() != 0 && context.shape.get() != shape {
             return Err(Error);
         }
-        if context.r1cs.get() == 0 {
+        if context.r1cs.get() == 0 || context.check_binding.get() {
             let m = cs.to_matrices().ok_or(Error)?;
             let csr = |rows: &Vec<Vec<(E::Fr, usize)>>| {
                 let (mut ptr_, mut col, mut val) = (vec![0u32], Vec::new(), Vec::<u64>::new());
@@ -366,6 +415,13 @@ where
                 (ptr_, col, val)
             };
             let (a, b, cc) = (csr(&m.a), csr(&m.b), csr(&m.c));
+            let fingerprint = csr_digest([(&a.0, &a.1, &a.2), (&b.0, &b.1, &b.2), (&cc.0, &cc.1, &cc.2)]);
+            if context.r1cs.get() != 0 {
+                // check_binding: same shape, but is it the same circuit?
+                if fingerprint != context.digest.get() {
+                    return Err(Error);
+                }
+            } else {
             let view = ffi::zl_r1cs {
                 n_constraints: m.num_constraints as u32,
                 n_instance: m.num_instance_variables as u32,
@@ -380,6 +436,8 @@ where
             }
             context.r1cs.set(handle);
             context.shape.set(shape);
+            context.digest.set(fingerprint);
+            }
         }
         // assignment = instance block (ONE, public inputs) then witnesses, as arkworks' in-memory Montgomery limbs: E::Fr is a
         // single-field tuple struct over BigInteger256, itself a single-field tuple struct over [u64; 4]; ark-ff 0.3 declares no

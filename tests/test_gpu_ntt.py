@@ -65,3 +65,34 @@ def test_ntt_roundtrip_and_spot_checks_full_size(backend, log_n):
         for cf in reversed(coeffs):
             acc = (acc * wk + cf) % r
         assert ol.limbs_to_ints(X2[k:k + 1])[0] == acc
+
+
+@pytest.mark.parametrize("coset", [False, True], ids=["plain", "coset"])
+def test_ntt_four_pass_sizes_roundtrip_and_spot_checks(backend, coset):
+    """sizes n >= 25 take FOUR passes through the lazily reduced kernel (k_ntt_pass28): a second middle pass with its own row table (d_row[2]) that
+    runs in place over the 40-byte scratch elements -- a path no smaller size reaches.  2^25, forward and inverse, plain and coset: the round trip is the
+    identity bit for bit, and the transform of a low-degree input equals Horner's evaluation at w^k (resp. g w^k) in Python integers."""
+    curve = po.BLS12_381
+    log_n = 25
+    n = 1 << log_n
+    x = ol.random_scalars(curve, n, 78)
+    X = backend.ntt(curve.cid, x, coset=coset)
+    assert not (X[:8] == x[:8]).all()
+    back = backend.ntt(curve.cid, X, inverse=True, coset=coset)
+    assert (back == x).all()
+    del X, back
+    r = curve.fr.p
+    w = po.domain_root(curve, log_n)
+    g = 7 if coset else 1  # Fr multiplicative generator of BLS12-381 (include/zl_backend.h: ZL_COSET)
+    m = 1 << 10
+    x2 = np.zeros_like(x)
+    x2[:m] = x[:m]
+    X2 = backend.ntt(curve.cid, x2, coset=coset)
+    coeffs = ol.limbs_to_ints(x2[:m])
+    rng = np.random.default_rng(4)
+    for k in [0, 1, n - 1, n // 2 + 1] + [int(v) for v in rng.integers(0, n, 6)]:
+        pt = g * pow(w, k, r) % r
+        acc = 0
+        for cf in reversed(coeffs):
+            acc = (acc * pt + cf) % r
+        assert ol.limbs_to_ints(X2[k:k + 1])[0] == acc, k

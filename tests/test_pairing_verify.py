@@ -118,3 +118,25 @@ def test_large_key_uses_window_tables_and_still_verifies(backend):
     finally:
         keys.close()
         circ.close()
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_pairing_product_falls_back_on_a_vertical_line(curve):
+    """the lock-step Miller loops cannot step over a vertical line (one shared inversion of the slope denominators) and hand the whole product to
+    the one-by-one loops.  Points of the prime-order subgroups never produce one, so the path is driven with a Q whose y is zero (not a curve point: its first
+    tangent is vertical): the product of [a valid pair, the degenerate pair] must still be the Fq12 product of the two single values (the final exponentiation is
+    a homomorphism), whichever path computed them -- and a status comes back, not a crash."""
+    from openzl_amd.backend import hook_pairing_product
+
+    G1 = po.g1_generator(curve)
+    P = ol.points_to_limbs(curve, [po.g1_mul(curve, 9, G1), po.g1_mul(curve, 0x77, G1)])
+    Q = gu.g2_mul_gen(curve, [5, 11])
+    Qbad = Q.copy()
+    half = Qbad.shape[1] // 2
+    Qbad[1, half:] = 0  # y = 0 (x kept): tangent at Q is vertical
+    ctx = po.Fq12Ctx(curve)
+    s0 = ol.limbs_to_ints(pairing(curve.cid, P[0], Q[0]))
+    s1 = ol.limbs_to_ints(hook_pairing_product(curve.cid, P[1:2], Qbad[1:2]))
+    got = ol.limbs_to_ints(hook_pairing_product(curve.cid, P, Qbad))
+    assert got == ctx.mul(s0, s1)
+    assert got != ctx.mul(s0, ol.limbs_to_ints(pairing(curve.cid, P[1], Q[1])))  # ... and it is not the value of the valid pair
