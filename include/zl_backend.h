@@ -254,6 +254,10 @@ int zl_point_from_bytes_uncompressed(zl_curve_t curve, zl_group_t group, const u
  * matrices and rejects a circuit whose variable counts or evaluation domain do not match the key).  ZL_EINVAL = malformed input. */
 int zl_groth16_keys_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len);
 int zl_groth16_keys_from_bytes(zl_ctx* ctx, zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags, zl_g16_keys** out);
+/* The same bytes validated on the HOST only (no ctx, no device memory): framing, Vec lengths against the input size, canonical coordinates, flag bits, the shape
+ * relations between the five queries; ZL_CHECK also verifies the verifying-key points (curve and subgroup).  ZL_OK = zl_groth16_keys_from_bytes would accept the
+ * framing (its device-side curve checks of the queries under ZL_CHECK are not repeated here).  Same error codes. */
+int zl_groth16_keys_parse(zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags);
 /* ark_groth16::VerifyingKey<E>::serialize (compressed points): alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (u64 length first).
  * The reference's VerifyingContext (/root/reference/plugins/arkworks/src/groth16.rs:181-396) frames a PreparedVerifyingKey as
  *     vk | alpha_g1_beta_g2 (one Fqk) | gamma_g2_neg_pc | delta_g2_neg_pc

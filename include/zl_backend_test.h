@@ -54,6 +54,9 @@ int zl_test_circuit_tweak(zl_circuit* c);
  * multiple of r used by the subtractions (0..20).  op: 0 mul(a, b) (= a b 2^-280 mod r)  1 a + b  2 a - b  3 canon(a)  4 a chain of lazy
  * additions / biased subtractions at the bounds the passes reach, closed by one product (zl_testhooks.hip). */
 int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out);
+/* The same header instantiated on NINE limbs of 29 bits (round 5: *_Fr29, R' = 2^261, what the NTT passes multiply with): op 0 = a b 2^-261 mod r; j <= 6; the
+ * chain of op 4 weakly reduces after every step (its products only take B(a) B(b) <= 70 / 169); op 5 (both instances) canon(wred(2a + 2b)). */
+int zl_test_fr29_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out);
 
 /* MEASUREMENT ONLY (bench.py's integer-ALU roofline): chains of the accumulation kernel's 14 x 28-bit Montgomery product on per-lane pseudo-random
  * operands, cu_count x 4 x waves_per_simd wavefronts, `iters` products per lane; returns 10^9 products per second.  This is the live-data ceiling of

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
     "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
-    "zl_point_bytes_uncompressed", "zl_point_to_bytes_uncompressed", "zl_point_from_bytes_uncompressed", "zl_groth16_keys_to_bytes", "zl_groth16_keys_from_bytes",
+    "zl_point_bytes_uncompressed", "zl_point_to_bytes_uncompressed", "zl_point_from_bytes_uncompressed", "zl_groth16_keys_to_bytes", "zl_groth16_keys_from_bytes", "zl_groth16_keys_parse",
     "zl_groth16_vk_to_bytes",
 ]
 
@@ -129,6 +129,7 @@ def load_library(path: Optional[str] = None):
     L.zl_point_from_bytes_uncompressed.argtypes = [C.c_int, C.c_int, u8p, C.c_int, u64p, u8p]
     L.zl_groth16_keys_to_bytes.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.zl_groth16_keys_from_bytes.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_uint, C.POINTER(vp)]
+    L.zl_groth16_keys_parse.argtypes = [C.c_int, u8p, C.c_size_t, C.c_uint]
     L.zl_groth16_vk_to_bytes.argtypes = [vp, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     # multi-GPU in one process
     L.zl_ctx_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
@@ -151,6 +152,7 @@ def load_library(path: Optional[str] = None):
     L.zl_test_circuit_tweak.argtypes = [vp]
     L.zl_test_fq_mul_rate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.zl_test_fr28_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
+    L.zl_test_fr29_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, u32p, C.c_size_t, u32p]
     L.zl_test_poseidon_permute_dev28r.argtypes = [vp, C.c_int, u64p]
     L.zl_test_fq_mul_clock.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.zl_test_acc_clock.argtypes = [vp, C.c_int]
@@ -406,13 +408,19 @@ class MultiBackend:
 
 
 # ---- test-only hooks (include/zl_backend_test.h): device Poseidon KAT, raw-limb field / point access ---------------------------------
-TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op",
+TEST_ABI_SYMBOLS = ["zl_test_poseidon_permute_dev", "zl_test_fp28_op", "zl_test_fp28_bn_op", "zl_test_pairing_product", "zl_test_point_op", "zl_test_circuit_tweak", "zl_test_fq_mul_rate", "zl_test_fr28_op", "zl_test_fr29_op",
                     "zl_test_poseidon_permute_dev28r", "zl_test_fq_mul_clock", "zl_test_acc_clock", "zl_test_acc_clock_read", "zl_test_clock_probe_launch", "zl_test_clock_probe_read"]
 
 
 def _p32(a: np.ndarray):
     assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def groth16_keys_parse(curve: int, data: bytes, check: bool = False) -> int:
+    """host-only validation of ProvingContext bytes (zl_groth16_keys_parse): the C error code (0 = acceptable framing)"""
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    return int(load_library().zl_groth16_keys_parse(curve, buf, len(data), ZL_CHECK if check else 0))
 
 
 def hook_poseidon_permute_dev(be: "Backend", curve: int, state: np.ndarray) -> np.ndarray:
@@ -467,15 +475,17 @@ def hook_point_op(be: Optional["Backend"], group: int, hot: bool, op: int, pq: n
     return out
 
 
-def hook_fr28_op(be: Optional["Backend"], curve: int, op: int, ab: np.ndarray, j: int = 2) -> np.ndarray:
-    """ab: (n, 2, 8) uint32 words of two values < 2^256 -> (n, 8) canonical result words; be = None runs the host code path"""
+def hook_fr28_op(be: Optional["Backend"], curve: int, op: int, ab: np.ndarray, j: int = 2, bits: int = 28) -> np.ndarray:
+    """ab: (n, 2, 8) uint32 words of two values < 2^256 -> (n, 8) canonical result words; be = None runs the host code path;
+    bits = 28: the 10 x 28-bit instance (R' = 2^280), 29: the 9 x 29-bit instance (R' = 2^261)"""
     a = np.ascontiguousarray(ab, dtype=np.uint32)
     n = a.shape[0]
     out = np.zeros((n, 8), dtype=np.uint32)
     L = load_library()
-    rc = L.zl_test_fr28_op(be._ctx if be is not None else None, curve, op, j, _p32(a), n, _p32(out))
+    fn = L.zl_test_fr28_op if bits == 28 else L.zl_test_fr29_op
+    rc = fn(be._ctx if be is not None else None, curve, op, j, _p32(a), n, _p32(out))
     if rc:
-        raise BackendError(rc, "zl_test_fr28_op")
+        raise BackendError(rc, "zl_test_fr28_op" if bits == 28 else "zl_test_fr29_op")
     return out
 
 

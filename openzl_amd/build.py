@@ -129,7 +129,7 @@ def build(verbose: bool = True, jobs: int | None = None) -> str:
         subprocess.check_call([sys.executable, gen])
     # the generated product scans (committed, like zl_params.h): regenerate when their generator is newer, so that an edit of gen_mul*.py can never
     # leave a stale header behind; the object digests then see the new text
-    for g, outs in (("gen_mul28.py", ("zl_mul28_gfx950.h", "zl_mul28r_gfx950.h")), ("gen_mul.py", ("zl_mul_gfx950.h",))):
+    for g, outs in (("gen_mul28.py", ("zl_mul28_gfx950.h", "zl_mul28r_gfx950.h", "zl_mul29r_gfx950.h")), ("gen_mul.py", ("zl_mul_gfx950.h",))):
         gp = os.path.join(CSRC, g)
         if os.path.exists(gp) and any(not os.path.exists(os.path.join(CSRC, o)) or os.path.getmtime(os.path.join(CSRC, o)) < os.path.getmtime(gp) for o in outs):
             subprocess.check_call([sys.executable, gp], stdout=subprocess.DEVNULL)

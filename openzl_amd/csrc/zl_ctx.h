@@ -114,6 +114,7 @@ struct zl_twiddles {
     void* d_lo = nullptr;  // w^i, i < 2^lo_bits
     void* d_hi = nullptr;  // w^(i << lo_bits)
     void* d_small = nullptr;  // per-radix tables
+    void* d_small_limbs = nullptr;  // the per-radix tables as limbs (ZL_TUNE_NTT_ROOTS_GLOBAL experiment)
     void* d_last = nullptr;   // combined inter-factor twiddles of the last pass, one per element (multi-pass sizes, built on first use)
     void* d_row[4] = {nullptr, nullptr, nullptr, nullptr};  // per-row twiddles of a MIDDLE pass (index: pass - 1), one row per value of the tile's high index; lazy passes only
     size_t last_bytes = 0;    // ... its size, and when it was last used: the tables of one ctx share a byte budget (ZL_TUNE_NTT_LAST_MB), least recently used first out

@@ -445,7 +445,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
                                                                                                                    unsigned flags) {
     using C = typename CodecOf<E>::type;
     Result<std::pair<ProvingContext, VerifyingContext>> res{false, {}, Error{ZL_EINVAL}};
-    if (!ctx || !in) return res;
+    if (!in) return res;  // ctx == nullptr: PARSE ONLY (zl_groth16_keys_parse) -- every byte is read and validated exactly as below, nothing goes to a device
     const size_t q1 = 2 * E::G1::FQ64, q2 = 2 * q1;
     const bool check = (flags & ZL_CHECK) != 0;
     size_t pos = 0;
@@ -511,7 +511,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
             }
         });
         if ((rc = bad.load())) break;
-        rc = zl_bases_upload(ctx, E::curve, g2 ? ZL_G2 : ZL_G1, xy.data(), n, 0, -1, ZL_CANON | (check ? ZL_CHECK : 0u), handle[k]);
+        if (ctx) rc = zl_bases_upload(ctx, E::curve, g2 ? ZL_G2 : ZL_G1, xy.data(), n, 0, -1, ZL_CANON | (check ? ZL_CHECK : 0u), handle[k]);
     }
     if (!rc && pos != len) rc = ZL_EINVAL;  // trailing bytes
     // shape: a, b1, b2 cover every variable; h has N - 1 entries for a power-of-two domain N >= 2; l covers the witnesses
@@ -522,7 +522,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         pc.n_witness = nv - ni;
         pc.domain_size = N;
     }
-    if (!rc) rc = build_window_tables(pc);
+    if (!rc && ctx) rc = build_window_tables(pc);
     if (rc) {
         release(pc);
         res.value = {};
@@ -839,6 +839,18 @@ int zl_groth16_keys_from_bytes(zl_ctx* ctx, zl_curve_t curve, const uint8_t* in,
     if (rc) { delete k; return rc; }
     *out = k;
     return ZL_OK;
+}
+// host-only validation of the same bytes (no ctx, no device): framing, lengths, canonical coordinates, flags; with ZL_CHECK the verifying-key points are also
+// checked for curve / subgroup membership (the queries' curve checks happen on the device at upload).  What a service runs on untrusted input before it
+// spends device memory on it, and the fuzz target of the sanitizer build (tests/test_sanitizers.py).
+int zl_groth16_keys_parse(zl_curve_t curve, const uint8_t* in, size_t len, unsigned flags) {
+    if (!in || (curve != ZL_BLS12_381 && curve != ZL_BN254) || (flags & ~ZL_CHECK)) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) {
+        auto r = Groth16<Bls12_381>::decode(nullptr, in, len, flags);
+        return r.ok ? ZL_OK : r.error.code;
+    }
+    auto r = Groth16<Bn254>::decode(nullptr, in, len, flags);
+    return r.ok ? ZL_OK : r.error.code;
 }
 int zl_groth16_vk_to_bytes(const zl_g16_keys* k, uint8_t* out, size_t cap, size_t* len) {
     if (!k || !len || (!out && cap)) return ZL_EINVAL;

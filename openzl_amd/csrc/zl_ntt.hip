@@ -38,6 +38,7 @@ struct NttArgs {
     uint32_t pre_coset, post_scale, post_coset, to_mont, from_mont;
     const void *t_lo, *t_hi;  // w^lo, w^(hi << L)
     const void* w_small;      // w_(2^s)^i, i < 2^(s-1)
+    const void* w_unpacked;   // lazy passes, optional (ZL_TUNE_NTT_ROOTS_GLOBAL=1): the same roots as limbs (4 L bytes each), read from global memory instead of LDS
     const void *g_lo, *g_hi;  // coset powers (hi table carries n^-1 for the inverse)
     const void* row_tw;       // middle pass (lazy form): w_N^((r K0(hi)) << shift) for every (hi, r), hi = the tile's high index (or null: combined per tile)
     const void* last_tw;      // last pass of a multi-pass transform: the complete inter-factor twiddle of every element, in load order (or null)
@@ -275,11 +276,28 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_pass(const Fp<FrP>* __re
 // Bounds: two-stage round r of a pass enters with every element below B_r r; its subtractions use K1 = 2^j r >= (B_r + 2) r (first stage; also the
 // second stage's a2 - a3, whose subtrahend is a product < 2r) and K2 >= (2 B_r + 2) r (second stage's a0 - a1); B_(r+1) = max(4 B_r, B_r + K1 + 4, 2 B_r + K2)
 // <= 6 B_r + 7: five rounds from B = 6 stay below 2^16 (the multiplier takes 2^25, the top limb 2^29).  The host simulates this and passes the biases.
+#ifndef NTT28_TILE_LOG
+#define NTT28_TILE_LOG 10  // elements per tile of the lazy passes (A/B: -DNTT28_TILE_LOG=11 -DNTT28_THREADS=512: two 77-KB workgroups per CU, 288-byte row segments)
+#endif
+#ifndef NTT28_THREADS
 #define NTT28_THREADS 256
-#define NTT28_TILE 1024
+#endif
+#define NTT28_TILE (1u << NTT28_TILE_LOG)
+// Round 5: the passes multiply on NINE limbs of 29 bits (R' = 2^261: 162 + 9 mads per product instead of 200 + 10, nine-limb additions, 36-byte LDS elements).
+// Six spare bits instead of 25: mul takes B(a) B(b) <= 70 (BLS12-381) / 169 (BN254), so the bound plan below does not apply -- every two-stage round enters with
+// all elements below 6r, uses the CONSTANT biases K1 = 8r, K2 = 16r, K3 = 4r, and weakly reduces (wred, ~30 instructions) the outputs no multiplication touched:
+// x0' = a0 + a1 (always) and, where the twiddle index is 0, x1', x2', x3' as well.  Every product operand then stays below 2 * 6 + 16 = 28 (static_assert below),
+// every wred input below 28 < 128.  -DZL_NTT_FR28 keeps round 4's 10 x 28-bit instance (A/B).
 template <class FrP> struct Fr28Of;
+#ifdef ZL_NTT_FR28
 template <> struct Fr28Of<BLS12_381_Fr> { using type = BLS12_381_Fr28; };
 template <> struct Fr28Of<BN254_Fr> { using type = BN254_Fr28; };
+#else
+template <> struct Fr28Of<BLS12_381_Fr> { using type = BLS12_381_Fr29; };
+template <> struct Fr28Of<BN254_Fr> { using type = BN254_Fr29; };
+#endif
+template <class P28> struct NttTight { static constexpr bool value = P28::MUL_BOUND < 1024; };  // few spare bits: constant biases + a weak reduction per round
+static_assert(BLS12_381_Fr29::MUL_BOUND >= 28 && BN254_Fr29::MUL_BOUND >= 28 && BLS12_381_Fr29::KQ_MAX >= 4, "tight rounds: product operands reach 2 * 6 + 16 = 28 r");
 // bias exponents per two-stage round of a pass (round 0 enters with B = 6: a caller's canonical-or-not 256-bit input is below 5.3 r, a product below 2 r)
 struct Ntt28Plan {
     int j1[6], j2[6];              // K1 = 2^j1 r >= (B + 2) r, K2 = 2^j2 r >= (2 B + 2) r; the single last stage of an odd s uses K1 of its round index
@@ -311,21 +329,21 @@ constexpr bool ntt28_plan_is_linear() {
 }
 static_assert(ntt28_plan_is_linear(), "k_ntt_pass28 computes j1 = 3 + 2 r, j2 = 4 + 2 r");
 template <class P28>
-__device__ __forceinline__ void load_bias28(uint32_t (&K)[10], int j) {  // uniform: constant-memory lookups
+__device__ __forceinline__ void load_bias28(uint32_t (&K)[P28::L], int j) {  // uniform: constant-memory lookups
 #pragma unroll
-    for (int i = 0; i < 10; i++) K[i] = P28::kq(j, i);
+    for (int i = 0; i < P28::L; i++) K[i] = P28::kq(j, i);
 }
 template <class E>
 __device__ __forceinline__ E lds_load28(const uint32_t* sh, uint32_t pos) {
     E r;
 #pragma unroll
-    for (int k = 0; k < 10; k++) r.l[k] = sh[k * NTT28_TILE + pos];
+    for (int k = 0; k < E::L; k++) r.l[k] = sh[k * NTT28_TILE + pos];
     return r;
 }
 template <class E>
 __device__ __forceinline__ void lds_store28(uint32_t* sh, uint32_t pos, const E& v) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) sh[k * NTT28_TILE + pos] = v.l[k];
+    for (int k = 0; k < E::L; k++) sh[k * NTT28_TILE + pos] = v.l[k];
 }
 template <class P28>
 __device__ __forceinline__ Fr28<P28> load28(const void* __restrict__ base, uint64_t idx) {  // one 32-byte element -> 10 limbs
@@ -336,23 +354,37 @@ __device__ __forceinline__ Fr28<P28> load28(const void* __restrict__ base, uint6
 }
 // the scratch vector between two lazy passes holds the ten limbs as they are (40 bytes per element, carried, bound as the pass left it): no weak
 // reduction, no packing on the way out and no unpacking on the way in (90 instructions per element and pass boundary)
+// (round 5: nine-limb elements take 36-byte slots -- 10 % less traffic between passes; a slot is only 4-byte aligned, so it moves as nine dwords)
+template <class P28> struct ScratchBytes { static constexpr size_t value = (size_t)4 * P28::L; };
 template <class P28>
 __device__ __forceinline__ Fr28<P28> load40(const void* __restrict__ base, uint64_t idx) {
-    const uint2* p = reinterpret_cast<const uint2*>(base) + 5 * idx;
     Fr28<P28> r;
+    if constexpr (P28::L & 1) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + (size_t)P28::L * idx;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint2 v = p[k];
-        r.l[2 * k] = v.x;
-        r.l[2 * k + 1] = v.y;
+        for (int k = 0; k < P28::L; k++) r.l[k] = p[k];
+    } else {
+        const uint2* p = reinterpret_cast<const uint2*>(base) + (P28::L / 2) * idx;
+#pragma unroll
+        for (int k = 0; k < P28::L / 2; k++) {
+            const uint2 v = p[k];
+            r.l[2 * k] = v.x;
+            r.l[2 * k + 1] = v.y;
+        }
     }
     return r;
 }
 template <class P28>
 __device__ __forceinline__ void store40(void* __restrict__ base, uint64_t idx, const Fr28<P28>& x) {
-    uint2* p = reinterpret_cast<uint2*>(base) + 5 * idx;
+    if constexpr (P28::L & 1) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(base) + (size_t)P28::L * idx;
 #pragma unroll
-    for (int k = 0; k < 5; k++) p[k] = make_uint2(x.l[2 * k], x.l[2 * k + 1]);
+        for (int k = 0; k < P28::L; k++) p[k] = x.l[k];
+    } else {
+        uint2* p = reinterpret_cast<uint2*>(base) + (P28::L / 2) * idx;
+#pragma unroll
+        for (int k = 0; k < P28::L / 2; k++) p[k] = make_uint2(x.l[2 * k], x.l[2 * k + 1]);
+    }
 }
 template <class P28>
 __device__ __forceinline__ Fr28<P28> twiddle2_28(const void* lo, const void* hi, uint32_t L, uint64_t e) {
@@ -371,11 +403,12 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
     using P28 = typename Fr28Of<FrP>::type;
     using E = Fr28<P28>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                          // [10][NTT28_TILE]
+    uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                          // [L][NTT28_TILE]
     const uint32_t tid = threadIdx.x;
     const uint32_t s = a.s, logC = a.logC, R = 1u << s, C = 1u << logC;
-    E* sh_w = reinterpret_cast<E*>(smem + (size_t)10 * 4 * NTT28_TILE);         // [2^(s-1)] butterfly roots
-    E* sh_row = sh_w + (R >> 1);                                                // [2^s] per-row twiddles (middle passes without a row table)
+    E* sh_w = reinterpret_cast<E*>(smem + (size_t)E::L * 4 * NTT28_TILE);       // [2^(s-1)] butterfly roots
+    constexpr bool TIGHT = NttTight<P28>::value;
+    E* sh_row = sh_w + (a.w_unpacked ? 0u : (R >> 1));                          // [2^s] per-row twiddles (middle passes without a row table)
     const uint32_t n_log = a.n_log;
 
     // ---- tile addressing (as k_ntt_pass) --------------------------------------------------------------------
@@ -426,7 +459,8 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
     }
     // ---- stage the small tables (unpacked once per tile) ----------------------------------------------------
     {
-        for (uint32_t i = tid; i < (R >> 1); i += NTT28_THREADS) sh_w[i] = load28<P28>(a.w_small, i);
+        if (!a.w_unpacked)
+            for (uint32_t i = tid; i < (R >> 1); i += NTT28_THREADS) sh_w[i] = load28<P28>(a.w_small, i);
         if (!LAST && a.p > 1) {
             // the row twiddles depend on the tile's high index only: tabulated once per (size, direction) (k_ntt_row_table28) -- a tile of 1024 elements
             // would otherwise pay 2^s products for them (measured: the middle pass of 2^24 0.92 ms against 0.85 for the 32-bit kernel's 2048-element tiles)
@@ -477,27 +511,41 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
         q[0] = make_uint4(w[0], w[1], w[2], w[3]);
         q[1] = make_uint4(w[4], w[5], w[6], w[7]);
     };
-    uint32_t K1[10], K2[10], K3[10];
-    load_bias28<P28>(K3, 2);  // 4 r: a2 - a3 (a3 is always a product, < 2r)
+    // butterfly roots: from LDS (staged above), or -- experiment -- straight from a limb-form table in global memory (cache-resident: 2^(s-1) x 36 B), which
+    // frees 4.6 KB of LDS per workgroup: 36.9 KB instead of 41.5, i.e. four workgroups per CU instead of three
+    const E* w_glob = reinterpret_cast<const E*>(a.w_unpacked);
+    auto root = [&](uint32_t i) -> E { return w_glob ? w_glob[i] : sh_w[i]; };
+    uint32_t K1[E::L], K2[E::L], K3[E::L];
+    load_bias28<P28>(K3, 2);  // 4 r: a2 - a3 (a3 is always a product, < 2r; a2 a product or, at k2 = 0 in a tight round, below 6 + 8 -- then nothing multiplies the difference)
+    if (TIGHT) {              // constant biases: every round enters below 6 r
+        load_bias28<P28>(K1, 3);
+        load_bias28<P28>(K2, 4);
+    }
     auto quad = [&](E& x0, E& x1, E& x2, E& x3, uint32_t k2, uint32_t hl) {
         const uint32_t h2 = 1u << hl, sh1 = s - 2 - hl;
         // carry passes only where a value becomes a subtrahend or goes back to LDS (3 per quad instead of 8): everything else feeds a product or the
         // minuend side of a biased subtraction with fat limbs (< 2^31; zl_field28r.h)
         const E a0 = zl::add_nc(x0, x2), a1 = zl::add(x1, x3);
         E a2 = zl::subk_nc(x0, x2, K1);
-        if (k2 != 0) a2 = zl::mul(a2, sh_w[k2 << sh1]);
-        const E a3 = zl::mul(zl::subk_nc(x1, x3, K1), sh_w[(k2 + h2) << sh1]);
+        if (k2 != 0) a2 = zl::mul(a2, root(k2 << sh1));
+        const E a3 = zl::mul(zl::subk_nc(x1, x3, K1), root((k2 + h2) << sh1));
         x0 = zl::add(a0, a1);
         x2 = zl::add(a2, a3);
         x1 = zl::subk_nc(a0, a1, K2);
         x3 = zl::subk_nc(a2, a3, K3);
+        if (TIGHT) x0 = zl::wred(x0);  // 4 B <= 24 -> < 2r: the one output of a quad that no product ever touches
         if (k2 != 0) {
-            const E w = sh_w[k2 << (sh1 + 1)];
+            const E w = root(k2 << (sh1 + 1));
             x1 = zl::mul(x1, w);
             x3 = zl::mul(x3, w);
         } else {
             zl::carry28r(x1);
             zl::carry28r(x3);
+            if (TIGHT) {  // trivial twiddles: B + 8 + 2, 2 B + 16, B + 8 + 4 <= 28 -> < 2r
+                x1 = zl::wred(x1);
+                x2 = zl::wred(x2);
+                x3 = zl::wred(x3);
+            }
         }
     };
     for (uint32_t idx = tid; idx < R * C; idx += NTT28_THREADS) {
@@ -509,8 +557,10 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
     while (hl >= 2u) {
         hl -= 2;
         const uint32_t h2 = 1u << hl, h = h2 << 1;
-        load_bias28<P28>(K1, 3 + 2 * (int)rd);
-        load_bias28<P28>(K2, 4 + 2 * (int)rd);
+        if (!TIGHT) {
+            load_bias28<P28>(K1, 3 + 2 * (int)rd);
+            load_bias28<P28>(K2, 4 + 2 * (int)rd);
+        }
         rd++;
         for (uint32_t q = tid; q < (R >> 2) * C; q += NTT28_THREADS) {
             const uint32_t col = q & (C - 1), rr = q >> logC;
@@ -527,8 +577,8 @@ __global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* 
         }
         __syncthreads();
     }
-    if (hl == 1) {  // odd s: the last stage (distance 1) on its own
-        load_bias28<P28>(K1, 3 + 2 * (int)rd);
+    if (hl == 1) {  // odd s: the last stage (distance 1) on its own (tight: enters below 4 r, leaves below 4 + 8)
+        if (!TIGHT) load_bias28<P28>(K1, 3 + 2 * (int)rd);
         for (uint32_t q = tid; q < (R >> 1) * C; q += NTT28_THREADS) {
             const uint32_t col = q & (C - 1), rr = q >> logC;
             const uint32_t i = rr << 1;
@@ -556,6 +606,16 @@ __global__ void __launch_bounds__(256) k_ntt_to_lazy(Fp<FrP>* __restrict__ table
 #pragma unroll
     for (int k = 0; k < F::N; k++) rp.l[k] = P28::rp(k);
     table[i] = zl::mul(table[i], rp);  // (x R)(R') / R = x R', reduced below r
+}
+// table[i] (32-byte canonical words) -> its limbs (4 L bytes), for the passes that read butterfly roots from global memory
+template <class FrP>
+__global__ void __launch_bounds__(256) k_ntt_unpack_table28(const Fp<FrP>* __restrict__ table, uint32_t* __restrict__ out, uint32_t count) {
+    using P28 = typename Fr28Of<FrP>::type;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Fr28<P28> e = load28<P28>(table, i);
+#pragma unroll
+    for (int k = 0; k < P28::L; k++) out[(size_t)P28::L * i + k] = e.l[k];
 }
 // the combined twiddles of the last pass (k_ntt_last_table) in the lazy multiplier's form
 template <class FrP>
@@ -737,6 +797,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     }
     // Round 4: the passes run on lazily reduced 28-bit limbs (k_ntt_pass28) unless ZL_NTT_NO_LAZY is set (developer A/B switch; the 32-bit passes stay)
     static const bool lazy = getenv("ZL_NTT_NO_LAZY") == nullptr;
+    static const bool roots_global = zl_tune("ZL_TUNE_NTT_ROOTS_GLOBAL", 1) != 0;  // round 5: on (2^24: 2.16 -> 2.13 ms, profiles/r05_ntt_fr29_ab2.log)
     zl_twiddles* tw;
     int rc;
     if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw, lazy))) return rc;
@@ -746,7 +807,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     F* scratch = nullptr;
     if (pl.P > 1) {
         void* p;
-        if ((rc = zl_scratch_get(ctx, 6, N * (lazy ? (size_t)40 : sizeof(F)), &p))) return rc;  // lazy passes: ten limbs per element between passes
+        if ((rc = zl_scratch_get(ctx, 6, N * (lazy ? ScratchBytes<typename Fr28Of<FrP>::type>::value : sizeof(F)), &p))) return rc;  // lazy passes: the limbs as they are between passes
         scratch = reinterpret_cast<F*>(p);
     }
     const unsigned L = tw->lo_bits;
@@ -804,6 +865,20 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         a.g_lo = g_lo;
         a.g_hi = g_hi;
         a.w_small = small + ((size_t)1 << (a.s ? a.s - 1 : 0));
+        a.w_unpacked = nullptr;
+        if (lazy && roots_global) {
+            using P28u = typename Fr28Of<FrP>::type;
+            if (!tw->d_small_limbs) {
+                void* t = nullptr;
+                if (hipMalloc(&t, (size_t)4 * P28u::L << NTT_MAX_S) == hipSuccess) {
+                    hipLaunchKernelGGL((k_ntt_unpack_table28<FrP>), dim3((1u << NTT_MAX_S) / 256), dim3(256), 0, st, small, (uint32_t*)t, 1u << NTT_MAX_S);
+                    tw->d_small_limbs = t;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (tw->d_small_limbs) a.w_unpacked = reinterpret_cast<const uint32_t*>(tw->d_small_limbs) + (size_t)P28u::L * ((size_t)1 << (a.s ? a.s - 1 : 0));
+        }
         a.to_mont = (p == 1 && !mont_in) ? 1 : 0;
         if (lazy) a.to_mont = (p == 1 && !mont_in && mont_out) ? 1 : 0;  // the data keeps its form: a conversion only when the caller asks for one
         a.pre_coset = (p == 1 && coset && !inverse) ? 1 : 0;
@@ -862,7 +937,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         if (pl.P == 1) cols_avail_log = 0;
         else if (!last) cols_avail_log = n - S_prev - a.s;
         else cols_avail_log = pl.sizes[0];
-        uint32_t logC = (lazy ? 10 : 11) - a.s;  // NTT_TILE = 2^11, NTT28_TILE = 2^10
+        uint32_t logC = (lazy ? (uint32_t)NTT28_TILE_LOG : 11u) - a.s;  // NTT_TILE = 2^11, NTT28_TILE = 2^NTT28_TILE_LOG
         if (a.s > 10) return ZL_EINVAL;
         if (logC > cols_avail_log) logC = cols_avail_log;
         a.logC = logC;
@@ -871,7 +946,8 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         F* dst = last ? data : scratch;
         if (lazy) {
             // tile + butterfly roots (+ the per-row twiddles of a middle pass that has no row table): 45 KB at s = 8 -> three workgroups per CU
-            const size_t lds28 = (size_t)10 * 4 * NTT28_TILE + (size_t)40 * (((size_t)1 << a.s) / 2 + ((!last && p > 1 && !a.row_tw) ? ((size_t)1 << a.s) : 0));
+            using E28 = Fr28<typename Fr28Of<FrP>::type>;
+            const size_t lds28 = (size_t)E28::L * 4 * NTT28_TILE + sizeof(E28) * ((a.w_unpacked ? 0 : ((size_t)1 << a.s) / 2) + ((!last && p > 1 && !a.row_tw) ? ((size_t)1 << a.s) : 0));
             if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
             else hipLaunchKernelGGL((k_ntt_pass28<FrP, false>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
         } else {
@@ -1050,6 +1126,7 @@ void zl_ntt_free(zl_ctx* ctx) {
         if (kv.second.d_lo) (void)hipFree(kv.second.d_lo);
         if (kv.second.d_last) (void)hipFree(kv.second.d_last);
         for (void* r : kv.second.d_row) if (r) (void)hipFree(r);
+        if (kv.second.d_small_limbs) (void)hipFree(kv.second.d_small_limbs);
     }
     ctx->twiddles.clear();
     ctx->ntt_last_bytes = 0;

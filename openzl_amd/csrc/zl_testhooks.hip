@@ -226,8 +226,8 @@ template <class P>
 ZL_HD static void fr28_op(int op, int j, const uint32_t* in, uint32_t* out) {
     using E = Fr28<P>;
     const E a = zl::unpack28r<P>(in), b = zl::unpack28r<P>(in + 8);
-    uint32_t K[10];
-    for (int i = 0; i < 10; i++) K[i] = P::kq(j, i);
+    uint32_t K[P::L];
+    for (int i = 0; i < P::L; i++) K[i] = P::kq(j, i);
     E r = a;
     switch (op) {
     case 0: r = zl::canon(zl::mul(a, b)); break;
@@ -240,10 +240,12 @@ ZL_HD static void fr28_op(int op, int j, const uint32_t* in, uint32_t* out) {
         for (int k = 0; k < 4; k++) {
             const E u = zl::add(x, x), v = zl::subk(x, bb, K);
             x = zl::add(u, v);
+            if (P::MUL_BOUND < 1024) x = zl::wred(x);  // the 29-bit instance: 3 x + 2^j r stays below 128 r, the weak reduction brings it back below 2 r (as the passes do every round)
         }
         r = zl::canon(zl::mul(x, b));
         break;
     }
+    case 5: r = zl::canon(zl::wred(zl::add(zl::add(a, a), zl::add(b, b)))); break;  // wred at the top of its range: 2a + 2b < 2^258
     default: break;
     }
     zl::pack28r<P>(out, r);
@@ -253,6 +255,26 @@ static __global__ void __launch_bounds__(64) k_test_fr28(int op, int j, const ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fr28_op<P>(op, j, in + (size_t)i * 16, out + (size_t)i * 8);
+}
+
+template <class PBls, class PBn>
+static int test_fr_lazy_op_t(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out) {
+    if ((!in || !out) && n) return ZL_EINVAL;
+    if (op < 0 || op > 5 || j < 0 || j > PBls::KQ_MAX || n >= (1u << 24) || (curve != ZL_BLS12_381 && curve != ZL_BN254)) return ZL_EINVAL;
+    if (!n) return ZL_OK;
+    if (!ctx) {
+        for (size_t i = 0; i < n; i++) {
+            if (curve == ZL_BLS12_381) fr28_op<PBls>(op, j, in + i * 16, out + i * 8);
+            else fr28_op<PBn>(op, j, in + i * 16, out + i * 8);
+        }
+        return ZL_OK;
+    }
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return run_dev(ctx, in, n * 16, out, n * 8, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
+        const dim3 grid((uint32_t)((n + 63) / 64)), block(64);
+        if (curve == ZL_BLS12_381) hipLaunchKernelGGL((k_test_fr28<PBls>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
+        else hipLaunchKernelGGL((k_test_fr28<PBn>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
+    });
 }
 
 template <class F> struct RawIO;
@@ -416,21 +438,10 @@ int zl_test_point_op(zl_ctx* ctx, zl_group_t group, int hot, int op, const uint3
 
 int zl_test_fr28_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out) {
     if ((!in || !out) && n) return ZL_EINVAL;
-    if (op < 0 || op > 4 || j < 0 || j > 20 || n >= (1u << 24) || (curve != ZL_BLS12_381 && curve != ZL_BN254)) return ZL_EINVAL;
-    if (!n) return ZL_OK;
-    if (!ctx) {
-        for (size_t i = 0; i < n; i++) {
-            if (curve == ZL_BLS12_381) fr28_op<BLS12_381_Fr28>(op, j, in + i * 16, out + i * 8);
-            else fr28_op<BN254_Fr28>(op, j, in + i * 16, out + i * 8);
-        }
-        return ZL_OK;
-    }
-    ZL_HIP(ctx, hipSetDevice(ctx->device));
-    return run_dev(ctx, in, n * 16, out, n * 8, [&](const uint32_t* d_in, uint32_t* d_out, hipStream_t st) {
-        const dim3 grid((uint32_t)((n + 63) / 64)), block(64);
-        if (curve == ZL_BLS12_381) hipLaunchKernelGGL((k_test_fr28<BLS12_381_Fr28>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
-        else hipLaunchKernelGGL((k_test_fr28<BN254_Fr28>), grid, block, 0, st, op, j, d_in, (uint32_t)n, d_out);
-    });
+    return test_fr_lazy_op_t<BLS12_381_Fr28, BN254_Fr28>(ctx, curve, op, j, in, n, out);
+}
+int zl_test_fr29_op(zl_ctx* ctx, zl_curve_t curve, int op, int j, const uint32_t* in, size_t n, uint32_t* out) {
+    return test_fr_lazy_op_t<BLS12_381_Fr29, BN254_Fr29>(ctx, curve, op, j, in, n, out);
 }
 
 int zl_test_fq_mul_rate(zl_ctx* ctx, int waves_per_simd, int iters, double* g_products_per_s) {

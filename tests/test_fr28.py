@@ -32,22 +32,26 @@ def _cases(r, rng, n):
     return vals
 
 
-def _check(be, curve):
+def _check(be, curve, bits=28):
     r = R[curve]
-    rng = random.Random(28 + curve)
+    rng = random.Random(bits + curve)
     vals = _cases(r, rng, 400)
+    if bits == 29:  # limb boundaries of the nine 29-bit limbs
+        edge29 = [(1 << 29) - 1, 1 << 29, sum(0x1FFFFFFF << (29 * i) for i in range(8)), (1 << 232) - 1, 1 << 232]
+        vals += [(a, b) for a in edge29 for b in edge29 + [r - 1, (1 << 256) - 1]]
     w = _words(vals)
-    rp_inv = pow(1 << 280, -1, r)
-    got = _ints(hook_fr28_op(be, curve, 0, w))
-    assert got == [a * b * rp_inv % r for a, b in vals]
-    assert _ints(hook_fr28_op(be, curve, 1, w)) == [(a + b) % r for a, b in vals]
-    assert _ints(hook_fr28_op(be, curve, 3, w)) == [a % r for a, _ in vals]
-    for j in (2, 3, 7, 12, 20):  # b < 2^256 < 2.3 r (BLS12-381) / 5.3 r (BN254): j >= 2 resp. 3 covers it
+    rp_inv = pow(1 << (280 if bits == 28 else 261), -1, r)
+    op = lambda o, **kw: _ints(hook_fr28_op(be, curve, o, w, bits=bits, **kw))  # noqa: E731
+    assert op(0) == [a * b * rp_inv % r for a, b in vals]
+    assert op(1) == [(a + b) % r for a, b in vals]
+    assert op(3) == [a % r for a, _ in vals]
+    assert op(5) == [(2 * a + 2 * b) % r for a, b in vals]  # the weak reduction at the top of its range (2a + 2b < 2^258)
+    for j in ((2, 3, 7, 12, 20) if bits == 28 else (2, 3, 5, 6)):  # b < 2^256 < 2.3 r (BLS12-381) / 5.3 r (BN254): j >= 2 resp. 3 covers it
         if (1 << j) < (1 << 256) // r + 2:
             continue
-        assert _ints(hook_fr28_op(be, curve, 2, w, j=j)) == [(a - b) % r for a, b in vals], j
-    # the lazy chain: x <- 2x + (x - b^2 R'^-1 + 2^j r) four times (bound 3^4 * B(a) + ...), then one product
-    for j in (2, 5, 11):
+        assert op(2, j=j) == [(a - b) % r for a, b in vals], j
+    # the lazy chain: x <- 2x + (x - b^2 R'^-1 + 2^j r) four times (28 bits: bound 3^4 * B(a) + ...; 29 bits: weakly reduced after every step), then one product
+    for j in ((2, 5, 11) if bits == 28 else (2, 4, 5)):
         exp = []
         for a, b in vals:
             bb = b * b * rp_inv % r
@@ -55,7 +59,7 @@ def _check(be, curve):
             for _ in range(4):
                 x = 3 * x - bb
             exp.append(x * b * rp_inv % r)
-        assert _ints(hook_fr28_op(be, curve, 4, w, j=j)) == exp, j
+        assert op(4, j=j) == exp, j
 
 
 @pytest.mark.parametrize("curve", [ZL_BLS12_381, ZL_BN254], ids=["bls12_381", "bn254"])
@@ -63,7 +67,18 @@ def test_fr28_host(curve):
     _check(None, curve)
 
 
+@pytest.mark.parametrize("curve", [ZL_BLS12_381, ZL_BN254], ids=["bls12_381", "bn254"])
+def test_fr29_host(curve):
+    _check(None, curve, bits=29)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", [ZL_BLS12_381, ZL_BN254], ids=["bls12_381", "bn254"])
 def test_fr28_device(backend, curve):
     _check(backend, curve)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [ZL_BLS12_381, ZL_BN254], ids=["bls12_381", "bn254"])
+def test_fr29_device(backend, curve):
+    _check(backend, curve, bits=29)

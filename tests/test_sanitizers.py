@@ -4,13 +4,14 @@ SURVEY.md §5: the reference runs its tests under sanitizers in CI).
   * `python -m openzl_amd.build --host-asan`: the HOST half of zl_host.hip (zl_serialize.h: zl_groth16_keys_from_bytes / zl_point_from_bytes*, zl_pairing.h, the
     R1CS / Poseidon / Groth16 mirror) and zl_capi.hip with -fsanitize=address,undefined -fno-sanitize-recover=all -> libzl_backend.asan.so;
   * `make -C oracle asan`: the C oracle the same way (it is the checker: a silent overflow there would void parity claims).
+No GPU-side variant: the ROCm compiler-rt intercepts hsa_amd_memory_pool_allocate for device-side ASan, and without that mode every HIP allocation of a process
+with the runtime preloaded fails ("AddressSanitizer: out of memory" inside libamdhip64, seen on the MI355X box in round 5).  The decoder of untrusted key bytes is
+therefore fuzzed through its host-only entry (zl_groth16_keys_parse: the same parser with the uploads skipped; tests/test_serialize.py), which runs here.
 Each test re-runs existing test files in a subprocess with the sanitized library selected (ZL_BACKEND_LIB / ZL_ORACLE_LIB) and the matching runtime
 preloaded; a sanitizer report aborts the subprocess, and its text is searched for as well."""
 import os
 import subprocess
 import sys
-
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAD = ("ERROR: AddressSanitizer", "runtime error:", "SUMMARY: UndefinedBehaviorSanitizer", "SUMMARY: AddressSanitizer")
@@ -49,9 +50,3 @@ def test_oracle_under_asan_ubsan():
     rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
     assert os.path.isabs(rt), "gcc has no libasan.so"
     _run({"ZL_ORACLE_LIB": os.path.join(ROOT, "oracle", "libzl_oracle_asan.so"), "LD_PRELOAD": rt}, ["test_oracle.py", "test_golden_vectors.py"], "not gpu")
-
-
-@pytest.mark.gpu
-def test_key_wire_corruption_fuzz_under_asan_ubsan():
-    """the decoder of untrusted key bytes (zl_groth16_keys_from_bytes) fed truncated / bit-flipped / length-lying inputs, and the byte-identical proof from a decoded key, on the GPU box"""
-    _run(_backend_asan(), ["test_gpu_key_wire.py", "test_serialize.py", "test_pairing_verify.py"], "gpu or not gpu", timeout=1500)

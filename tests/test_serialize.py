@@ -172,3 +172,81 @@ def test_uncompressed_malformed_and_checked(curve):
     junk = bytearray(good); junk[-1] |= 0x40
     xy, inf = zb.point_from_bytes_uncompressed(curve.cid, 1, bytes(junk))
     assert inf == 1 and not xy.any()
+
+
+# ---- ProvingContext bytes on the host only (zl_groth16_keys_parse): the decoder of untrusted input, without a device -------------------------------
+def _g1_pts(curve, arr):
+    arr = np.asarray(arr).reshape(-1, 2 * ol.nlq(curve))
+    return [ol.limbs_to_point(curve, row, int(not row.any())) for row in arr]
+
+
+def _g2_pts(curve, arr):
+    nq = ol.nlq(curve)
+    out = []
+    for row in np.asarray(arr).reshape(-1, 4 * nq):
+        if not row.any():
+            out.append(None)
+            continue
+        v = ol.limbs_to_ints(row.reshape(4, nq))
+        out.append(((v[0], v[1]), (v[2], v[3])))
+    return out
+
+
+def _oracle_key_bytes(curve, k=1):
+    """the oracle's own setup of the k-hash Poseidon chain under a fixed trapdoor, encoded by the independent Python restatement (oracle/pyoracle.py) -- no GPU"""
+    td = po.Groth16Trapdoor(alpha=11, beta=13, gamma=17, delta=19, tau=23)
+    cs = po.poseidon_chain_circuit(curve.fr, k)
+    pk = gu.setup_with_trapdoor(curve, cs, td)
+    g1 = lambda ks: _g1_pts(curve, ol.oracle_g1_mul_gen(curve, ol.ints_to_limbs(ks, 4)))
+    vk = {"alpha_g1": _g1_pts(curve, pk["alpha_g1"])[0], "beta_g2": _g2_pts(curve, pk["beta_g2"])[0],
+          "gamma_g2": _g2_pts(curve, gu.g2_mul_gen(curve, [td.gamma]))[0], "delta_g2": _g2_pts(curve, pk["delta_g2"])[0],
+          "gamma_abc_g1": g1(pk["ex"]["gamma_abc"])}
+    pts = {"vk": vk, "beta_g1": _g1_pts(curve, pk["beta_g1"])[0], "delta_g1": _g1_pts(curve, pk["delta_g1"])[0],
+           "a_query": _g1_pts(curve, pk["a_query"]), "b_g1_query": _g1_pts(curve, pk["b_g1_query"]), "b_g2_query": _g2_pts(curve, pk["b_g2_query"]),
+           "h_query": _g1_pts(curve, pk["h_query"]), "l_query": _g1_pts(curve, pk["l_query"])}
+    return po.groth16_pk_bytes(curve, pts)
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_proving_context_parse_on_the_host_accepts_the_restatement_and_survives_corruption(curve):
+    """zl_groth16_keys_parse reads every byte zl_groth16_keys_from_bytes reads, on the host alone: the Python restatement's encoding of the oracle's key is
+    accepted (with and without ZL_CHECK); truncations, trailing bytes, lying Vec lengths and non-canonical coordinates are refused with ZL_EINVAL; 300 random byte
+    flips / truncations / splices never crash (this test also runs under AddressSanitizer + UBSan: tests/test_sanitizers.py)."""
+    data = _oracle_key_bytes(curve)
+    assert zb.groth16_keys_parse(curve.cid, data) == 0
+    assert zb.groth16_keys_parse(curve.cid, data, check=True) == 0
+    assert zb.groth16_keys_parse(curve.cid, data[:-1]) == -1
+    assert zb.groth16_keys_parse(curve.cid, data + b"\0") == -1
+    assert zb.groth16_keys_parse(curve.cid, b"") == -1
+    assert zb.groth16_keys_parse(3, data) == -1
+    nb = (curve.fq.p.bit_length() + 63) // 64 * 8
+    off = 2 * nb + 3 * 4 * nb  # gamma_abc length prefix: after alpha_g1 and three G2 points
+    for lie in (1 << 60, (1 << 64) - 1, len(data), int.from_bytes(data[off:off + 8], "little") + 1):
+        bad = bytearray(data)
+        bad[off:off + 8] = lie.to_bytes(8, "little")
+        assert zb.groth16_keys_parse(curve.cid, bytes(bad)) == -1, lie
+    bad = bytearray(data)
+    bad[0:nb] = curve.fq.p.to_bytes(nb, "little")  # alpha_g1.x = q: not canonical
+    assert zb.groth16_keys_parse(curve.cid, bytes(bad)) == -1
+    bad = bytearray(data)
+    y = int.from_bytes(bad[nb:2 * nb], "little")
+    bad[nb:2 * nb] = ((y + 1) % curve.fq.p).to_bytes(nb, "little")  # alpha_g1 off the curve: taken as given unchecked, refused under ZL_CHECK
+    assert zb.groth16_keys_parse(curve.cid, bytes(bad)) == 0 and zb.groth16_keys_parse(curve.cid, bytes(bad), check=True) == -6
+    rng = np.random.default_rng(20260929 + curve.cid)
+    seen = set()
+    for trial in range(300):
+        bad = bytearray(data)
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                bad[int(rng.integers(0, len(bad)))] ^= int(rng.integers(1, 256))
+        elif kind == 1:
+            bad = bad[:int(rng.integers(0, len(bad)))]
+        elif kind == 2:
+            i, j = sorted(int(v) for v in rng.integers(0, len(bad), 2))
+            bad = bad[:i] + bad[j:]
+        else:
+            i = int(rng.integers(0, len(bad) - 8))
+            bad[i:i + 8] = rng.bytes(8)
+        seen.add(zb.groth16_keys_parse(curve.cid, bytes(bad), check=bool(trial & 4)))
+    assert seen <= {0, -1, -6} and -1 in seen
