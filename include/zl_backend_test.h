@@ -19,7 +19,8 @@ extern "C" {
  * the device Fr multiplier the NTT uses; round constants / MDS come from the host mirror (Grain LFSR, Cauchy matrix).
  * state: 3 x 4 u64 canonical, in place.  All 64 lanes compute the same permutation; ZL_EHIP if they disagree. */
 int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state);
-/* The same permutation computed with the lazily reduced 10 x 28-bit Fr multiplier of the NTT PASSES (openzl_amd/csrc/zl_field28r.h, mul28r_asm, R' = 2^280):
+/* The same permutation computed with the lazily reduced Fr multiplier of the NTT PASSES (openzl_amd/csrc/zl_field28r.h): since round 5 nine 29-bit limbs
+ * (mul29r_asm, R' = 2^261) -- and, in the same call, round 4's ten 28-bit limbs (mul28r_asm, R' = 2^280); the two must agree:
  * since round 4 the hot NTT no longer multiplies with the 8 x 32 carry chain the hook above exercises, so the reference's [3, 1, 2] vector is run
  * through this multiplier as well (conversions, 63 rounds, Fermat inversions for the MDS entries, lazy additions without comparisons, one canon at the end). */
 int zl_test_poseidon_permute_dev28r(zl_ctx* ctx, zl_curve_t curve, uint64_t* state);

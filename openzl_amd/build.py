@@ -31,7 +31,7 @@ if TAG:
 STRIP_NOPS = os.environ.get("ZL_STRIP_ASM_NOPS", "") == "1"
 STRIP_VERSION = "strip-nops-v1"
 _LLVM = "/opt/rocm/lib/llvm/bin"
-STRIP_UNITS = ("zl_msm_acc_",)  # unit-name prefixes compiled that way
+STRIP_UNITS = tuple(u for u in os.environ.get("ZL_STRIP_UNITS", "zl_msm_acc_").split(",") if u)  # unit-name prefixes compiled that way
 _SAFE_NEXT = re.compile(r"^(;;#ASMSTART|v_mul_lo_u32|v_lshrrev_b64|v_and_b32_e32|v_and_b32_e64)\b")
 _INC = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
 

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64) k_test_poseidon(const uint32_t* __restrict
 // The same permutation on the lazily reduced 10 x 28-bit Fr of the NTT passes (zl_field28r.h, round 4): since that round the hot NTT multiplies with
 // mul28r_asm, not with the 8 x 32 carry chain above, so the one reference-held vector is run through THIS multiplier too.
 // Everything stays in the multiplier's own Montgomery form x R' (R' = 2^280): to_mont = mul(x, R'^2), products mul(a R', b R') = a b R', lazy additions
-// (bounds: an MDS row sum of three products < 6r, plus a round key < 8r; 8 * 8 << 2^25), Fermat inversion for the Cauchy entries with the same
+// (bounds: an MDS row sum of three products < 6r, plus a round key < 8r; 8 * 8 = 64 <= MUL_BOUND of either instance: 70 at 9 x 29 bits, 2^25 at 10 x 28), Fermat inversion for the Cauchy entries with the same
 // multiplier, from_mont = mul(x R', 1), canon, pack.  No value is ever compared with r before the final canon.
 template <class FrP, class P28>
 __global__ void __launch_bounds__(64) k_test_poseidon28r(const uint32_t* __restrict__ keys_canon, int full_rounds, int partial_rounds, uint32_t* __restrict__ state,
@@ -402,9 +402,16 @@ int zl_test_poseidon_permute_dev(zl_ctx* ctx, zl_curve_t curve, uint64_t* state)
 int zl_test_poseidon_permute_dev28r(zl_ctx* ctx, zl_curve_t curve, uint64_t* state) {
     if (!ctx || !state) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    if (curve == ZL_BLS12_381) return poseidon_dev_t<BLS12_381_Fr, BLS12_381_Fr28>(ctx, state);
-    if (curve == ZL_BN254) return poseidon_dev_t<BN254_Fr, BN254_Fr28>(ctx, state);
-    return ZL_EINVAL;
+    if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;
+    // both instances of the lazy field: nine 29-bit limbs (what the NTT passes multiply with since round 5) and ten 28-bit limbs (round 4, kept as the A/B build);
+    // the 29-bit result is returned, a disagreement between the two is an error
+    uint64_t s28[12];
+    memcpy(s28, state, sizeof s28);
+    int rc = curve == ZL_BLS12_381 ? poseidon_dev_t<BLS12_381_Fr, BLS12_381_Fr29>(ctx, state) : poseidon_dev_t<BN254_Fr, BN254_Fr29>(ctx, state);
+    if (rc) return rc;
+    rc = curve == ZL_BLS12_381 ? poseidon_dev_t<BLS12_381_Fr, BLS12_381_Fr28>(ctx, s28) : poseidon_dev_t<BN254_Fr, BN254_Fr28>(ctx, s28);
+    if (rc) return rc;
+    return memcmp(s28, state, sizeof s28) ? ZL_EHIP : ZL_OK;
 }
 
 int zl_test_fp28_op(zl_ctx* ctx, int op, const uint32_t* in, size_t n, uint32_t* out) { return test_fp28_op_t<F28>(ctx, op, in, n, out); }
