@@ -57,6 +57,11 @@ template <class G>
 struct MsmJob {
     using F = typename G::F;
     using X = XYZZ<F>;
+    // carried bucket set (host-scalar shards, zl_capi.hip msm_host_chunked): the shards of ONE MSM run as jobs with the same windows over the SAME bucket sums;
+    // carry_in: this job adds into the sums the earlier shards left (k_msm_accumulate_carry, merge kernels with carry = 1); reduce = false: no bucket
+    // reduction after this job (only the last shard reduces) -- its result is just the sum of its scalar-1 bases
+    bool carry_in = false, reduce = true;
+    hipEvent_t ev_merged = nullptr;  // recorded behind the merge kernels of tail(): the next shard's accumulation waits for it
     // plan
     bool pre = false;
     int c = 0, W = 0;
@@ -453,7 +458,10 @@ struct MsmJob {
         if (wg_per_cu > 0 && ctx->cu_count > 0 && nchunks >= 8 * (uint64_t)lanes_persist)  // >= 8 chunks per lane: the last, partial round costs little
             hipLaunchKernelGGL((k_msm_accumulate_persist<G>), dim3((uint32_t)wg_per_cu * (uint32_t)ctx->cu_count), dim3(ZL_ACC_PERSIST_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases,
                                d_buckets, d_partials, ZL_CHUNK, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, nchunks);
-        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // four lanes per chunk while that still fits the machine at three waves per SIMD
+        else if (carry_in)
+            hipLaunchKernelGGL((k_msm_accumulate_carry<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
+        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // four lanes per chunk while that still fits the machine at three waves per SIMD
             hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (G::COORDS == 1 && ctx->acc_clk && (size_t)((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK) * 32 <= ctx->acc_clk_cap) {  // armed by the measurement hook zl_test_acc_clock only
@@ -470,20 +478,28 @@ struct MsmJob {
     int tail(zl_ctx* ctx, hipStream_t st) {
         // four lanes per group operation (zl_quad.h) in every tail launch that does not fill the machine
         const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
+        const uint32_t carry = carry_in ? 1u : 0u;
         if (NB <= quad_max)
-            hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
+            hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else
-        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
-                           d_partials, d_big_list, d_big_count, ZL_CHUNK);
+                           d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
         hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                            d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-        hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count);
+        hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+        if (ev_merged) ZL_HIP(ctx, hipEventRecord(ev_merged, st));  // the bucket sums of this shard are final
         // scalar-1 bases: window-0 table entries are the bases themselves
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
                            pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
                            (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set, (const uint32_t*)d_ones_count);
+        if (!reduce) {  // an earlier shard of a carried bucket set: only the sum of its scalar-1 bases travels
+            ZL_HIP(ctx, hipGetLastError());
+            ZL_HIP(ctx, hipMemcpyAsync(hw + (size_t)SETS * roots_per_set, d_sets + (size_t)SETS * roots_per_set, sizeof(X), hipMemcpyDeviceToHost, st));
+            ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 8, hipMemcpyDeviceToHost, st));
+            return ZL_OK;
+        }
         {
             const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
             const uint32_t leaves = SETS * red_blocks;
@@ -531,6 +547,7 @@ struct MsmJob {
         return v;
     }
     X finish(bool parallel = true) const {
+        if (!reduce) return hw[(size_t)SETS * roots_per_set];
         std::vector<X> V(SETS);
         if (parallel && SETS >= 4) zl_pool_get().parallel_for(SETS, [&](size_t w) { V[w] = window_value((int)w); });
         else for (uint32_t w = 0; w < SETS; w++) V[w] = window_value((int)w);

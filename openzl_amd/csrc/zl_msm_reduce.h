@@ -18,7 +18,9 @@ template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 256) ? 3 : 1) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
                                                    const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
-                                                   uint32_t ZL_CHUNK, uint32_t big_span) {
+                                                   uint32_t ZL_CHUNK, uint32_t big_span, uint32_t carry) {
+    // carry != 0 (host-scalar shards, zl_msm_accumulate.h): the bucket sums hold the earlier shards' sums -- an empty bucket keeps its sum, a cut bucket adds its
+    // partials to it
     ZL_SIDE_PRIO();
     using F = TailF<typename G::F>;
     XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
@@ -28,12 +30,13 @@ __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 25
     const int sub = QUAD ? (int)(gt & 3u) : 0;
     if (b >= NB) return;
     const uint32_t s = offsets[b], e = offsets[b + 1];
-    if (s == e) { if (sub == 0) bucket_sums[b] = XYZZ<F>::inf(); return; }
+    if (s == e) { if (sub == 0 && !carry) bucket_sums[b] = XYZZ<F>::inf(); return; }
     const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
     if (t0 == t1) return;  // written directly by msm_accumulate
     if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (sub == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
     if (t1 - t0 + 1 > big_span) { if (sub == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
     XYZZ<F> acc = XYZZ<F>::inf();
+    if (carry) acc = bucket_sums[b];
     for (uint32_t t = t0; t <= t1; t++) {
         const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
         if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
@@ -65,7 +68,7 @@ __device__ __forceinline__ void zl_block_tree(XYZZ<typename G::F>* sh, XYZZ<type
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
-                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK, uint32_t carry) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -75,6 +78,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
         XYZZ<F> acc = XYZZ<F>::inf();
+        if (carry && threadIdx.x == 0) acc = bucket_sums[b];
         for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
             const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
             zl::add_full(acc, p);
@@ -111,12 +115,13 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint3
 }
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __restrict__ bucket_sums, const XYZZ<typename G::F>* __restrict__ giant_tmp,
-                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count, uint32_t carry) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= *giant_count) return;
     XYZZ<F> acc = XYZZ<F>::inf();
+    if (carry) acc = bucket_sums[giant_list[item]];
     for (uint32_t k = 0; k < ZL_GIANT_PARTS; k++) {
         const XYZZ<F> p = giant_tmp[(size_t)item * ZL_GIANT_PARTS + k];
         zl::add_full(acc, p);
@@ -260,11 +265,11 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
 
 // every instantiation MsmJob<G>::tail launches (X as in zl_msm_accumulate.h)
 #define ZL_MSM_TAIL_KERNELS(X, G) \
-    X template __global__ void k_msm_merge<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
+    X template __global__ void k_msm_merge<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_giant<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
-    X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*); \
+    X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
     X template __global__ void k_msm_ones<G>(const uint32_t*, const uint32_t*, const Affine<typename G::F>*, XYZZ<typename G::F>*, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_reduce_level0<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \

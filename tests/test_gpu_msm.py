@@ -599,3 +599,55 @@ def test_msm_ranges_of_one_handle_and_repeated_points(backend, curve):
             assert inf == einf and (got == exp).all(), (first, cnt)
     finally:
         backend.bases_free(h)
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n,plan", [(20, "16,17,18"), (22, "19,20")], ids=["2^20-lds-sort", "2^22-wide-sort"])
+@pytest.mark.parametrize("case", ["uniform", "skewed"])
+def test_msm_host_scalars_on_a_carried_bucket_set(backend, curve, log_n, plan, case):
+    """zl_msm with HOST scalars (what multi_scalar_mul is handed) cuts a large input into growing shards whose copies hide under the earlier shards' work; since
+    round 5 the shards are jobs over ONE carried bucket set with the windows of the whole MSM (k_msm_accumulate_carry continues a bucket's sum, k_msm_merge adds the
+    cut buckets' partials to it, only the last shard reduces).  Driven here at sizes the check finishes quickly (ZL_TUNE_HOST_CHUNK_MIN_LOG / ZL_TUNE_HOST_SHARDS:
+    three resp. two leading shards + the rest, unaligned total), on uniform scalars and on a distribution built to hit the shard-specific paths: a shard whose
+    scalars are all zero (every bucket empty: sums must survive), all equal (one giant bucket per window in that shard only), scalars 1 and r - 1 (the
+    scalar-1 bypass of a non-reducing shard), negations of the previous shard's scalars (P - P inside carried buckets).  Exact against (sum s_i k_i) G, and the
+    independent-jobs path (ZL_TUNE_HOST_CARRY=0) must give the same point."""
+    import os
+
+    r = curve.fr.p
+    n = (1 << log_n) + 777
+    rng = np.random.Generator(np.random.PCG64(99 + log_n + curve.cid))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    if case == "skewed":
+        k64[1 << 17:(1 << 17) + 4096] = k64[0:4096]  # the same points again in the second shard ...
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    S = ol.random_scalars(curve, n, 100 + log_n)
+    if case == "skewed":
+        sizes = [1 << int(x) for x in plan.split(",")]
+        o1, o2 = sizes[0], sizes[0] + sizes[1]
+        S[0:16] = 0
+        S[16:32] = ol.ints_to_limbs([1], 4)[0]
+        S[32:48] = ol.ints_to_limbs([r - 1], 4)[0]
+        S[o1:o1 + 4096] = ol.ints_to_limbs([(r - v) % r for v in ol.limbs_to_ints(S[0:4096])], 4)  # ... with the negated scalars: k s - k s in carried buckets
+        S[o1 + 8192:o2] = 0 if len(sizes) > 2 else S[o1 + 8192:o2]                                   # (three-shard plan: most of the second shard empty)
+        S[o2:o2 + 50000] = ol.ints_to_limbs([0xABCDEF0123456789ABCDEF0123456789ABCDEF0123456789 % r], 4)[0]  # a giant bucket per window in the next shard
+        S[o2 + 50000:o2 + 50016] = ol.ints_to_limbs([1], 4)[0]
+    S = np.ascontiguousarray(S)
+    h = backend.bases_generate(curve.cid, k)
+    exp = _oracle_point(curve, _dot_mod_r_u64k(S, k64, r))
+    old = {kk: os.environ.get(kk) for kk in ("ZL_TUNE_HOST_CHUNK_MIN_LOG", "ZL_TUNE_HOST_SHARDS", "ZL_TUNE_HOST_CARRY")}
+    try:
+        os.environ["ZL_TUNE_HOST_CHUNK_MIN_LOG"] = "18"
+        os.environ["ZL_TUNE_HOST_SHARDS"] = plan
+        for carry in ("1", "0", "1"):
+            os.environ["ZL_TUNE_HOST_CARRY"] = carry
+            got, inf = backend.msm(h, S)
+            assert not inf and (got == exp).all(), carry
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = v
+        backend.bases_free(h)
