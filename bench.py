@@ -1076,7 +1076,7 @@ def main():
             ntt_cpu["parity_full_size"] = True
             del X_cpu, X_gpu
         ntt_traffic, ntt_traffic_src = None, None
-        for cand in ("r04_pmc_traffic_ntt.json",):
+        for cand in ("r05_pmc_traffic_ntt.json", "r04_pmc_traffic_ntt.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if ln == int(pmc["log_n"]):
@@ -1256,7 +1256,7 @@ def main():
         # WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration, null otherwise
         traffic = None
         traffic_src = None
-        for cand in ("r04_pmc_traffic.json",):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
+        for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if args.log_n == int(pmc["log_n"]) and head["window_bits"] == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
