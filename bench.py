@@ -672,7 +672,7 @@ def config2_leg(R: Run):
         inp.free()
 
 
-def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup):
+def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup, g16_k=None):
     """ONE process, G devices: zl_ctx_create_multi (RCCL communicator inside the library when the devices are distinct) + zl_msm_sharded
     (complete local Pippenger per device on its own host thread -> ncclAllGather of the partials -> fold) and zl_ntt_sharded (cross step ->
     grouped ncclSend / ncclRecv all-to-all -> local transform).  Returns the result dict; every MSM result is checked exactly."""
@@ -754,6 +754,9 @@ def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup):
             out["ntt"] = {"log_n": ntt_log_m + log_g, "elements_per_gpu": M, "forward_ms": float(np.mean(f_ms)), "inverse_ms": float(np.mean(i_ms)),
                           "forward_elems_per_s": tot / (float(np.mean(f_ms)) * 1e-3), "inverse_elems_per_s": tot / (float(np.mean(i_ms)) * 1e-3),
                           "self_check": "iNTT(NTT(x)) == x on every rank; bit-exact parity of the entry point in tests/test_gpu_multi.py"}
+        k_g16 = g16_k if g16_k is not None else (min(args.groth16_k, 4096 if log_n >= 22 else 64) if getattr(args, "groth16_k", 0) > 0 else 0)
+        if k_g16 > 0:
+            out["groth16_one_proof_over_ranks"] = mctx_groth16_leg(mb, k_g16)
         return out
     finally:
         for hh, r in zip(hs, mb.ranks):
@@ -762,6 +765,54 @@ def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup):
             except Exception:  # noqa: BLE001
                 pass
         mb.close()
+
+
+def mctx_groth16_leg(mb, k):
+    """ONE proof over the ranks of the mctx (zl_groth16_prove_sharded): the key is compiled on rank 0, every query cut into G contiguous slices and uploaded to the
+    ranks, the witness map runs on rank 0, every rank its five partial MSMs, the host folds and assembles.  The proof must equal rank 0's single-device proof for
+    the same (r, s) byte for byte.  Latency scaling of one proof (what 'constraints/s at N GPUs' means for a single prover), beside the replicas leg."""
+    from openzl_amd import ZL_BLS12_381, Circuit, Groth16Keys
+
+    be0 = mb.ranks[0]
+    circ = Circuit(ZL_BLS12_381, k)
+    keys = Groth16Keys(be0, circ, seed=0x5EED0006)
+    skeys = None
+    try:
+        arr = circ.arrays()
+        n_c = arr["n_constraints"]
+        ref, r, s = keys.prove(seed=7)
+        for _ in range(2):
+            keys.prove(seed=7)
+        t1 = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            keys.prove(seed=7)
+            t1.append(time.perf_counter() - t0)
+        pk = {name: be0.bases_download(getattr(keys.pk, name)) for name in ("a_query", "b_g1_query", "h_query", "l_query", "b_g2_query")}
+        nq = 6
+        for name, words in (("alpha_g1", 2 * nq), ("beta_g1", 2 * nq), ("delta_g1", 2 * nq), ("beta_g2", 4 * nq), ("delta_g2", 4 * nq)):
+            pk[name] = np.ctypeslib.as_array(getattr(keys.pk, name), shape=(words,)).copy()
+        skeys = mb.groth16_shard_keys(ZL_BLS12_381, pk, arr)
+        z = arr["assignment"]
+        got = skeys.prove(z, r, s)
+        if not all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, ref)):
+            raise SystemExit("zl_groth16_prove_sharded self-check failed: the proof over the ranks differs from the single-device proof")
+        for _ in range(2):
+            skeys.prove(z, r, s)
+        tg = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            skeys.prove(z, r, s)
+            tg.append(time.perf_counter() - t0)
+        return {"hashes": k, "constraints": int(n_c), "ranks": mb.size, "prove_ms": float(np.median(tg)) * 1e3, "single_device_prove_ms": float(np.median(t1)) * 1e3,
+                "constraints_per_s": n_c / float(np.median(tg)), "equals_single_device_proof": True,
+                "note": "functional: the witness map runs on rank 0 alone and the five MSMs of a rank run one after the other through the single-call path; "
+                        "exchange = device-to-device copies of the z / h slices + 5 x 512 B of partials per rank"}
+    finally:
+        if skeys is not None:
+            skeys.close()
+        keys.close()
+        circ.close()
 
 
 def main_mctx(args):
@@ -1235,11 +1286,12 @@ def main():
             # 2^26 = 8 x 2^23 through the sharded entry point with 8 virtual ranks on this one GPU: functional (exact) check of the whole
             # config-4 data path; its multi-GPU throughput needs N > 1 (scaling.config4 on that line)
             shard_log = 23 if args.log_n >= 24 else max(10, args.log_n - 3)
-            r4 = mctx_run(args, [local_rank] * 8, shard_log, 0, 2, 1)
+            r4 = mctx_run(args, [local_rank] * 8, shard_log, 0, 2, 1, g16_k=64 if args.groth16_k > 0 else 0)
             m4 = r4["msm"]
             configs["4"] = {"config": f"2^{shard_log + 3} BLS12-381 G1 MSM as 8 shards of 2^{shard_log} (zl_msm_sharded, 8 virtual ranks on ONE GPU)",
                             "functional": True, "checked_exactly": True, "ms_per_msm_on_one_gpu": m4["ms_per_step"], "points_per_s_on_one_gpu": m4["points_per_s"],
-                            "multi_gpu_throughput": "not measured at N = 1 (see scaling.config4 of a --gpus N run)", "exchange": r4["exchange"]}
+                            "multi_gpu_throughput": "not measured at N = 1 (see scaling.config4 of a --gpus N run)", "exchange": r4["exchange"],
+                            "groth16_one_proof_over_8_virtual_ranks": r4.get("groth16_one_proof_over_ranks")}
 
         _guard("config1", _leg_c1)
         _guard("config2", _leg_c2)

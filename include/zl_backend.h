@@ -191,6 +191,20 @@ int zl_r1cs_free(zl_ctx* ctx, uint64_t handle);
 /* flags: ZL_MONT = the assignment is in arkworks' in-memory Montgomery form (no host-side into_repr pass needed) */
 int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* assignment, unsigned flags,
                               const uint64_t* r, const uint64_t* s, zl_g16_proof* out);
+/* ONE proof over the G devices of an mctx: the five MSMs of create_proof_with_assignment shard by point range like any MSM.  Rank g holds, on
+ * zl_mctx_ctx(m, g), bases handles with ITS contiguous slice of every query -- a / b_g1 / b_g2 over the variables [var_first, var_first + var_count) (variable 0
+ * is the constant ONE), l over the witnesses [wit_first, ...), h over the domain indices [h_first, ...) of the N - 1 quotient coefficients -- uploaded with the
+ * single-device calls; the slices of consecutive ranks must tile the three ranges in rank order (a rank may hold empty slices: count 0, handle ignored).
+ * Rank 0 also holds the constraint matrices (r1cs_handle_rank0 from zl_r1cs_upload on zl_mctx_ctx(m, 0)) and runs the witness map; the other ranks receive
+ * their slices of z and h by device-to-device copy, every rank runs its five partial MSMs, the host folds the partials over the ranks and assembles the proof.
+ * pk: only curve and the five single points are read.  The proof equals zl_groth16_prove_resident's for the same (r, s), byte for byte. */
+typedef struct zl_g16_shard {
+    uint64_t a_query, b_g1_query, h_query, l_query; /* ZL_G1 handles on this rank's ctx: var_count, var_count, h_count, wit_count points */
+    uint64_t b_g2_query;                            /* ZL_G2 handle: var_count points */
+    size_t var_first, var_count, wit_first, wit_count, h_first, h_count;
+} zl_g16_shard;
+int zl_groth16_prove_sharded(zl_mctx* m, const zl_g16_pk* pk, const zl_g16_shard* shards, uint64_t r1cs_handle_rank0, const uint64_t* assignment,
+                             unsigned flags, const uint64_t* r, const uint64_t* s, zl_g16_proof* out);
 /* the quotient polynomial h of the last successful zl_groth16_prove* call on this ctx (N x 4 u64 canonical), for tests;
  * ZL_EINVAL when there is none (it lives in scratch slot 8 and is invalidated when the next proof starts) */
 int zl_groth16_last_h(zl_ctx* ctx, uint64_t* out, size_t n);

@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
@@ -53,6 +53,12 @@ class R1csC(C.Structure):
 class G16PkC(C.Structure):
     _fields_ = [("curve", C.c_int), ("a_query", C.c_uint64), ("b_g1_query", C.c_uint64), ("h_query", C.c_uint64), ("l_query", C.c_uint64),
                 ("b_g2_query", C.c_uint64), ("alpha_g1", u64p), ("beta_g1", u64p), ("delta_g1", u64p), ("beta_g2", u64p), ("delta_g2", u64p)]
+
+
+class G16ShardC(C.Structure):
+    _fields_ = [("a_query", C.c_uint64), ("b_g1_query", C.c_uint64), ("h_query", C.c_uint64), ("l_query", C.c_uint64), ("b_g2_query", C.c_uint64),
+                ("var_first", C.c_size_t), ("var_count", C.c_size_t), ("wit_first", C.c_size_t), ("wit_count", C.c_size_t), ("h_first", C.c_size_t),
+                ("h_count", C.c_size_t)]
 
 
 class G16ProofC(C.Structure):
@@ -100,6 +106,7 @@ def load_library(path: Optional[str] = None):
     L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.zl_groth16_prove.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(R1csC), u64p, u64p, u64p, C.POINTER(G16ProofC)]
+    L.zl_groth16_prove_sharded.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(G16ShardC), C.c_uint64, u64p, C.c_uint, u64p, u64p, C.POINTER(G16ProofC)]
     L.zl_groth16_last_h.argtypes = [vp, u64p, C.c_size_t]
     L.zl_circuit_poseidon_chain.argtypes = [C.c_int, C.c_uint32, u64p, u64p, C.POINTER(vp)]
     L.zl_circuit_free.argtypes = [vp]
@@ -356,6 +363,84 @@ class Backend:
         return out
 
 
+class ShardedGroth16Keys:
+    """a proving key spread over the ranks of a MultiBackend (zl_g16_shard per rank) + the constraint matrices on rank 0"""
+
+    def __init__(self, mb: "MultiBackend", curve: int, pk: dict, r1cs: dict, cuts=None):
+        self.mb, self.curve, self.L = mb, curve, mb.L
+        G = mb.size
+        ni, nw = r1cs["n_instance"], r1cs["n_witness"]
+        nv = ni + nw
+        n_h = pk["h_query"].shape[0]
+
+        def bounds(total):
+            if cuts is not None:
+                edges = [0] + [int(round(total * f)) for f in cuts] + [total]
+            else:
+                edges = [total * g // G for g in range(G + 1)]
+            return [(edges[g], max(0, edges[g + 1] - edges[g])) for g in range(G)]
+
+        vb, wb, hb = bounds(nv), bounds(nw), bounds(n_h)
+        self.shards = (G16ShardC * G)()
+        self._made, self._keep, self._r1cs = [], [], 0
+        try:
+            for g in range(G):
+                be = mb.ranks[g]
+                sh = self.shards[g]
+                (sh.var_first, sh.var_count), (sh.wit_first, sh.wit_count), (sh.h_first, sh.h_count) = vb[g], wb[g], hb[g]
+                for name, (f, c), grp in (("a_query", vb[g], ZL_G1), ("b_g1_query", vb[g], ZL_G1), ("h_query", hb[g], ZL_G1), ("l_query", wb[g], ZL_G1),
+                                          ("b_g2_query", vb[g], ZL_G2)):
+                    if c == 0:
+                        continue
+                    hnd = be.bases_upload(curve, np.ascontiguousarray(pk[name][f:f + c]), group=grp)
+                    self._made.append((be, hnd))
+                    setattr(sh, name, hnd)
+            cs = R1csC()
+            cs.n_constraints, cs.n_instance, cs.n_witness = r1cs["n_constraints"], ni, nw
+            keep = []
+            for m, key in enumerate("ABC"):
+                ptr, col, val = (np.ascontiguousarray(x, dtype=t) for x, t in zip(r1cs[key], (np.uint32, np.uint32, np.uint64)))
+                keep += [ptr, col, val]
+                cs.row_ptr[m] = ptr.ctypes.data_as(C.POINTER(C.c_uint32))
+                cs.col[m] = col.ctypes.data_as(C.POINTER(C.c_uint32))
+                cs.val[m] = val.ctypes.data_as(u64p)
+            hr = C.c_uint64()
+            be0 = mb.ranks[0]
+            be0._check(self.L.zl_r1cs_upload(be0._ctx, curve, C.byref(cs), C.byref(hr)), "zl_r1cs_upload")
+            self._r1cs = hr.value
+            self.pkc = G16PkC()
+            self.pkc.curve = curve
+            for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2"):
+                arr = np.ascontiguousarray(pk[k], dtype=np.uint64)
+                self._keep.append(arr)
+                setattr(self.pkc, k, arr.ctypes.data_as(u64p))
+        except Exception:
+            self.close()
+            raise
+
+    def prove(self, assignment: np.ndarray, r: np.ndarray, s: np.ndarray, mont: bool = False):
+        proof = G16ProofC()
+        z = np.ascontiguousarray(assignment, dtype=np.uint64)
+        rc = self.L.zl_groth16_prove_sharded(self.mb._m, C.byref(self.pkc), self.shards, self._r1cs, _p64(z), ZL_MONT if mont else 0, _p64(np.ascontiguousarray(r)),
+                                             _p64(np.ascontiguousarray(s)), C.byref(proof))
+        if rc:
+            raise BackendError(rc, "zl_groth16_prove_sharded", self.L.zl_strerror(rc).decode())
+        nq = FQ_LIMBS[self.curve]
+        return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,
+                np.array(proof.c[: 2 * nq], dtype=np.uint64), proof.c_inf)
+
+    def close(self):
+        for be, hnd in self._made:
+            try:
+                be.bases_free(hnd)
+            except Exception:
+                pass
+        self._made = []
+        if self._r1cs:
+            self.L.zl_r1cs_free(self.mb.ranks[0]._ctx, self._r1cs)
+            self._r1cs = 0
+
+
 class MultiBackend:
     """zl_mctx: G devices driven from one process (include/zl_backend.h, multi-GPU section).  ranks[g] is a Backend bound to rank g's
     ctx (upload / generate that rank's shard of the bases there); device ids may repeat (virtual ranks on one GPU, test mode)."""
@@ -384,6 +469,20 @@ class MultiBackend:
         if rc:
             raise BackendError(rc, "zl_msm_sharded", self.L.zl_strerror(rc).decode())
         return out, inf.value
+
+    def groth16_shard_keys(self, curve: int, pk: dict, r1cs: dict, cuts=None) -> "ShardedGroth16Keys":
+        """Spread a proving key over the ranks of this mctx for zl_groth16_prove_sharded.  pk: the key as HOST arrays of canonical affine points ('a_query' ... as
+        (n, words) uint64, all-zero row = infinity) + the five single points; every query is cut into contiguous slices (cuts: optional fractions at which to
+        cut, default equal parts), rank g uploads its slices to its own ctx, rank 0 uploads the matrices."""
+        return ShardedGroth16Keys(self, curve, pk, r1cs, cuts)
+
+    def groth16_prove_sharded(self, curve: int, pk: dict, r1cs: dict, assignment: np.ndarray, r: np.ndarray, s: np.ndarray, cuts=None):
+        """upload + one proof + free (tests); returns (a, a_inf, b, b_inf, c, c_inf)"""
+        keys = self.groth16_shard_keys(curve, pk, r1cs, cuts)
+        try:
+            return keys.prove(assignment, r, s)
+        finally:
+            keys.close()
 
     def ntt_sharded(self, curve: int, d_data, log_n: int, inverse: bool = False, coset: bool = False, mont: bool = False):
         G = self.size

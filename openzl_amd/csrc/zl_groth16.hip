@@ -11,6 +11,7 @@
 // elementwise kernels around zl_ntt_run / zl_msm_run; the window Horner and the final few group operations run on host.
 #include <stdlib.h>
 #include <string.h>
+#include <array>
 #include <thread>
 #include <vector>
 #include <chrono>
@@ -122,8 +123,10 @@ static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
 template <class G1, class G2>
 // `witness` (optional): the assignment arrives in two pieces, `assignment` = the instance block and `witness` = the witness block, as the
 // compiler holds them (openzl::Groth16::prove): two copies to the device instead of a host-side concatenation of tens of megabytes per proof
+// wm_only: the assignment goes to the device and the witness map runs (z canonical at ctx->g16_z, h at ctx->g16_h), no MSM, no proof: the first step of a proof
+// whose MSMs run on several devices (groth16_prove_sharded_t below); pk's handles are not looked at
 static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* cs, const uint64_t* assignment, unsigned flags, const uint64_t* r,
-                           const uint64_t* s, zl_g16_proof* out, const uint64_t* witness = nullptr) {
+                           const uint64_t* s, zl_g16_proof* out, const uint64_t* witness = nullptr, bool wm_only = false) {
     using FrP = typename G1::FrP;
     using Fr = Fp<FrP>;
     using F1 = typename G1::F;
@@ -138,14 +141,14 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     const uint32_t N = 1u << log_n;
     // handles
     const uint64_t hs[5] = {pk->a_query, pk->b_g1_query, pk->h_query, pk->l_query, pk->b_g2_query};
-    const zl_bases* bs[5];
-    for (int i = 0; i < 5; i++) {
+    const zl_bases* bs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 5 && !wm_only; i++) {
         auto it = ctx->bases.find(hs[i]);
         if (it == ctx->bases.end()) return ZL_EHANDLE;
         if (it->second.curve != (int)pk->curve || it->second.group != (i == 4 ? ZL_G2 : ZL_G1)) return ZL_EHANDLE;
         bs[i] = &it->second;
     }
-    if (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw) return ZL_EINVAL;
+    if (!wm_only && (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw)) return ZL_EINVAL;
 
     hipStream_t st = ctx->stream;
     static const bool trace = getenv("ZL_HOST_TRACE") != nullptr;  // developer aid: host-side phase times on stderr
@@ -246,6 +249,17 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     });
     // (every return below first waits for that thread: it works on this frame)
     auto wm_fail = [&](int code) { w_wm.wait(); (void)hipStreamSynchronize(s_wm); ctx->timing_on = timing_saved; return code; };
+    if (wm_only) {
+        w_wm.wait();
+        const hipError_t e1 = hipStreamSynchronize(s_wm), e2 = hipStreamSynchronize(st);
+        ctx->timing_on = timing_saved;
+        if (rc_wm) return rc_wm;
+        if (e1 != hipSuccess || e2 != hipSuccess) { ctx->last_hip = (int)(e1 != hipSuccess ? e1 : e2); return ZL_EHIP; }
+        ctx->g16_h = d_h;
+        ctx->g16_h_n = N;
+        ctx->g16_z = d_zc;
+        return ZL_OK;
+    }
     // ---- the five MSMs ----------------------------------------------------------------------------------------------
     uint64_t part[5][ZL_PARTIAL_WORDS];
     const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
@@ -399,6 +413,136 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     }
     lap_us("proof normalised");
     return ZL_OK;
+}
+
+// ---- one proof over the G devices of an mctx ---------------------------------------------------------------------------
+// Rank g holds, on zl_mctx_ctx(m, g), bases handles with ITS contiguous slice of every query (zl_g16_shard); rank 0 also holds the constraint matrices.
+//   1. rank 0: assignment -> device, witness map (spmv, 7 NTTs) -> h                                        (groth16_prove_t, wm_only)
+//   2. every rank, on its own host thread: its slices of z and h arrive by device-to-device copy, then its five partial MSMs (a, b1, l, h in G1 and b2
+//      in G2) through the single-device pipeline (zl_msm_run) -> five un-normalised partial sums per rank
+//   3. host: the partials of each MSM are folded over the ranks (what an all-gather + fold does between processes: EC addition is not a collective's
+//      reduce op) and the proof is assembled exactly as the single-device prover does
+// Same proof, byte for byte, as zl_groth16_prove_resident with the same (r, s) (tests/test_gpu_multi.py).  Functional: the MSM phase of a proof shards like
+// any MSM (512 B of partials per rank and MSM); the witness map stays on one device (the NTTs of one proof are replicas work, not sharded work).
+template <class G1, class G2>
+static int groth16_prove_sharded_t(zl_mctx* m, const zl_g16_pk* pk, const zl_g16_shard* shards, const zl_r1cs_dev* cs, const uint64_t* assignment, unsigned flags,
+                                   const uint64_t* r, const uint64_t* s, zl_g16_proof* out) {
+    using FrP = typename G1::FrP;
+    using F1 = typename G1::F;
+    using F2 = typename G2::F;
+    const int G = zl_mctx_size(m);
+    zl_ctx* ctx0 = zl_mctx_ctx(m, 0);
+    const uint32_t ni = cs->n_instance, nw = cs->n_witness, nv = ni + nw;
+    unsigned log_n = 1;
+    while ((1ull << log_n) < (uint64_t)cs->n_constraints + ni) log_n++;
+    const size_t N = (size_t)1 << log_n;
+    // the slices must tile [0, nv), [0, nw) and [0, N - 1) in rank order
+    size_t v = 0, w = 0, hq = 0;
+    for (int g = 0; g < G; g++) {
+        if (shards[g].var_first != v || shards[g].wit_first != w || shards[g].h_first != hq) return ZL_EINVAL;
+        v += shards[g].var_count; w += shards[g].wit_count; hq += shards[g].h_count;
+    }
+    if (v != nv || w != nw || hq != N - 1) return ZL_EINVAL;
+    int rc;
+    ZL_HIP(ctx0, hipSetDevice(ctx0->device));
+    if ((rc = groth16_prove_t<G1, G2>(ctx0, pk, cs, assignment, flags, r, s, nullptr, nullptr, true))) return rc;
+    const unsigned char* d_z0 = reinterpret_cast<const unsigned char*>(ctx0->g16_z);
+    const unsigned char* d_h0 = reinterpret_cast<const unsigned char*>(ctx0->g16_h);
+    std::vector<std::array<uint64_t, 5 * ZL_PARTIAL_WORDS>> parts((size_t)G);
+    std::vector<int> rcs((size_t)G, ZL_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; g++)
+        th.emplace_back([&, g]() {
+            zl_ctx* c = zl_mctx_ctx(m, g);
+            const zl_g16_shard& sh = shards[g];
+            auto fail = [&](int code) { rcs[(size_t)g] = code; };
+            if (hipSetDevice(c->device) != hipSuccess) return fail(ZL_EHIP);
+            // this rank's scalars: [variables | witnesses | quotient coefficients], canonical, copied from rank 0's device
+            void* d = nullptr;
+            const size_t nvar = sh.var_count, nwit = sh.wit_count, nh = sh.h_count;
+            int r2 = zl_scratch_get(c, 7, (nvar + nwit + nh + 1) * 32, &d);
+            if (r2) return fail(r2);
+            unsigned char* ds = reinterpret_cast<unsigned char*>(d);
+            hipError_t e = hipSuccess;
+            if (nvar) e = hipMemcpyPeerAsync(ds, c->device, d_z0 + sh.var_first * 32, ctx0->device, nvar * 32, c->stream);
+            if (e == hipSuccess && nwit) e = hipMemcpyPeerAsync(ds + nvar * 32, c->device, d_z0 + ((size_t)ni + sh.wit_first) * 32, ctx0->device, nwit * 32, c->stream);
+            if (e == hipSuccess && nh) e = hipMemcpyPeerAsync(ds + (nvar + nwit) * 32, c->device, d_h0 + sh.h_first * 32, ctx0->device, nh * 32, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->last_hip = (int)e; return fail(ZL_EHIP); }
+            const struct { uint64_t handle; int group; const unsigned char* sc; size_t n; } jobs[5] = {
+                {sh.a_query, ZL_G1, ds, nvar}, {sh.b_g1_query, ZL_G1, ds, nvar}, {sh.h_query, ZL_G1, ds + (nvar + nwit) * 32, nh},
+                {sh.l_query, ZL_G1, ds + nvar * 32, nwit}, {sh.b_g2_query, ZL_G2, ds, nvar}};
+            for (int j = 0; j < 5; j++) {
+                uint64_t* outp = parts[(size_t)g].data() + (size_t)j * ZL_PARTIAL_WORDS;
+                memset(outp, 0, ZL_PARTIAL_WORDS * 8);
+                if (jobs[j].n == 0) {  // an empty slice contributes the point at infinity
+                    if (jobs[j].group == ZL_G1) { const XYZZ<F1> z = XYZZ<F1>::inf(); memcpy(outp, &z, sizeof z); }
+                    else { const XYZZ<F2> z = XYZZ<F2>::inf(); memcpy(outp, &z, sizeof z); }
+                    continue;
+                }
+                auto it = c->bases.find(jobs[j].handle);
+                if (it == c->bases.end() || it->second.curve != (int)pk->curve || it->second.group != jobs[j].group || it->second.n < jobs[j].n) return fail(ZL_EHANDLE);
+                r2 = ZL_DISPATCH(pk->curve, jobs[j].group, zl_msm_run, c, it->second, 0, jobs[j].sc, jobs[j].n, outp);
+                if (r2) return fail(r2);
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[(size_t)g]) return rcs[(size_t)g];
+    // fold over the ranks, then the assembly of create_proof_with_assignment
+    XYZZ<F1> sum1[4];
+    XYZZ<F2> sum2 = XYZZ<F2>::inf();
+    for (auto& x : sum1) x = XYZZ<F1>::inf();
+    for (int g = 0; g < G; g++) {
+        for (int j = 0; j < 4; j++) zl::add_full(sum1[j], from_partial<F1>(parts[(size_t)g].data() + (size_t)j * ZL_PARTIAL_WORDS));
+        zl::add_full(sum2, from_partial<F2>(parts[(size_t)g].data() + (size_t)4 * ZL_PARTIAL_WORDS));
+    }
+    uint32_t rw[8], sw[8], rsw[8];
+    memcpy(rw, r, 32);
+    memcpy(sw, s, 32);
+    {
+        using FrF = Fp<FrP>;
+        FrF rm, sm;
+        memcpy(rm.l, rw, 32);
+        memcpy(sm.l, sw, 32);
+        const FrF rs = zl::from_mont(zl::mul(zl::to_mont(rm), zl::to_mont(sm)));
+        memcpy(rsw, rs.l, 32);
+    }
+    const XYZZ<F1> delta1 = affine_from_canon<G1>(pk->delta_g1);
+    const XYZZ<F2> delta2 = affine_from_canon<G2>(pk->delta_g2);
+    XYZZ<F1> g_a = zl::mul_scalar_w4(delta1, rw);           // A = alpha + sum z_i a_i + r delta
+    zl::add_full(g_a, sum1[0]);
+    zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
+    XYZZ<F1> g1_b = zl::mul_scalar_w4(delta1, sw);          // B1 = beta + sum z_i b_i + s delta
+    zl::add_full(g1_b, sum1[1]);
+    zl::add_full(g1_b, affine_from_canon<G1>(pk->beta_g1));
+    XYZZ<F2> g2_b = zl::mul_scalar_w4(delta2, sw);          // B = the same in G2
+    zl::add_full(g2_b, sum2);
+    zl::add_full(g2_b, affine_from_canon<G2>(pk->beta_g2));
+    XYZZ<F1> g_c = zl::mul_scalar_w4(g_a, sw);              // C = s A + r B1 - r s delta + sum_w z_w l_w + sum h_i H_i
+    zl::add_full(g_c, zl::mul_scalar_w4(g1_b, rw));
+    XYZZ<F1> rs_delta = zl::mul_scalar_w4(delta1, rsw);
+    zl::neg_inplace(rs_delta);
+    zl::add_full(g_c, rs_delta);
+    zl::add_full(g_c, sum1[3]);
+    zl::add_full(g_c, sum1[2]);
+    memset(out, 0, sizeof *out);
+    store_canon<G1>(out->a, &out->a_inf, g_a);
+    store_canon<G2>(out->b, &out->b_inf, g2_b);
+    store_canon<G1>(out->c, &out->c_inf, g_c);
+    return ZL_OK;
+}
+extern "C" int zl_groth16_prove_sharded(zl_mctx* m, const zl_g16_pk* pk, const zl_g16_shard* shards, uint64_t r1cs_handle_rank0, const uint64_t* assignment,
+                                        unsigned flags, const uint64_t* r, const uint64_t* s, zl_g16_proof* out) {
+    if (!m || !pk || !shards || !assignment || !r || !s || !out || (flags & ~ZL_MONT)) return ZL_EINVAL;
+    if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
+    zl_ctx* ctx0 = zl_mctx_ctx(m, 0);
+    if (!ctx0) return ZL_EINVAL;
+    auto it = ctx0->r1cs.find(r1cs_handle_rank0);
+    if (it == ctx0->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_sharded_t<BlsG1, BlsG2>(m, pk, shards, &it->second, assignment, flags, r, s, out);
+    if (pk->curve == ZL_BN254) return groth16_prove_sharded_t<BnG1, BnG2>(m, pk, shards, &it->second, assignment, flags, r, s, out);
+    return ZL_EINVAL;
 }
 
 // Full structural validation of a caller-supplied CSR, once per upload (O(nnz) on the host): row_ptr starts at 0 and is monotone,

@@ -5,6 +5,7 @@ Bit-exact against the oracle's single-device answers."""
 import numpy as np
 import pytest
 
+import groth16_util as gu
 import oracle_lib as ol
 from oracle_lib import po
 from openzl_amd import MultiBackend
@@ -121,3 +122,24 @@ def test_msm_sharded_single_rank_through_rccl(monkeypatch):
         mb.ranks[0].bases_free(h)
     finally:
         mb.close()
+
+
+@pytest.mark.parametrize("curve,k,G,cuts", [(po.BLS12_381, 8, 2, None), (po.BLS12_381, 8, 4, None), (po.BN254, 8, 4, None), (po.BLS12_381, 1, 4, (0.0, 0.1, 0.1)),
+                                             (po.BLS12_381, 64, 3, None)], ids=["bls-k8-G2", "bls-k8-G4", "bn254-k8-G4", "bls-k1-G4-empty-slices", "bls-k64-G3"])
+def test_groth16_one_proof_over_virtual_ranks(curve, k, G, cuts):
+    """ONE proof over the G ranks of an mctx (zl_groth16_prove_sharded): every rank holds a contiguous slice of each of the five
+    queries, rank 0 runs the witness map, every rank its five partial MSMs, the host folds and assembles -- the proof must equal the CPU oracle's (and hence
+    the single-device prover's) for the same (r, s), byte for byte, for equal cuts, for three ranks (slices that are no power of two) and for cuts that leave a
+    rank with EMPTY slices (rank 0 with none of the points: it still runs the witness map).  Virtual ranks on GPU 0: RCCL plays no part here, the exchange of a
+    proof is the device-to-device copies of the z / h slices and 5 x 512 B of partials per rank."""
+    import test_groth16 as tg
+
+    cs, pk, arrays, z, r, s = tg._case(curve, k)
+    mb = MultiBackend([0] * G)
+    try:
+        got = mb.groth16_prove_sharded(curve.cid, pk, arrays, z, r, s, cuts=cuts)
+    finally:
+        mb.close()
+    exp, _ = gu.oracle_prove(curve, arrays, z, pk, r, s, threads=8)
+    for g_, e in zip(got, exp):
+        assert np.array_equal(np.asarray(g_), np.asarray(e))

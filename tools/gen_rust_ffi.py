@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "plugins", "arkworks-mi355x", "src", "ffi.rs")
 SCALAR = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "size_t": "usize", "long": "core::ffi::c_long", "uint64_t": "u64", "uint32_t": "u32",
           "uint8_t": "u8", "float": "f32", "char": "core::ffi::c_char", "void": "core::ffi::c_void", "zl_curve_t": "i32", "zl_group_t": "i32"}
 OPAQUE = ["zl_ctx", "zl_mctx", "zl_circuit", "zl_g16_keys"]
-STRUCTS = ["zl_r1cs", "zl_g16_pk", "zl_g16_proof", "zl_timing"]
+STRUCTS = ["zl_r1cs", "zl_g16_pk", "zl_g16_shard", "zl_g16_proof", "zl_timing"]
 
 
 def strip_comments(text: str) -> str:
