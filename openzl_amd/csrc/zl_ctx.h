@@ -164,6 +164,7 @@ struct zl_ctx {
     zl_worker* workers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // persistent host threads of this ctx: 0 witness-map issue, 1 G2 MSM (Groth16); 2..5 one per lane stream (side-by-side MSM batches)
     void* g16_h = nullptr;  // quotient polynomial of the last zl_groth16_prove (inside scratch slot 8; reset when the next proof starts)
     size_t g16_h_n = 0;
+    int ntt_fit_beside = 0;  // this ctx's transforms run beside a kernel that leaves 96 registers per SIMD (a proof's witness map: ctx->aux2): use the capped passes (zl_ntt.hip)
     void* g16_z = nullptr;  // the canonical assignment of the last witness-map-only run (sharded proofs: the other ranks copy their slices from here)
     // MEASUREMENT ONLY (zl_test_acc_clock): when non-null, large G1 accumulations run as k_msm_accumulate_clk and leave four clock reads per wave here
     void* acc_clk = nullptr;

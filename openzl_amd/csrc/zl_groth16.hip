@@ -212,6 +212,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
     }
     zl_ctx* wm = ctx->aux2;
+    wm->ntt_fit_beside = wm_only ? 0 : 1;  // the witness map of a whole proof runs beside the G2 accumulation; on its own (sharded proofs) it takes the faster passes
     hipStream_t s_wm = wm->stream;
     hipEvent_t ev_z = wm->ev[0], ev_h = wm->ev[1];
     ZL_HIP(ctx, hipEventRecord(ev_z, st));

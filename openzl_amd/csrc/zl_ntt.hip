@@ -398,8 +398,11 @@ __device__ __forceinline__ Fr28<P28> const28(WordsFn f) {
     return zl::unpack28r<P28>(w);
 }
 
-template <class FrP, bool LAST>
-__global__ void __launch_bounds__(NTT28_THREADS, 2) k_ntt_pass28(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
+// Two register budgets of the same kernel (round 5): MINB = 2 lets the compiler take the 101-104 registers the nine-limb pass wants (a transform on its own:
+// 2.13 ms at 2^24); MINB = 5 caps it at 96 (6 spilled dwords, 2.24 ms), which is what fits beside the 416-register G2 accumulation of a Groth16 proof -- the
+// witness map of a proof runs there (zl_ctx::ntt_fit_beside; uncapped passes waited 5 ms for the accumulation to end, profiles/r05_g16_ntt_regs_ab.log)
+template <class FrP, bool LAST, int MINB = 2>
+__global__ void __launch_bounds__(NTT28_THREADS, MINB) k_ntt_pass28(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
     using P28 = typename Fr28Of<FrP>::type;
     using E = Fr28<P28>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -827,8 +830,10 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     // tiles + tables can exceed the 64 KiB default dynamic-LDS limit (gfx950 has 160 KiB per CU); per device, so set per call
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass28<FrP, false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ctx->timing_on) ZL_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     uint32_t S_prev = 0;
     // byte budget of the per-(size, direction) tables of this ctx -- the last pass's combined twiddles (N x 32 B) and the middle passes' row tables (<= 32 MB each):
@@ -948,8 +953,13 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
             // tile + butterfly roots (+ the per-row twiddles of a middle pass that has no row table): 45 KB at s = 8 -> three workgroups per CU
             using E28 = Fr28<typename Fr28Of<FrP>::type>;
             const size_t lds28 = (size_t)E28::L * 4 * NTT28_TILE + sizeof(E28) * ((a.w_unpacked ? 0 : ((size_t)1 << a.s) / 2) + ((!last && p > 1 && !a.row_tw) ? ((size_t)1 << a.s) : 0));
-            if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
-            else hipLaunchKernelGGL((k_ntt_pass28<FrP, false>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+            if (ctx->ntt_fit_beside && NTT28_THREADS == 256) {
+                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 5>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 5>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+            } else {
+                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 2>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 2>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+            }
         } else {
         const size_t lds = (size_t)F::N * 4 * NTT_TILE + sizeof(F) * (((size_t)1 << a.s) / 2 + ((size_t)1 << a.s));
         if (last) hipLaunchKernelGGL((k_ntt_pass<FrP, true>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
