@@ -216,6 +216,11 @@ typedef struct zl_circuit zl_circuit;   /* an R1CS<F> compiler in proof mode hol
 typedef struct zl_g16_keys zl_g16_keys; /* Groth16<E>::ProvingContext (+ the setup trapdoor, kept for exponent checks) */
 /* k chained Poseidon arity-2 hashes over the curve's Fr: h_1 = H(x0,x1), h_{j+1} = H(h_j,x1), public input h_k */
 int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out);
+/* The same circuit run by a WITNESS-ONLY compiler (ark-relations' SynthesisMode::Prove { construct_matrices: false }): variables with their values, no linear
+ * combinations, no constraint rows -- ~10x faster to synthesise.  zl_groth16_prove_circuit takes it for keys that already hold the circuit's matrices (compiled
+ * for it, or bound by an earlier proof with a full circuit); zl_circuit_export then yields an empty CSR and the assignment, zl_circuit_is_satisfied checks only
+ * the enforced equalities. */
+int zl_circuit_poseidon_chain_witness(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out);
 void zl_circuit_free(zl_circuit* c);
 /* CSR view + assignment (pointers stay valid until zl_circuit_free) */
 int zl_circuit_export(const zl_circuit* c, zl_r1cs* view, const uint64_t** assignment);

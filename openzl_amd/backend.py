@@ -24,7 +24,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_poseidon_chain_witness", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None):
     L.zl_circuit_free.argtypes = [vp]
     L.zl_circuit_free.restype = None
     L.zl_circuit_export.argtypes = [vp, C.POINTER(R1csC), C.POINTER(u64p)]
+    L.zl_circuit_poseidon_chain_witness.argtypes = L.zl_circuit_poseidon_chain.argtypes
     L.zl_circuit_is_satisfied.argtypes = [vp]
     L.zl_poseidon_permute.argtypes = [C.c_int, u64p]
     L.zl_groth16_compile.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
@@ -734,13 +735,16 @@ def proof_from_bytes(curve: int, data: bytes):
 class Circuit:
     """R1CS<F> compiler in proof mode holding the config-5 Poseidon-chain circuit (host code, no GPU)."""
 
-    def __init__(self, curve: int, k: int, x0: int = 1, x1: int = 2):
+    def __init__(self, curve: int, k: int, x0: int = 1, x1: int = 2, witness_only: bool = False):
+        """witness_only: run the circuit in a witness-only compiler (R1CS::for_witness: values, no rows) -- for proofs against keys that already hold the matrices"""
         self.L = load_library()
         self.curve = curve
+        self.witness_only = witness_only
         self._c = C.c_void_p()
         a = np.array([[(x0 >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64)
         b = np.array([[(x1 >> (64 * j)) & (2**64 - 1) for j in range(4)]], dtype=np.uint64)
-        rc = self.L.zl_circuit_poseidon_chain(curve, k, _p64(a), _p64(b), C.byref(self._c))
+        fn = self.L.zl_circuit_poseidon_chain_witness if witness_only else self.L.zl_circuit_poseidon_chain
+        rc = fn(curve, k, _p64(a), _p64(b), C.byref(self._c))
         if rc:
             raise BackendError(rc, "zl_circuit_poseidon_chain")
         self._view = R1csC()
@@ -762,8 +766,11 @@ class Circuit:
         for m, key in enumerate("ABC"):
             ptr = np.ctypeslib.as_array(v.row_ptr[m], shape=(v.n_constraints + 1,)).copy()
             nnz = int(ptr[-1])
-            col = np.ctypeslib.as_array(v.col[m], shape=(max(nnz, 1),))[:nnz].copy()
-            val = np.ctypeslib.as_array(v.val[m], shape=(max(nnz, 1) * 4,))[: nnz * 4].copy().reshape(nnz, 4)
+            if nnz == 0:  # (a witness-only circuit exports no rows)
+                col, val = np.zeros(0, dtype=np.uint32), np.zeros((0, 4), dtype=np.uint64)
+            else:
+                col = np.ctypeslib.as_array(v.col[m], shape=(nnz,)).copy()
+                val = np.ctypeslib.as_array(v.val[m], shape=(nnz * 4,)).copy().reshape(nnz, 4)
             out[key] = (ptr, col, val)
         nv = v.n_instance + v.n_witness
         out["assignment"] = np.ctypeslib.as_array(self._zp, shape=(nv * 4,)).copy().reshape(nv, 4)
@@ -836,12 +843,13 @@ class Groth16Keys:
             d[k] = np.ctypeslib.as_array(getattr(self.pk, k), shape=(n,)).copy()
         return d
 
-    def prove(self, seed: int):
-        """Groth16::prove(context, compiler, rng=SplitMix64(seed)) -> ((a, a_inf, b, b_inf, c, c_inf), r, s)"""
+    def prove(self, seed: int, circuit: Optional["Circuit"] = None):
+        """Groth16::prove(context, compiler, rng=SplitMix64(seed)) -> ((a, a_inf, b, b_inf, c, c_inf), r, s); circuit: another compiler of the SAME circuit
+        (e.g. a witness-only one with a new witness) instead of the one the keys were built with"""
         proof = G16ProofC()
         r = np.zeros(4, dtype=np.uint64)
         s = np.zeros(4, dtype=np.uint64)
-        self.backend._check(self.L.zl_groth16_prove_circuit(self.backend._ctx, self._k, self.circuit._c, seed, C.byref(proof), _p64(r), _p64(s)),
+        self.backend._check(self.L.zl_groth16_prove_circuit(self.backend._ctx, self._k, (circuit or self.circuit)._c, seed, C.byref(proof), _p64(r), _p64(s)),
                             "zl_groth16_prove_circuit")
         nq = FQ_LIMBS[self.circuit.curve]
         return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,

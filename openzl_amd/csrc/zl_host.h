@@ -103,6 +103,7 @@ struct FpVar {
     using F = Fp<FrP>;
     LinearCombination<FrP> lc;
     F value;  // Montgomery; meaningful in proof mode only
+    bool konst = false;  // a constant (no variable in it): tracked beside lc because a witness-only compiler keeps no linear combinations
 };
 
 // ---- R1CS<F>: the plugin's compiler (constraint/mod.rs:64-108) -----------------------------------------------------------
@@ -111,39 +112,60 @@ class R1CS {
 public:
     using F = Fp<FrP>;
     using LC = LinearCombination<FrP>;
-    enum class Mode { Setup, Prove };
+    enum class Mode { Setup, Prove, ProveWitnessOnly };
     static R1CS for_contexts() { return R1CS(Mode::Setup); }  // SynthesisMode::Setup (constraint/mod.rs:84-90)
     static R1CS for_proofs() { return R1CS(Mode::Prove); }    // SynthesisMode::Prove (constraint/mod.rs:94-99)
+    // ark-relations' SynthesisMode::Prove { construct_matrices: false }: the circuit code runs, variables are allocated with their values, but no linear
+    // combination is formed and no constraint row stored.  What a prover needs per proof once its ProvingContext holds the circuit's matrices on the device
+    // (they are static per circuit): Groth16::prove takes such a compiler for a BOUND context and ships its assignment.  (round 5: 958 465 constraints
+    // synthesise in ~0.1 s this way against 1.1 s with the rows; the binding cannot be checked -- no rows to fingerprint -- so a witness-only compiler of another
+    // circuit with the same variable counts yields a proof that does not verify, as a wrong witness would.)
+    static R1CS for_witness() { return R1CS(Mode::ProveWitnessOnly); }
+    bool witness_only() const { return mode_ == Mode::ProveWitnessOnly; }
 
     // allocation: Public -> instance variable (new_input), Secret -> witness (new_witness) (constraint/mod.rs:302-338)
     FpVar<FrP> new_input(const F& value_mont) {
         instance_.push_back(value_mont);
-        return FpVar<FrP>{LC::variable((uint32_t)instance_.size() - 1), value_mont};
+        if (witness_only()) return FpVar<FrP>{LC{}, value_mont, false};
+        return FpVar<FrP>{LC::variable((uint32_t)instance_.size() - 1), value_mont, false};
     }
     FpVar<FrP> new_witness(const F& value_mont) {
         witness_.push_back(value_mont);
-        return FpVar<FrP>{LC::variable(kWitnessBit | ((uint32_t)witness_.size() - 1)), value_mont};
+        if (witness_only()) return FpVar<FrP>{LC{}, value_mont, false};
+        return FpVar<FrP>{LC::variable(kWitnessBit | ((uint32_t)witness_.size() - 1)), value_mont, false};
     }
-    FpVar<FrP> constant(const F& c_mont) const { return FpVar<FrP>{LC::constant(c_mont), c_mont}; }
+    FpVar<FrP> constant(const F& c_mont) const { return FpVar<FrP>{witness_only() ? LC{} : LC::constant(c_mont), c_mont, true}; }
     // linear operations: no constraints (plugins/arkworks/src/poseidon/mod.rs:225-274)
-    FpVar<FrP> add(const FpVar<FrP>& a, const FpVar<FrP>& b) const { return FpVar<FrP>{a.lc.add(b.lc), zl::add(a.value, b.value)}; }
-    FpVar<FrP> add_const(const FpVar<FrP>& a, const F& c) const { return FpVar<FrP>{a.lc.add(LC::constant(c)), zl::add(a.value, c)}; }
-    FpVar<FrP> mul_const(const FpVar<FrP>& a, const F& c) const { return FpVar<FrP>{a.lc.scale(c), zl::mul(a.value, c)}; }
+    FpVar<FrP> add(const FpVar<FrP>& a, const FpVar<FrP>& b) const {
+        if (witness_only()) return FpVar<FrP>{LC{}, zl::add(a.value, b.value), a.konst && b.konst};
+        return FpVar<FrP>{a.lc.add(b.lc), zl::add(a.value, b.value), a.konst && b.konst};
+    }
+    FpVar<FrP> add_const(const FpVar<FrP>& a, const F& c) const {
+        if (witness_only()) return FpVar<FrP>{LC{}, zl::add(a.value, c), a.konst};
+        return FpVar<FrP>{a.lc.add(LC::constant(c)), zl::add(a.value, c), a.konst};
+    }
+    FpVar<FrP> mul_const(const FpVar<FrP>& a, const F& c) const {
+        if (witness_only()) return FpVar<FrP>{LC{}, zl::mul(a.value, c), a.konst};
+        return FpVar<FrP>{a.lc.scale(c), zl::mul(a.value, c), a.konst};
+    }
     // multiplication: one constraint a * b = out with a fresh witness; constants fold
     FpVar<FrP> mul(const FpVar<FrP>& a, const FpVar<FrP>& b) {
-        if (a.lc.is_constant()) return mul_const(b, a.value);
-        if (b.lc.is_constant()) return mul_const(a, b.value);
+        if (witness_only() ? a.konst : a.lc.is_constant()) return mul_const(b, a.value);
+        if (witness_only() ? b.konst : b.lc.is_constant()) return mul_const(a, b.value);
         FpVar<FrP> out = new_witness(zl::mul(a.value, b.value));
+        if (witness_only()) return out;
         A_.push_back(a.lc);
         B_.push_back(b.lc);
         C_.push_back(out.lc);
         return out;
     }
     void enforce_equal(const FpVar<FrP>& a, const FpVar<FrP>& b) {  // a * 1 = b
+        if (witness_only()) { equal_ok_ = equal_ok_ && a.value == b.value; return; }
         A_.push_back(a.lc);
         B_.push_back(LC::constant(F::one()));
         C_.push_back(b.lc);
     }
+    bool equalities_hold() const { return equal_ok_; }  // witness-only: every enforce_equal saw equal values
     // Measure (openzl-crypto/src/constraint.rs:151-188; plugin impl constraint/mod.rs:169-177)
     size_t constraint_count() const { return A_.size(); }
     size_t public_variable_count() const { return instance_.size() - 1; }
@@ -160,6 +182,7 @@ public:
         return acc;
     }
     bool is_satisfied() const {
+        if (witness_only()) return equal_ok_;  // no rows: only the enforced equalities can be checked
         for (size_t i = 0; i < A_.size(); i++)
             if (zl::mul(eval(A_[i]), eval(B_[i])) != eval(C_[i])) return false;
         return true;
@@ -211,6 +234,7 @@ public:
 private:
     explicit R1CS(Mode m) : mode_(m) { instance_.push_back(F::one()); }
     Mode mode_;
+    bool equal_ok_ = true;
     std::vector<F> instance_, witness_;
     std::vector<LC> A_, B_, C_;
     mutable uint64_t digest_ = 0;

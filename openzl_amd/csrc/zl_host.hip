@@ -545,12 +545,13 @@ void Groth16<E>::release(ProvingContext& pc) {
 template <class E>
 Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, const Compiler& cs, SplitMix64& rng, F* r_out, F* s_out) {
     Result<Proof> res{false, {}, Error{ZL_EINVAL}};
-    if (cs.mode() != Compiler::Mode::Prove) return res;  // the reference panics when a setup-mode compiler reaches prove
+    if (cs.mode() == Compiler::Mode::Setup) return res;  // the reference panics when a setup-mode compiler reaches prove
     if (cs.num_instance_variables() != pc.n_instance || cs.secret_variable_count() != pc.n_witness) return res;
+    if (cs.witness_only() && !pc.r1cs) return res;  // a witness-only compiler has no rows to bind an unbound context to
     const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
     if (r_out) *r_out = r;
     if (s_out) *s_out = s;
-    if (pc.r1cs && (cs.constraint_count() != pc.n_constraints || cs.structure_digest() != pc.circuit_digest)) return res;  // not the bound circuit
+    if (pc.r1cs && !cs.witness_only() && (cs.constraint_count() != pc.n_constraints || cs.structure_digest() != pc.circuit_digest)) return res;  // not the bound circuit
     if (!pc.r1cs) {
         // a context decoded from bytes (Groth16::decode) does not know its circuit: the first proof uploads the matrices, after checking
         // that the compiler's evaluation domain is the one the key's h_query was generated for
@@ -590,6 +591,20 @@ template struct R1csExport<BLS12_381_Fr>;
 template struct R1csExport<BN254_Fr>;
 
 // config 5 circuit: h_1 = H(x0, x1), h_{j+1} = H(h_j, x1), public input h_k  
+// the same circuit code run by a witness-only compiler (R1CS::for_witness): every link through the gadget, values only
+template <class FrP>
+static R1CS<FrP> poseidon_chain_witness(uint32_t k, const Fp<FrP>& x0_canon, const Fp<FrP>& x1_canon) {
+    using F = Fp<FrP>;
+    static const poseidon::Constants<FrP> consts;
+    R1CS<FrP> cs = R1CS<FrP>::for_witness();
+    FpVar<FrP> cur = cs.new_witness(zl::to_mont(x0_canon));
+    const FpVar<FrP> b = cs.new_witness(zl::to_mont(x1_canon));
+    for (uint32_t j = 0; j < k; j++) cur = poseidon::hash(consts, cur, b, cs);
+    // the public input is the chain's output (the instance block is its own vector: allocating it last changes no index)
+    const FpVar<FrP> out_pub = cs.new_input(cur.value);
+    cs.enforce_equal(cur, out_pub);
+    return cs;
+}
 template <class FrP>
 static R1CS<FrP> poseidon_chain(uint32_t k, const Fp<FrP>& x0_canon, const Fp<FrP>& x1_canon) {
     using F = Fp<FrP>;
@@ -694,6 +709,26 @@ int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, 
         Fp<BN254_Fr> a, b;
         memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
         c->bn = new R1CS<BN254_Fr>(poseidon_chain<BN254_Fr>(k, a, b));
+        c->ex_bn.build(*c->bn);
+    }
+    *out = c;
+    return ZL_OK;
+}
+// the same circuit synthesised by a witness-only compiler (values, no rows): for proofs against a context that already holds the circuit's matrices
+int zl_circuit_poseidon_chain_witness(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out) {
+    if (!out || !x0 || !x1 || k == 0 || (curve != ZL_BLS12_381 && curve != ZL_BN254)) return ZL_EINVAL;
+    zl_circuit* c = new (std::nothrow) zl_circuit();
+    if (!c) return ZL_ENOMEM;
+    c->curve = curve;
+    if (curve == ZL_BLS12_381) {
+        Fp<BLS12_381_Fr> a, b;
+        memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
+        c->bls = new R1CS<BLS12_381_Fr>(poseidon_chain_witness<BLS12_381_Fr>(k, a, b));
+        c->ex_bls.build(*c->bls);  // (no rows: only the assignment is exported)
+    } else {
+        Fp<BN254_Fr> a, b;
+        memcpy(a.l, x0, 32); memcpy(b.l, x1, 32);
+        c->bn = new R1CS<BN254_Fr>(poseidon_chain_witness<BN254_Fr>(k, a, b));
         c->ex_bn.build(*c->bn);
     }
     *out = c;

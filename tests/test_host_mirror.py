@@ -114,3 +114,58 @@ def test_proving_context_refuses_a_different_circuit_of_the_same_shape(backend):
         keys.close()
         for c in (c1, c2, c3):
             c.close()
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_witness_only_compiler_yields_the_same_assignment(curve):
+    """R1CS::for_witness (ark-relations' SynthesisMode::Prove { construct_matrices: false }): the circuit code runs, every variable gets its value, no linear
+    combination is formed and no row stored -- the assignment must be the full compiler's, element for element, and the enforced equality must hold."""
+    for k, x0, x1 in ((1, 1, 2), (3, 7, 0), (5, curve.fr.p - 1, 12345)):
+        full, wit = Circuit(curve.cid, k, x0=x0, x1=x1), Circuit(curve.cid, k, x0=x0, x1=x1, witness_only=True)
+        try:
+            fa, wa = full.arrays(), wit.arrays()
+            assert wit.shape == (0, full.shape[1], full.shape[2]) and wit.is_satisfied() and full.is_satisfied()
+            assert np.array_equal(fa["assignment"], wa["assignment"])
+            assert all(wa[m][0].tolist() == [0] and wa[m][1].size == 0 for m in "ABC")
+        finally:
+            full.close()
+            wit.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_prove_with_a_witness_only_compiler(backend, curve):
+    """A context that holds its circuit's matrices proves from a witness-only compiler: the same proof as from the full compiler for the same witness and rng,
+    a verifying proof for a NEW witness (what a prover does per proof: the matrices are static), and refusals where the binding cannot hold: another shape,
+    or a context decoded from bytes that has not seen a full compiler yet."""
+    from openzl_amd import BackendError
+
+    k = 3
+    full = Circuit(curve.cid, k)
+    keys = Groth16Keys(backend, full, seed=21)
+    w_same = Circuit(curve.cid, k, witness_only=True)
+    w_new = Circuit(curve.cid, k, x0=99, x1=77, witness_only=True)
+    w_shape = Circuit(curve.cid, k + 1, witness_only=True)
+    decoded = None
+    try:
+        p_full, r1, s1 = keys.prove(seed=5)
+        p_wit, r2, s2 = keys.prove(seed=5, circuit=w_same)
+        assert (r1 == r2).all() and (s1 == s2).all()
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(p_full, p_wit))
+        p_new, _, _ = keys.prove(seed=6, circuit=w_new)
+        pub_new = w_new.arrays()["assignment"][1:2]
+        assert keys.verify(p_new, pub_new) and not keys.verify(p_new, full.arrays()["assignment"][1:2])
+        with pytest.raises(BackendError):
+            keys.prove(seed=7, circuit=w_shape)
+        decoded = Groth16Keys.from_bytes(backend, full, keys.to_bytes())
+        with pytest.raises(BackendError):
+            decoded.prove(seed=8, circuit=w_same)       # unbound: no rows to bind to
+        decoded.prove(seed=8)                            # the full compiler binds it ...
+        p_dec, _, _ = decoded.prove(seed=5, circuit=w_same)  # ... and then the witness-only one proves
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(p_full, p_dec))
+    finally:
+        if decoded is not None:
+            decoded.close()
+        keys.close()
+        for c in (full, w_same, w_new, w_shape):
+            c.close()
