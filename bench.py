@@ -338,7 +338,7 @@ class Run:
 
 
 class MsmInputs:
-    """One rank's shard of a synthetic MSM: bases P_i = k_i G with known 63-bit k_i from the device generator (resident in HBM), two
+    """One rank's shard of a synthetic MSM: bases P_i = k_i G with known k_i uniform in [1, r) (so uniform points of the group) from the device generator (resident in HBM), two
     different scalar vectors (consecutive steps of a pipelined batch alternate between them, so a cross-job buffer race in the
     three-stream pipeline cannot hide behind identical inputs), and the exact expected answers (sum s_i k_i mod r) G -- of this shard
     and of all shards together -- from one O(n) dot product per vector."""
@@ -349,20 +349,18 @@ class MsmInputs:
 
         torch, be = R.torch, R.be
         self.R, self.n, self.curve = R, n, curve or ZL_BLS12_381
-        rng = np.random.Generator(np.random.PCG64(seed * 7919 + 1000 + R.rank))
-        self.k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-        k = np.zeros((n, 4), dtype=np.uint64)
-        k[:, 0] = self.k64
+        k = random_scalars_lt_r(n, seed * 7919 + 1000 + R.rank, r_mod, bits)  # uniform in [0, r): P_i = k_i G is then a uniform point of the group
+        k[~k.any(axis=1), 0] = 1
         t0 = time.perf_counter()
         self.h = be.bases_generate(self.curve, k)
         self.t_generate = time.perf_counter() - t0
-        del k
         self.vecs = [random_scalars_lt_r(n, seed * 7919 + 2000 + R.rank, r_mod, bits), random_scalars_lt_r(n, seed * 7919 + 4000 + R.rank, r_mod, bits)]
         if R.args.scalars == "skewed":
             self.vecs = [skewed(v) for v in self.vecs]
         self.d_vecs = [torch.from_numpy(v.view(np.int64)).to(R.dev) for v in self.vecs]
         torch.cuda.synchronize()
-        self.dots = [dot_mod_r(v, self.k64, r_mod) for v in self.vecs]
+        self.k64 = k  # (n, 4) limbs: the name is historical (rounds 1-4 drew 63-bit multipliers)
+        self.dots = [dot_mod_r(v, k, r_mod) for v in self.vecs]
         self.exp_xy = [expected_point(be, self.curve, d) for d in self.dots]   # this rank's shard
         self.exp_all = self.exp_xy                                              # all ranks together
         if R.world > 1 and not local_only:
@@ -688,15 +686,12 @@ def mctx_run(args, devices, log_n, ntt_log_m, steps, warmup, g16_k=None):
     try:
         for g in range(G):
             dev = torch.device("cuda", devices[g])
-            rng = np.random.Generator(np.random.PCG64(77000 + g))
-            k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-            k = np.zeros((n, 4), dtype=np.uint64)
-            k[:, 0] = k64
+            k = random_scalars_lt_r(n, 77000 + g)
             hs.append(mb.ranks[g].bases_generate(ZL_BLS12_381, k))
             vs = [random_scalars_lt_r(n, 78000 + 2 * g), random_scalars_lt_r(n, 78001 + 2 * g)]
             d_s.append([torch.from_numpy(v.view(np.int64)).to(dev) for v in vs])
             for j in (0, 1):
-                dots[j] = (dots[j] + dot_mod_r(vs[j], k64, R_BLS)) % R_BLS
+                dots[j] = (dots[j] + dot_mod_r(vs[j], k, R_BLS)) % R_BLS
             del k, vs
         for g in set(devices):
             torch.cuda.synchronize(g)
@@ -1344,7 +1339,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"bls12_381_g1_msm_2^{args.log_n}_per_gpu", "points_per_gpu": n, "curve": "BLS12-381 G1",
                        "scalars": "uniform < r (255 bit)" if args.scalars == "uniform" else "50% zeros, 25% ones, 25% uniform",
-                       "bases": "k_i*G from a device generator, resident in HBM; NO per-key precomputation (what multi_scalar_mul(bases, scalars) is)",
+                       "bases": "k_i*G with k_i uniform in [1, r) (uniform points of the group, discrete logs known to the checker only) from a device generator, resident in HBM; NO per-key precomputation (what multi_scalar_mul(bases, scalars) is)",
                        "window_bits": cw, "windows": (256 + cw - 1) // cw,
                        "precomputed_table": "none (the fixed-key table mode is reported separately as msm_fixed_key)",
                        "parallelism": f"shard{world}" if world > 1 else "single",

@@ -284,10 +284,9 @@ def test_msm_known_discrete_log_bn254_2_22(backend, mode):
 
     curve = po.BN254
     n, r = 1 << 22, curve.fr.p
-    rng = np.random.Generator(np.random.PCG64(2254))
-    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-    k = np.zeros((n, 4), dtype=np.uint64)
-    k[:, 0] = k64
+    from openzl_amd.selfcheck import dot_mod_r
+
+    k = ol.random_scalars(curve, n, 2254)  # uniform in [0, r): uniform points of the group
     S = ol.random_scalars(curve, n, 2255)
     S[5] = 0
     S[6] = ol.ints_to_limbs([1], 4)[0]
@@ -301,8 +300,8 @@ def test_msm_known_discrete_log_bn254_2_22(backend, mode):
     got, inf = backend.msm_dev(h, d1.data_ptr(), n)
     parts = backend.msm_batch_partial_dev(h, [d1.data_ptr(), d2.data_ptr(), d1.data_ptr()], n)
     backend.bases_free(h)
-    exp1 = _oracle_point(curve, _dot_mod_r_u64k(S, k64, r))
-    exp2 = _oracle_point(curve, _dot_mod_r_u64k(S2, k64, r))
+    exp1 = _oracle_point(curve, dot_mod_r(S, k, r))
+    exp2 = _oracle_point(curve, dot_mod_r(S2, k, r))
     assert not inf and (got == exp1).all()
     for j, e in enumerate((exp1, exp2, exp1)):
         xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1])
@@ -322,9 +321,7 @@ def test_msm_wide_path_unaligned_adversarial(backend, case):
     r = curve.fr.p
     n = (1 << 21) + 12345
     rng = np.random.Generator(np.random.PCG64(4242))
-    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
-    k = np.zeros((n, 4), dtype=np.uint64)
-    k[:, 0] = k64
+    k = ol.random_scalars(curve, n, 4241)  # uniform in [0, r): uniform points of the group
     if case == "uniform":
         S = ol.random_scalars(curve, n, 4243)
     elif case == "all_equal":
@@ -336,7 +333,7 @@ def test_msm_wide_path_unaligned_adversarial(backend, case):
     h = backend.bases_generate(curve.cid, k)
     d_s = torch.from_numpy(np.ascontiguousarray(S).view(np.int64)).cuda()
     torch.cuda.synchronize()
-    exp = _oracle_point(curve, dot_mod_r(np.ascontiguousarray(S), k64, r))
+    exp = _oracle_point(curve, dot_mod_r(np.ascontiguousarray(S), k, r))
     try:
         for c in (0, 19):
             backend.set_msm_window(c)
@@ -373,16 +370,15 @@ def test_config4_eight_shards_of_2_23(backend):
     zl_partials_sum -- checked exactly against (sum s_i k_i) G."""
     import torch
 
+    from openzl_amd.selfcheck import dot_mod_r
+
     curve = po.BLS12_381
     shards, n_s = 8, 1 << 23
     r = curve.fr.p
     parts = []
     dot = 0
     for g in range(shards):
-        rng = np.random.Generator(np.random.PCG64(9000 + g))
-        k64 = rng.integers(1, 1 << 63, size=n_s, dtype=np.uint64)
-        k = np.zeros((n_s, 4), dtype=np.uint64)
-        k[:, 0] = k64
+        k = ol.random_scalars(curve, n_s, 9000 + g)  # uniform in [0, r): uniform points of the group
         S = ol.random_scalars(curve, n_s, 9100 + g)
         if g == 3:  # Groth16-witness-like shard: half zeros, a quarter ones
             S[: n_s // 2] = 0
@@ -393,7 +389,7 @@ def test_config4_eight_shards_of_2_23(backend):
         parts.append(backend.msm_partial_dev(h, d_s.data_ptr(), n_s))
         backend.bases_free(h)
         del d_s
-        dot = (dot + _dot_mod_r_u64k(S, k64, r)) % r
+        dot = (dot + dot_mod_r(S, k, r)) % r
     got, inf = backend.partials_sum(curve.cid, np.stack(parts))
     assert ol.limbs_to_point(curve, got, inf) == po.g1_mul(curve, dot, po.g1_generator(curve))
 
