@@ -1,6 +1,7 @@
 """ctypes binding of include/zl_backend.h.  No compute happens in Python and there is no CPU fallback."""
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 from typing import Optional, Tuple
@@ -22,7 +23,7 @@ u8p = C.POINTER(C.c_uint8)
 
 # every symbol include/zl_backend.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
+    "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_fork", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
     "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_poseidon_chain_witness", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
@@ -81,6 +82,7 @@ def load_library(path: Optional[str] = None):
     vp = C.c_void_p
     L.zl_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
     L.zl_ctx_destroy.argtypes = [vp]
+    L.zl_ctx_fork.argtypes = [vp, C.POINTER(vp)]
     L.zl_ctx_destroy.restype = None
     L.zl_ctx_set_stream.argtypes = [vp, vp]
     L.zl_ctx_sync.argtypes = [vp]
@@ -195,7 +197,18 @@ class Backend:
         if rc != 0:
             raise BackendError(rc, what, self.L.zl_strerror(rc).decode())
 
+    def fork(self) -> "Backend":
+        """zl_ctx_fork: a second prover lane on this device that reads this backend's device-resident keys (one lane per host thread; close it before this one)"""
+        child = Backend.__new__(Backend)
+        child.L, child._bases, child._owned, child._parent = self.L, collections.ChainMap({}, self._bases), True, self
+        child._ctx = C.c_void_p()
+        self._check(self.L.zl_ctx_fork(self._ctx, C.byref(child._ctx)), "zl_ctx_fork")
+        self.__dict__.setdefault("_forks", []).append(child)
+        return child
+
     def close(self):
+        for f in self.__dict__.pop("_forks", []):  # the lanes go first: they read this ctx's objects
+            f.close()
         if self._ctx:
             if self._owned:
                 self.L.zl_ctx_destroy(self._ctx)
@@ -843,13 +856,14 @@ class Groth16Keys:
             d[k] = np.ctypeslib.as_array(getattr(self.pk, k), shape=(n,)).copy()
         return d
 
-    def prove(self, seed: int, circuit: Optional["Circuit"] = None):
+    def prove(self, seed: int, circuit: Optional["Circuit"] = None, lane: Optional[Backend] = None):
         """Groth16::prove(context, compiler, rng=SplitMix64(seed)) -> ((a, a_inf, b, b_inf, c, c_inf), r, s); circuit: another compiler of the SAME circuit
-        (e.g. a witness-only one with a new witness) instead of the one the keys were built with"""
+        (e.g. a witness-only one with a new witness) instead of the one the keys were built with; lane: a fork() of the keys' backend to run on (one
+        per host thread: concurrent proofs over one device-resident key)"""
         proof = G16ProofC()
         r = np.zeros(4, dtype=np.uint64)
         s = np.zeros(4, dtype=np.uint64)
-        self.backend._check(self.L.zl_groth16_prove_circuit(self.backend._ctx, self._k, (circuit or self.circuit)._c, seed, C.byref(proof), _p64(r), _p64(s)),
+        self.backend._check(self.L.zl_groth16_prove_circuit((lane or self.backend)._ctx, self._k, (circuit or self.circuit)._c, seed, C.byref(proof), _p64(r), _p64(s)),
                             "zl_groth16_prove_circuit")
         nq = FQ_LIMBS[self.circuit.curve]
         return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,

@@ -63,8 +63,24 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
     return ZL_OK;
 }
 
+int zl_ctx_fork(zl_ctx* parent, zl_ctx** out) {
+    if (!parent || !out) return ZL_EINVAL;
+    *out = nullptr;
+    if (parent->parent) return ZL_EINVAL;  // one level: fork the root
+    zl_ctx* c = nullptr;
+    const int rc = zl_ctx_create(&c, parent->device);
+    if (rc) return rc;
+    c->parent = parent;
+    c->msm_c = parent->msm_c;
+    c->next_handle = ((uint64_t)(++parent->fork_seq) << 48) | 1;
+    parent->forks.fetch_add(1);
+    *out = c;
+    return ZL_OK;
+}
+
 void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->parent) ctx->parent->forks.fetch_sub(1);
     (void)hipSetDevice(ctx->device);
     for (zl_ctx* c : {ctx, ctx->aux, ctx->aux2}) {
         if (!c) continue;
@@ -158,8 +174,12 @@ int zl_bases_upload(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const void*
     b.group = group;
     int rc = ZL_DISPATCH(curve, group, zl_bases_upload, ctx, xy, n, stride_bytes, inf_offset, flags, &b);
     if (rc) return rc;
-    const uint64_t h = ctx->next_handle++;
-    ctx->bases[h] = b;
+    uint64_t h;
+    {
+        std::unique_lock<std::shared_mutex> lk(ctx->maps_mu);
+        h = ctx->next_handle++;
+        ctx->bases[h] = b;
+    }
     *handle_out = h;
     return ZL_OK;
 }
@@ -171,23 +191,28 @@ int zl_bases_generate(zl_ctx* ctx, zl_curve_t curve, zl_group_t group, const uin
     b.group = group;
     int rc = ZL_DISPATCH(curve, group, zl_bases_generate, ctx, k, n, &b);
     if (rc) return rc;
-    const uint64_t h = ctx->next_handle++;
-    ctx->bases[h] = b;
+    uint64_t h;
+    {
+        std::unique_lock<std::shared_mutex> lk(ctx->maps_mu);
+        h = ctx->next_handle++;
+        ctx->bases[h] = b;
+    }
     *handle_out = h;
     return ZL_OK;
 }
 int zl_bases_download(zl_ctx* ctx, uint64_t handle, size_t first, size_t count, uint64_t* out_xy) {
     if (!ctx || (!out_xy && count)) return ZL_EINVAL;
-    auto it = ctx->bases.find(handle);
-    if (it == ctx->bases.end()) return ZL_EHANDLE;
-    if (first > it->second.n || count > it->second.n - first) return ZL_EINVAL;
+    const zl_bases* bp = zl_find_bases(ctx, handle);
+    if (!bp) return ZL_EHANDLE;
+    if (first > bp->n || count > bp->n - first) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    return ZL_DISPATCH(it->second.curve, it->second.group, zl_bases_download, ctx, it->second, first, count, out_xy);
+    return ZL_DISPATCH(bp->curve, bp->group, zl_bases_download, ctx, *bp, first, count, out_xy);
 }
 int zl_bases_precompute(zl_ctx* ctx, uint64_t handle, int c) {
     if (!ctx || c < 0) return ZL_EINVAL;
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ZL_EHANDLE;
+    if (ctx->forks.load() > 0) return ZL_EINVAL;  // the table replaces what the lanes read: build it before forking
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     return ZL_DISPATCH(it->second.curve, it->second.group, zl_bases_precompute, ctx, it->second, c);
 }
@@ -195,6 +220,7 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     if (!ctx) return ZL_EINVAL;
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ZL_EHANDLE;
+    if (ctx->forks.load() > 0) return ZL_EINVAL;  // a fork may be reading it: destroy the forks first
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_pts) (void)hipFree(it->second.d_pts);
     if (it->second.d_table) (void)hipFree(it->second.d_table);
@@ -207,26 +233,26 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
 int zl_msm_batch_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials) {
     if (!ctx || (count && (!out_partials || !d_scalars))) return ZL_EINVAL;
     for (size_t i = 0; i < count; i++) if (!d_scalars[i] && n) return ZL_EINVAL;
-    auto it = ctx->bases.find(bases);
-    if (it == ctx->bases.end()) return ZL_EHANDLE;
-    if (first > it->second.n || n > it->second.n - first) return ZL_EINVAL;
+    const zl_bases* bp = zl_find_bases(ctx, bases);
+    if (!bp) return ZL_EHANDLE;
+    if (first > bp->n || n > bp->n - first) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    return ZL_DISPATCH(it->second.curve, it->second.group, zl_msm_run_batch, ctx, it->second, first, d_scalars, n, count, out_partials);
+    return ZL_DISPATCH(bp->curve, bp->group, zl_msm_run_batch, ctx, *bp, first, d_scalars, n, count, out_partials);
 }
 int zl_msm_partial_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     if (!ctx || !out_partial || (!d_scalars && n)) return ZL_EINVAL;
-    auto it = ctx->bases.find(bases);
-    if (it == ctx->bases.end()) return ZL_EHANDLE;
-    if (first > it->second.n || n > it->second.n - first) return ZL_EINVAL;
+    const zl_bases* bp = zl_find_bases(ctx, bases);
+    if (!bp) return ZL_EHANDLE;
+    if (first > bp->n || n > bp->n - first) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    return ZL_DISPATCH(it->second.curve, it->second.group, zl_msm_run, ctx, it->second, first, d_scalars, n, out_partial);
+    return ZL_DISPATCH(bp->curve, bp->group, zl_msm_run, ctx, *bp, first, d_scalars, n, out_partial);
 }
 int zl_msm_dev(zl_ctx* ctx, uint64_t bases, size_t first, const void* d_scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!out_xy) return ZL_EINVAL;
     uint64_t partial[ZL_PARTIAL_WORDS];
     int rc = zl_msm_partial_dev(ctx, bases, first, d_scalars, n, partial);
     if (rc) return rc;
-    const zl_bases& b = ctx->bases[bases];
+    const zl_bases& b = *zl_find_bases(ctx, bases);  // (found by zl_msm_partial_dev above)
     return ZL_DISPATCH(b.curve, b.group, zl_partial_to_affine, partial, out_xy, out_inf);
 }
 // Host scalars (what VariableBaseMSM::multi_scalar_mul is handed: the witness is new for every proof).  One copy followed by one MSM leaves
@@ -308,9 +334,9 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
 
 int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
     if (!ctx || !out_xy || (!scalars && n)) return ZL_EINVAL;
-    auto it = ctx->bases.find(bases);
-    if (it == ctx->bases.end()) return ZL_EHANDLE;
-    if (first > it->second.n || n > it->second.n - first) return ZL_EINVAL;
+    const zl_bases* bp = zl_find_bases(ctx, bases);
+    if (!bp) return ZL_EHANDLE;
+    if (first > bp->n || n > bp->n - first) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     void* d_sc = nullptr;
     if (n) {
@@ -318,7 +344,7 @@ int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, s
         if (rc) return rc;
         // the window table of a precomputed handle is built for full-size MSMs over it; shards would each pay its merged bucket set
         // (ZL_TUNE_HOST_CHUNK_MIN_LOG: developer / test knob -- the shard pipeline at sizes the oracle can check, with ZL_TUNE_HOST_SHARDS naming the shards)
-        if (n >= ((size_t)1 << zl_tune("ZL_TUNE_HOST_CHUNK_MIN_LOG", 22)) && it->second.precomp_c == 0 && !getenv("ZL_NO_HOST_CHUNKS")) return msm_host_chunked(ctx, it->second, first, scalars, n, d_sc, out_xy, out_inf);
+        if (n >= ((size_t)1 << zl_tune("ZL_TUNE_HOST_CHUNK_MIN_LOG", 22)) && bp->precomp_c == 0 && !getenv("ZL_NO_HOST_CHUNKS")) return msm_host_chunked(ctx, *bp, first, scalars, n, d_sc, out_xy, out_inf);
         ZL_HIP(ctx, hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     return zl_msm_dev(ctx, bases, first, d_sc, n, out_xy, out_inf);

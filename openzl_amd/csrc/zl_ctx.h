@@ -6,6 +6,8 @@
 #include <atomic>
 #include <functional>
 #include <map>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 #include "../../include/zl_backend.h"
 #include "zl_curve.h"
@@ -128,6 +130,13 @@ struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Mon
     int curve = 0;
 };
 struct zl_ctx {
+    // A FORK (zl_ctx_fork) is a second prover lane on the parent's device: its own streams, scratch, events, workers and twiddle tables, and READ access to the
+    // parent's device-resident objects (bases with their tables, R1CS matrices) through zl_find_bases / zl_find_r1cs -- so N host threads prove side by side
+    // over ONE copy of a proving key, like N threads sharing the reference's `&ProvingContext` (groth16.rs:445-457 takes it by shared reference).
+    zl_ctx* parent = nullptr;
+    std::atomic<int> forks{0};  // live forks of this ctx: its handles cannot be freed while any exists
+    mutable std::shared_mutex maps_mu;  // guards the two handle maps below: lookups from the lanes (shared) against uploads (exclusive); entries are node-stable
+    int fork_seq = 0;           // forks number their own handles from (seq << 48) | 1: no value of theirs collides with one of the parent's
     int device = 0;
     int cu_count = 0;                  // compute units of the device (grid of the persistent accumulation kernel)
     hipStream_t stream = nullptr;      // stream in use
@@ -170,6 +179,30 @@ struct zl_ctx {
     void* acc_clk = nullptr;
     size_t acc_clk_cap = 0, acc_clk_waves = 0;
 };
+
+// handle lookup: a ctx's own objects first, then its parent's (forks).  The maps of a ctx with live forks are read-only (uploads and frees are refused), so
+// concurrent finds from several lanes are plain concurrent reads of a std::map.
+inline const zl_bases* zl_find_bases(const zl_ctx* ctx, uint64_t handle) {
+    for (const zl_ctx* c = ctx; c; c = c->parent) {
+        std::shared_lock<std::shared_mutex> lk(c->maps_mu);
+        auto it = c->bases.find(handle);
+        if (it != c->bases.end()) return &it->second;
+    }
+    return nullptr;
+}
+inline const zl_r1cs_dev* zl_find_r1cs(const zl_ctx* ctx, uint64_t handle) {
+    for (const zl_ctx* c = ctx; c; c = c->parent) {
+        std::shared_lock<std::shared_mutex> lk(c->maps_mu);
+        auto it = c->r1cs.find(handle);
+        if (it != c->r1cs.end()) return &it->second;
+    }
+    return nullptr;
+}
+// the lazily built per-handle caches (zl_bases::d_endo, first_xy) are filled under this lock: two lanes may meet on the first use of a shared handle
+inline std::mutex& zl_bases_cache_mutex() {
+    static std::mutex m;
+    return m;
+}
 
 // developer tuning knob / deployment limit read from the environment (unset = the default)
 inline int zl_tune(const char* name, int dflt) {

@@ -143,10 +143,10 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     const uint64_t hs[5] = {pk->a_query, pk->b_g1_query, pk->h_query, pk->l_query, pk->b_g2_query};
     const zl_bases* bs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 5 && !wm_only; i++) {
-        auto it = ctx->bases.find(hs[i]);
-        if (it == ctx->bases.end()) return ZL_EHANDLE;
-        if (it->second.curve != (int)pk->curve || it->second.group != (i == 4 ? ZL_G2 : ZL_G1)) return ZL_EHANDLE;
-        bs[i] = &it->second;
+        const zl_bases* bp = zl_find_bases(ctx, hs[i]);  // (a fork reads its parent's key)
+        if (!bp) return ZL_EHANDLE;
+        if (bp->curve != (int)pk->curve || bp->group != (i == 4 ? ZL_G2 : ZL_G1)) return ZL_EHANDLE;
+        bs[i] = bp;
     }
     if (!wm_only && (bs[0]->n < nv || bs[1]->n < nv || bs[4]->n < nv || bs[2]->n < (size_t)N - 1 || bs[3]->n < nw)) return ZL_EINVAL;
 
@@ -277,6 +277,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         // static per key: fetched from the device on the first proof only
         const struct { const zl_bases* b; int group; uint64_t* out; size_t words; } firsts[3] = {
             {bs[0], ZL_G1, a0_xy, 12}, {bs[1], ZL_G1, b0_xy, 12}, {bs[4], ZL_G2, b20_xy, 24}};
+        std::lock_guard<std::mutex> cache_lk(zl_bases_cache_mutex());  // (two lanes may prove over one key for the first time together)
         for (const auto& f : firsts) {
             if (f.b->first_xy.empty()) {
                 uint64_t tmp[24] = {0};
@@ -572,8 +573,12 @@ extern "C" int zl_r1cs_upload(zl_ctx* ctx, zl_curve_t curve, const zl_r1cs* cs, 
     dev.curve = curve;
     const int rc = curve == ZL_BLS12_381 ? r1cs_upload_t<BLS12_381_Fr>(ctx, cs, &dev) : r1cs_upload_t<BN254_Fr>(ctx, cs, &dev);
     if (rc) return rc;
-    const uint64_t h = ctx->next_handle++;
-    ctx->r1cs[h] = dev;
+    uint64_t h;
+    {
+        std::unique_lock<std::shared_mutex> lk(ctx->maps_mu);
+        h = ctx->next_handle++;
+        ctx->r1cs[h] = dev;
+    }
     *handle_out = h;
     return ZL_OK;
 }
@@ -581,6 +586,7 @@ extern "C" int zl_r1cs_free(zl_ctx* ctx, uint64_t handle) {
     if (!ctx) return ZL_EINVAL;
     auto it = ctx->r1cs.find(handle);
     if (it == ctx->r1cs.end()) return ZL_EHANDLE;
+    if (ctx->forks.load() > 0) return ZL_EINVAL;  // a fork may be reading it: destroy the forks first
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_base) (void)hipFree(it->second.d_base);
     ctx->r1cs.erase(it);
@@ -590,24 +596,24 @@ extern "C" int zl_groth16_prove_resident(zl_ctx* ctx, const zl_g16_pk* pk, uint6
                                          const uint64_t* r, const uint64_t* s, zl_g16_proof* out) {
     if (!ctx || !pk || !assignment || !r || !s || !out || (flags & ~ZL_MONT)) return ZL_EINVAL;
     if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2) return ZL_EINVAL;
-    auto it = ctx->r1cs.find(r1cs_handle);
-    if (it == ctx->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
+    const zl_r1cs_dev* rd = zl_find_r1cs(ctx, r1cs_handle);
+    if (!rd || rd->curve != (int)pk->curve) return ZL_EHANDLE;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
-    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, assignment, flags, r, s, out);
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, rd, assignment, flags, r, s, out);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, rd, assignment, flags, r, s, out);
     return ZL_EINVAL;
 }
 // internal (zl_host.hip): the assignment as the compiler holds it -- instance block and witness block, Montgomery limbs
 int zl_groth16_prove_split(zl_ctx* ctx, const zl_g16_pk* pk, uint64_t r1cs_handle, const uint64_t* instance, const uint64_t* witness, const uint64_t* r,
                            const uint64_t* s, zl_g16_proof* out) {
     if (!ctx || !pk || !instance || !r || !s || !out) return ZL_EINVAL;
-    auto it = ctx->r1cs.find(r1cs_handle);
-    if (it == ctx->r1cs.end() || it->second.curve != (int)pk->curve) return ZL_EHANDLE;
-    if (it->second.n_witness && !witness) return ZL_EINVAL;
+    const zl_r1cs_dev* rd = zl_find_r1cs(ctx, r1cs_handle);
+    if (!rd || rd->curve != (int)pk->curve) return ZL_EHANDLE;
+    if (rd->n_witness && !witness) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     static const uint64_t none[4] = {0, 0, 0, 0};
-    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, &it->second, instance, ZL_MONT, r, s, out, witness ? witness : none);
-    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, &it->second, instance, ZL_MONT, r, s, out, witness ? witness : none);
+    if (pk->curve == ZL_BLS12_381) return groth16_prove_t<BlsG1, BlsG2>(ctx, pk, rd, instance, ZL_MONT, r, s, out, witness ? witness : none);
+    if (pk->curve == ZL_BN254) return groth16_prove_t<BnG1, BnG2>(ctx, pk, rd, instance, ZL_MONT, r, s, out, witness ? witness : none);
     return ZL_EINVAL;
 }
 extern "C" int zl_groth16_prove(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs* cs, const uint64_t* assignment, const uint64_t* r, const uint64_t* s,

@@ -439,7 +439,10 @@ struct Groth16 {
     // `exported`: the CSR export of `compiler` when the caller already holds one (the C hooks do): saves rebuilding it for the matrix upload
     static Result<std::pair<ProvingContext, VerifyingContext>> compile(zl_ctx* ctx, const Compiler& compiler, SplitMix64& rng,
                                                                         const R1csExport<FrP>* exported = nullptr);
-    static Result<Proof> prove(const ProvingContext& context, const Compiler& compiler, SplitMix64& rng, F* r_out = nullptr, F* s_out = nullptr);
+    // lane: the ctx the proof runs on -- the context's own (default) or a fork of it (zl_ctx_fork): N host threads, one lane each, prove side by side over
+    // ONE device-resident key, as N threads may share the reference's `&ProvingContext`.  A context decoded from bytes is bound (first proof) on its own ctx.
+    static Result<Proof> prove(const ProvingContext& context, const Compiler& compiler, SplitMix64& rng, F* r_out = nullptr, F* s_out = nullptr,
+                               zl_ctx* lane = nullptr);
     // verify (groth16.rs:459-466): e(A, B) == e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta); input = public inputs (canonical)
     static Result<bool> verify(const VerifyingContext& vk, const Input& input, const Proof& proof);
     static void release(ProvingContext& context);

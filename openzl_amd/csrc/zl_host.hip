@@ -543,8 +543,10 @@ void Groth16<E>::release(ProvingContext& pc) {
 
 // Groth16::prove (groth16.rs:445-457): r, s <- rng; create_proof_with_assignment on the device
 template <class E>
-Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, const Compiler& cs, SplitMix64& rng, F* r_out, F* s_out) {
+Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, const Compiler& cs, SplitMix64& rng, F* r_out, F* s_out, zl_ctx* lane) {
     Result<Proof> res{false, {}, Error{ZL_EINVAL}};
+    if (!lane) lane = pc.ctx;
+    if (lane != pc.ctx && (lane->parent != pc.ctx || !pc.r1cs)) return res;  // not a lane of this context / binding happens on the context's own ctx
     if (cs.mode() == Compiler::Mode::Setup) return res;  // the reference panics when a setup-mode compiler reaches prove
     if (cs.num_instance_variables() != pc.n_instance || cs.secret_variable_count() != pc.n_witness) return res;
     if (cs.witness_only() && !pc.r1cs) return res;  // a witness-only compiler has no rows to bind an unbound context to
@@ -578,7 +580,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     uint64_t rw[4], sw[4];
     memcpy(rw, r.l, 32);
     memcpy(sw, s.l, 32);
-    const int rc = zl_groth16_prove_split(pc.ctx, &pk, pc.r1cs, reinterpret_cast<const uint64_t*>(inst.data()),
+    const int rc = zl_groth16_prove_split(lane, &pk, pc.r1cs, reinterpret_cast<const uint64_t*>(inst.data()),
                                           wit.empty() ? nullptr : reinterpret_cast<const uint64_t*>(wit.data()), rw, sw, &res.value);
     if (rc) { res.error = Error{rc}; return res; }  // .map_err(|_| Error) groth16.rs:456
     res.ok = true;
@@ -832,14 +834,14 @@ int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit
     SplitMix64 rng(seed);
     if (c->curve == ZL_BLS12_381) {
         Fp<BLS12_381_Fr> r, s;
-        auto res = Groth16<Bls12_381>::prove(k->pc_bls, *c->bls, rng, &r, &s);
+        auto res = Groth16<Bls12_381>::prove(k->pc_bls, *c->bls, rng, &r, &s, ctx);
         if (!res.ok) return res.error.code;
         *proof = res.value;
         if (r_out) memcpy(r_out, r.l, 32);
         if (s_out) memcpy(s_out, s.l, 32);
     } else {
         Fp<BN254_Fr> r, s;
-        auto res = Groth16<Bn254>::prove(k->pc_bn, *c->bn, rng, &r, &s);
+        auto res = Groth16<Bn254>::prove(k->pc_bn, *c->bn, rng, &r, &s, ctx);
         if (!res.ok) return res.error.code;
         *proof = res.value;
         if (r_out) memcpy(r_out, r.l, 32);

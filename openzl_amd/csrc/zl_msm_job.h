@@ -237,6 +237,7 @@ struct MsmJob {
             // the per-call scratch copy below).  k_gls_psi is 50 us of latency in front of the G2 MSM of every small proof, k_glv_phi 12-100 us.
             const size_t endo_bytes = (size_t)(endo_k - 1) * n_real * sizeof(Affine<F>);
             const zl_bases& bs = *bsp;
+            std::lock_guard<std::mutex> cache_lk(zl_bases_cache_mutex());  // the handle may be shared by the lanes of a forked ctx
             if (!bs.d_endo && endo_bytes <= ((size_t)zl_tune("ZL_TUNE_ENDO_CACHE_MB", 512) << 20)) {
                 void* q = nullptr;
                 if (hipMalloc(&q, endo_bytes) == hipSuccess) {

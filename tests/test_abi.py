@@ -42,6 +42,7 @@ def test_strerror_and_argument_checks():
     assert L.zl_strerror(0) == b"ok"
     assert L.zl_strerror(-5) == b"unknown bases handle"
     assert L.zl_ctx_create(None, 0) == -1  # ZL_EINVAL
+    assert L.zl_ctx_fork(None, None) == -1
     out = np.zeros(12, dtype=np.uint64)
     inf = C.c_uint8(0)
     assert L.zl_partials_sum(99, 1, None, 0, ol.p64(out), C.byref(inf)) == -1
