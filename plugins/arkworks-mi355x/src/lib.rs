@@ -117,6 +117,12 @@ fn ctx() -> Result<*mut ffi::zl_ctx, Error> {
 /// * [`ProvingContext::rebind`] drops the resident matrices, so that the next proof uploads (and fingerprints) its own;
 /// * and the contract, as in the reference: `prove` NEVER checks the proof it returns (`Groth16::prove`, groth16.rs:445-457, does not either) -- a caller that
 ///   switches circuits on one context without `rebind` in a release build gets `Ok(proof)` that does not verify.  `ProofSystem::verify` is the check.
+///
+/// Threading: this type is `!Send + !Sync` (thread-local `zl_ctx`, `Cell` state) where the reference's is both.  The backend side of the remedy exists since
+/// round 5 -- `zl_ctx_fork` gives every further thread its own lane over ONE device-resident key and `zl_groth16_prove_circuit(lane, ..)` /
+/// `zl_groth16_prove_resident(lane, ..)` run on it (tests/test_gpu_lanes.py; two lanes: +6 % proofs/s at 958 465 constraints, +64 % at 235) -- the shim side
+/// (the context owning its root ctx, a `Mutex<Vec<lane>>` pool, the binding state behind the same mutex, `unsafe impl Send + Sync`) is not written: it
+/// cannot be compiled or tested in this tree.
 pub struct ProvingContext<E>
 where
     E: Mi355xEngine,
