@@ -110,6 +110,56 @@ def random_scalars_lt_r(n: int, seed: int, r: int = R_BLS, bits: int = 255) -> n
     return out
 
 
+def live_pmc_traffic(what: str, log_n: int):
+    """HBM traffic of the dominant kernel measured IN THIS RUN: two child processes of the same single-call command the committed PMC files come from
+    (tools/msm_one.py / tools/ntt_one.py), each under `rocprofv3 --pmc <one counter> --kernel-trace` -- FETCH_SIZE and WRITE_SIZE in separate passes, no other
+    trace domain, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- folded by tools/pmc_fold.py (counter x 1024 B; 2 x FETCH_SIZE + WRITE_SIZE on gfx950).
+    The parent process is idle meanwhile (all timed legs are over).  Returns (bytes per launch | per transform, detail dict); raises on any failure."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+        raise RuntimeError("this process runs under rocprofv3 itself")
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_fold
+
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "msm_one.py"), str(log_n), "0", "-1", "1"] if what == "msm" else [sys.executable, os.path.join(ROOT, "tools", "ntt_one.py"), str(log_n), "2"]
+    got, child_out = {}, ""
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zl_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "-f", "csv", "--"] + cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            child_out = r.stdout.decode(errors="replace")
+            csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode or not csvs:
+                raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {child_out[-200:]}")
+            got[counter] = pmc_fold.rows(csvs[0], counter)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    how = f"measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace (separate passes) -- python {' '.join(os.path.relpath(c, ROOT) if os.path.isabs(c) and c.startswith(ROOT) else c for c in cmd[1:])}"
+    if what == "msm":
+        fm, wm = pmc_fold.per_kernel_max(f), pmc_fold.per_kernel_max(w)
+        acc = [k for k in set(fm) | set(wm) if k.startswith("k_msm_accumulate")]
+        if not acc:
+            raise RuntimeError("no k_msm_accumulate dispatch in the counter file")
+        import re
+        m = re.findall(r"c=(\d+)", child_out)
+        return sum(2.0 * fm.get(k, 0.0) + wm.get(k, 0.0) for k in acc), {"how": how, "window_bits": int(m[-1]) if m else None,
+                                                                            "FETCH_SIZE_bytes": sum(fm.get(k, 0.0) for k in acc), "WRITE_SIZE_bytes": sum(wm.get(k, 0.0) for k in acc)}
+    P = 1 if log_n <= 10 else min(4, (log_n + 7) // 8)
+    fp, wp = [v for _, k, v in f if k.startswith("k_ntt_pass")], [v for _, k, v in w if k.startswith("k_ntt_pass")]
+    if len(fp) < 2 * P or len(wp) < 2 * P:
+        raise RuntimeError("fewer NTT pass dispatches than one forward + inverse transform in the counter file")
+    return 2.0 * sum(fp[-2 * P:-P]) + sum(wp[-2 * P:-P]), {"how": how, "passes": P, "FETCH_SIZE_bytes": sum(fp[-2 * P:-P]), "WRITE_SIZE_bytes": sum(wp[-2 * P:-P])}
+
+
 def limbs_to_int(row) -> int:
     return sum(int(v) << (64 * j) for j, v in enumerate(row))
 
@@ -872,6 +922,7 @@ def main():
     ap.add_argument("--strong-log-total", type=int, default=24, help="N > 1: total points of the strong-scaling leg")
     ap.add_argument("--no-mctx", action="store_true", help="N > 1: skip the child-process run of the one-process transport")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-scalar leg (pcie_inclusive): rocprofv3 runs of the headline keep only the headline's own accumulation launches")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic in this run (four child processes under rocprofv3 --pmc after the timed legs, ~70 s); the committed PMC passes of the same configuration are quoted instead")
     ap.add_argument("--dry-run", action="store_true", help="print the legs a `--gpus N` run executes, the per-rank HBM plan and the expected wall time, and exit (no GPU, no process group)")
     args = ap.parse_args()
 
@@ -1346,7 +1397,28 @@ def main():
         # WRITE_SIZE in separate runs of this same command); only valid for the profiled configuration, null otherwise
         traffic = None
         traffic_src = None
+        traffic_how = None
+        under_prof = any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)  # (a rocprofv3 run of this file: no profiler inside the profiler)
+        if world == 1 and not args.no_live_traffic and not under_prof:
+            # measured NOW, after every timed leg: child processes under rocprofv3 --pmc (live_pmc_traffic); any failure falls back to the committed passes below
+            try:
+                t_live, det = live_pmc_traffic("msm", args.log_n)
+                if det.get("window_bits") not in (None, head["window_bits"]):
+                    raise RuntimeError(f"the child process picked c = {det['window_bits']}, the timed run c = {head['window_bits']}")
+                traffic, traffic_how = t_live, det
+            except Exception as e:  # noqa: BLE001
+                leg_errors["live_traffic_msm"] = f"{type(e).__name__}: {e}"
+            if ntt_info is not None:
+                try:
+                    t_live, det = live_pmc_traffic("ntt", int(ntt_info["log_n"]))
+                    ntt_info["roofline"]["traffic"] = t_live
+                    ntt_info["roofline"]["traffic_unit"] = "bytes per transform, all passes, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction of the guide); " + det["how"]
+                    ntt_info["roofline"]["traffic_detail"] = det
+                except Exception as e:  # noqa: BLE001
+                    leg_errors["live_traffic_ntt"] = f"{type(e).__name__}: {e}"
         for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
+            if traffic is not None:
+                break
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if args.log_n == int(pmc["log_n"]) and head["window_bits"] == int(pmc["window_bits"]) and not pmc.get("precomputed_table", False):
@@ -1382,8 +1454,10 @@ def main():
                        "result_check": "every timed step equals (sum s_i k_i) G exactly at full size (known discrete logs); the CPU oracle's MSM of the "
                                        "complete input equals it too (cpu_baseline.parity_full_size)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": f"bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B), from the committed PMC passes of this configuration "
-                                         f"(profiles/{traffic_src or 'r04_pmc_traffic.json'}: rocprofv3 cannot run inside the timed process); null for any other configuration",
+                         "traffic": traffic, "traffic_unit": ("bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B); " + traffic_how["how"]) if traffic_how else
+                                         f"bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B), from the committed PMC passes of this configuration "
+                                         f"(profiles/{traffic_src or 'r04_pmc_traffic.json'}; --no-live-traffic, N > 1 or a failed live pass: see leg_errors); null for any other configuration",
+                         "traffic_detail": traffic_how,
                          "algorithmic_bytes": 128.0 * n, "kernel": "k_msm_accumulate",
                          "int_alu": {"unit": "G Fq-mul/s", "achieved": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9, "peak": fq_mul_peak_live(be),
                                      "frac": head["entries"] * MULS_PER_MIXED_ADD / (dom * 1e-3) / 1e9 / fq_mul_peak_live(be),

@@ -40,13 +40,17 @@ def test_bench_single_gpu_small():
     assert d["cpu_baseline"]["parity_full_size"] is True and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["ntt"]["cpu_baseline"]["parity_full_size"] is True and d["groth16"]["cpu_baseline"]["parity_full_size"] is True
     assert d["groth16"]["verified"] is True and d["msm_fixed_key"]["table_build_ms"] > 0
+    # roofline.traffic is a measurement of THIS run (child processes under rocprofv3 --pmc after the timed legs), for both kernels
+    rf, nrf = d["roofline"], d["ntt"]["roofline"]
+    assert rf["traffic_detail"]["how"].startswith("measured in this run") and rf["traffic"] >= 0.5 * rf["algorithmic_bytes"] and rf["traffic_detail"]["window_bits"] == d["config"]["window_bits"]
+    assert nrf["traffic_detail"]["how"].startswith("measured in this run") and nrf["traffic"] >= 64.0 * (1 << 14)
 
 
 def test_bench_scaling_model():
     """N = 1 at 2^22: the line carries the single-GPU times of the 2^21 prefix (exact) and the model's fields; the 2^24-specific efficiencies need the
     full size and are exercised by the driver's default run."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "22", "--steps", "3", "--warmup", "1", "--no-ntt", "--groth16-k", "0", "--no-cpu", "--no-skew",
-                        "--fixed-key", "-1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--fixed-key", "-1", "--no-live-traffic"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     m = d["scaling_model"]
@@ -116,7 +120,7 @@ def test_bench_one_rank_nccl_group_runs_every_collective():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ZL_DIST_BACKEND")}
     env["ZL_FORCE_COLLECTIVE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "18", "--ntt-log-n", "16", "--groth16-k", "0", "--steps", "3", "--warmup", "1", "--no-cpu",
-                        "--no-configs", "--no-skew", "--no-pcie", "--fixed-key", "-1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                        "--no-configs", "--no-skew", "--no-pcie", "--fixed-key", "-1", "--no-live-traffic"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     c = d["collective"]
