@@ -160,6 +160,28 @@ def live_pmc_traffic(what: str, log_n: int):
     return 2.0 * sum(fp[-2 * P:-P]) + sum(wp[-2 * P:-P]), {"how": how, "passes": P, "FETCH_SIZE_bytes": sum(fp[-2 * P:-P]), "WRITE_SIZE_bytes": sum(wp[-2 * P:-P])}
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a 256-thread host with cpu.max = 16 CPUs runs 256
+    OpenMP threads on 16 of them -- what os.cpu_count() cannot see; the round-4 `all_core_grid` leg did exactly that)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:  # noqa: BLE001
+            pass
+    return max(1, n)
+
+
 def limbs_to_int(row) -> int:
     return sum(int(v) << (64 * j) for j, v in enumerate(row))
 
@@ -168,7 +190,7 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
     """Time the CPU oracle (oracle/libzl_oracle.so: plain-C restatement of the arkworks 0.3.0 algorithm, 'port') on the host cores of this
     box, on the SAME bases and scalars the GPU was timed on (bases downloaded from the device, canonical affine).  Checker code used as a
     reported baseline only -- never on the product path.  Three configurations:
-      all-core (chunk x window) grid (value): the FULL input is cut into chunks so that chunks x windows ~ threads, every (chunk, window)
+      all-core (chunk x window) grid (value): the FULL input is cut into chunks so that chunks x windows ~ 4 x threads (threads = host_cores(): affinity capped by the cgroup quota), every (chunk, window)
           pair is one task of ark's window routine, partial sums are added -- uses every core on the same algorithm (not an arkworks
           configuration; NOT necessarily the fastest: on a many-core box the window-parallel sample below can beat it, `value` is the best of the two); its result must equal the GPU's full-size result bit for bit;
       window-parallel: what arkworks' `parallel` feature does (one thread per window), on a 2^22 sample with the window width ark's rule
@@ -180,7 +202,7 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
 
     curve = po.BLS12_381
     n = s_host.shape[0]
-    avail = os.cpu_count() or 1
+    avail = host_cores()
     threads = max(1, min(threads_req or avail, avail))
     t0 = time.perf_counter()
     bases = be.bases_download(h)  # canonical affine x||y, the very points the GPU used
@@ -207,7 +229,7 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
         "cflags": _ORACLE["cflags"],
         "value_is": "all_core_grid" if best_is_grid else "window_parallel",
         "all_core_grid": {"value": grid_rate, "cores": threads},
-        "sample": f"the complete 2^{full_log_n} BLS12-381 G1 input of the GPU run (same bases, same scalars) as a (chunk x window) task grid over {threads} "
+        "sample": f"the complete 2^{full_log_n} BLS12-381 G1 input of the GPU run (same bases, same scalars) as a (chunk x window) task grid (~4 tasks per thread) over {threads} "
                   f"threads (ark's window routine per task, ark window rule for the chunk length, partials added); arkworks-algorithm "
                   f"restatement in C, not the arkworks binary; {sec_all:.2f} s of wall time",
         "parity_full_size": parity,
@@ -217,7 +239,7 @@ def cpu_baseline(be, h, k64, s_host, gpu_xy, threads_req: int, full_log_n: int):
                             f"reduction by ~{100.0 * 2 * (1 << c_full) / m:.0f} % relative to the full input)"},
         "single_thread": {"value": m1 / sec_one, "cores": 1, "sample": f"2^{m1.bit_length() - 1} prefix, ark window rule for that size; 1 thread = the reference's "
                           "actual configuration (no `parallel` feature, plugins/arkworks/Cargo.toml)"},
-        "host_cpus": avail,
+        "host_cpus": avail, "host_cpus_online": os.cpu_count(),
         "bases_download_s": t_dl,
     }
 
@@ -231,7 +253,7 @@ def cpu_baseline_ntt(x_mont: np.ndarray, threads_req: int):
 
     curve = po.BLS12_381
     n = x_mont.shape[0]
-    avail = os.cpu_count() or 1
+    avail = host_cores()
     threads = max(1, min(threads_req or avail, avail, 64))
     X, sec_f = ol.oracle_ntt_timed(curve, x_mont, inverse=False, threads=threads)
     back, sec_i = ol.oracle_ntt_timed(curve, X, inverse=True, threads=threads)
@@ -254,7 +276,7 @@ def cpu_baseline_groth16(be, keys, circ, gpu_proof, r, s, threads_req: int):
     from openzl_amd import ZL_G2  # noqa: F401
 
     curve = po.BLS12_381
-    avail = os.cpu_count() or 1
+    avail = host_cores()
     threads = max(1, min(threads_req or avail, avail, 32))
     arrays = circ.arrays()
     pk = keys.pk_dict()

@@ -37,7 +37,11 @@ def dot_mod_r(S: np.ndarray, K: np.ndarray, r: int) -> int:
                     acc[a + b] += int((prod & m32).sum(dtype=np.uint64)) + (int((prod >> sh).sum(dtype=np.uint64)) << 32)
         return sum(v << (32 * w) for w, v in enumerate(acc))
 
-    workers = max(1, min(32, os.cpu_count() or 1, (n + BLK - 1) // BLK))
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        cpus = os.cpu_count() or 1
+    workers = max(1, min(32, cpus, (n + BLK - 1) // BLK))
     step = (n + workers - 1) // workers
     with ThreadPoolExecutor(max_workers=workers) as pool:
         total = sum(pool.map(lambda lo: rows(lo, min(lo + step, n)), range(0, n, step)))

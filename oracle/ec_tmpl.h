@@ -233,17 +233,18 @@ static void E(msm_ark_c)(E(jac) *out, const E(aff) *bases, const uint64_t *scala
     free(ws);
 }
 /* All-core MSM as a (chunk x window) grid (NOT what arkworks 0.3.0 does -- its `parallel` feature stops at one thread per window): the
- * input is cut into contiguous chunks so that chunks x windows ~ threads, every (chunk, window) pair is one task running ark's window
+ * input is cut into contiguous chunks so that chunks x windows ~ 4 x threads, every (chunk, window) pair is one task running ark's window
  * routine (window width by ark's rule for the chunk length; bucket arrays of a chunk-sized problem stay cache-sized), then a Horner per
  * chunk and the chunk results are added.  It uses every core on the same algorithm; it is NOT always the fastest arrangement (on a 256-thread box the window-parallel run of a 2^22 prefix on 15 threads measured faster per point: bench.py reports both and takes the better). */
 static void E(msm_chunked)(E(jac) *out, const E(aff) *bases, const uint64_t *scalars, size_t n, int threads) {
     int nt = threads < 1 ? 1 : threads;
     size_t chunks = 1;
     int c = E(ark_c)(n), nwin = (SC_BITS + c - 1) / c;
-    for (chunks = 1; chunks < (size_t)nt && chunks < n; chunks++) {
+    /* >= 4 tasks per thread (dynamic schedule): with tasks ~ threads the last round of a 272-task grid ran on 16 of 256 threads */
+    for (chunks = 1; chunks < 4 * (size_t)nt && chunks * 4096 < n; chunks++) {
         c = E(ark_c)((n + chunks - 1) / chunks);
         nwin = (SC_BITS + c - 1) / c;
-        if (chunks * (size_t)nwin >= (size_t)nt) break;
+        if (chunks * (size_t)nwin >= 4 * (size_t)nt) break;
     }
     if (chunks < 1) chunks = 1;
     size_t per = (n + chunks - 1) / chunks;
