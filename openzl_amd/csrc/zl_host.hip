@@ -357,7 +357,8 @@ Result<bool> Groth16<E>::verify(const VerifyingContext& vk, const Input& input, 
 
 // Window tables for the queries of a large proving key (static per circuit, like the key itself): the five MSMs of every proof then
 // run on one merged bucket set each.  Measured at N = 2^20 (958 465 constraints): prove 33.5 -> 29.2 ms in round 1 with c = 20 for the G1
-// queries (13 windows) and c = 16 for the G2 query; re-measured in round 3 (19.4 ms): G1 c = 19 / 21 -> 20.9 / 22.6 ms, G2 c = 17 / 18 / 20 -> 19.4 / 19.2 / 20.5.
+// queries (13 windows) and c = 16 for the G2 query; re-measured in round 3 (19.4 ms): G1 c = 19 / 21 -> 20.9 / 22.6 ms, G2 c = 17 / 18 / 20 -> 19.4 / 19.2 / 20.5;
+// round 5 (18.1 ms, profiles/r05_g16_table_widths.log, two interleaved passes): G1 19 / 21 -> 19.4 / 20.6, G2 17 / 18 / 19 -> 18.4 / 17.9-18.35 / 19.0: the defaults stand.
 // Memory: 13 x 128 B per G1 point, 16 x 256 B per G2 point (about 11 GB for this key).  Small keys stay on the plain path.
 template <class E>
 int Groth16<E>::build_window_tables(const ProvingContext& pc) {
