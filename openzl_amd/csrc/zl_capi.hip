@@ -70,17 +70,28 @@ int zl_ctx_fork(zl_ctx* parent, zl_ctx** out) {
     zl_ctx* c = nullptr;
     const int rc = zl_ctx_create(&c, parent->device);
     if (rc) return rc;
-    c->parent = parent;
     c->msm_c = parent->msm_c;
-    c->next_handle = ((uint64_t)(++parent->fork_seq) << 48) | 1;
-    parent->forks.fetch_add(1);
+    {
+        std::unique_lock<std::shared_mutex> lk(parent->maps_mu);  // (two threads may fork one parent at once)
+        c->parent = parent;
+        c->next_handle = ((uint64_t)(++parent->fork_seq) << 48) | 1;
+        parent->fork_list.push_back(c);
+        parent->forks.fetch_add(1);
+    }
     *out = c;
     return ZL_OK;
 }
 
 void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->parent) ctx->parent->forks.fetch_sub(1);
+    if (ctx->parent) {
+        std::unique_lock<std::shared_mutex> lk(ctx->parent->maps_mu);
+        auto& fl = ctx->parent->fork_list;
+        for (size_t i = 0; i < fl.size(); i++) if (fl[i] == ctx) { fl.erase(fl.begin() + (long)i); break; }
+        ctx->parent->forks.fetch_sub(1);
+    }
+    for (zl_ctx* f : ctx->fork_list) f->parent = nullptr;  // destroyed before its forks (a caller error): orphan them rather than leave them a dangling pointer
+    ctx->fork_list.clear();
     (void)hipSetDevice(ctx->device);
     for (zl_ctx* c : {ctx, ctx->aux, ctx->aux2}) {
         if (!c) continue;

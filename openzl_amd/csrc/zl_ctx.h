@@ -136,6 +136,7 @@ struct zl_ctx {
     zl_ctx* parent = nullptr;
     std::atomic<int> forks{0};  // live forks of this ctx: its handles cannot be freed while any exists
     mutable std::shared_mutex maps_mu;  // guards the two handle maps below: lookups from the lanes (shared) against uploads (exclusive); entries are node-stable
+    std::vector<zl_ctx*> fork_list;  // the live forks (under maps_mu): a parent destroyed first orphans them (parent = nullptr: their lookups of its handles then fail with ZL_EHANDLE instead of reading freed memory)
     int fork_seq = 0;           // forks number their own handles from (seq << 48) | 1: no value of theirs collides with one of the parent's
     int device = 0;
     int cu_count = 0;                  // compute units of the device (grid of the persistent accumulation kernel)

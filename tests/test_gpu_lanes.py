@@ -127,3 +127,31 @@ def test_decoded_context_binds_on_its_own_ctx_then_serves_lanes(backend):
         keys.close()
         full.close()
         wit.close()
+
+
+def test_parent_destroyed_before_its_lane_orphans_it(backend):
+    """a caller error the library must survive: the lane outlives its parent -> its lookups of the parent's handles fail with ZL_EHANDLE (no dangling pointer),
+    its own objects keep working, destroying it afterwards is clean"""
+    import torch
+
+    L = backend.L
+    parent, lane = C.c_void_p(), C.c_void_p()
+    assert L.zl_ctx_create(C.byref(parent), 0) == 0 and L.zl_ctx_fork(parent, C.byref(lane)) == 0
+    curve = po.BLS12_381
+    k = ol.random_scalars(curve, 64, 5)
+    S = ol.random_scalars(curve, 64, 6)
+    d = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    u64p = C.POINTER(C.c_uint64)
+    h, h2 = C.c_uint64(), C.c_uint64()
+    assert L.zl_bases_generate(parent, curve.cid, 1, k.ctypes.data_as(u64p), 64, C.byref(h)) == 0
+    assert L.zl_bases_generate(lane, curve.cid, 1, k.ctypes.data_as(u64p), 64, C.byref(h2)) == 0
+    part, part2 = np.zeros(64, dtype=np.uint64), np.zeros(64, dtype=np.uint64)
+    assert L.zl_msm_partial_dev(lane, h.value, 0, d.data_ptr(), 64, part.ctypes.data_as(u64p)) == 0
+    L.zl_ctx_destroy(parent)
+    assert L.zl_msm_partial_dev(lane, h.value, 0, d.data_ptr(), 64, part2.ctypes.data_as(u64p)) == -5
+    assert L.zl_msm_partial_dev(lane, h2.value, 0, d.data_ptr(), 64, part2.ctypes.data_as(u64p)) == 0
+    a, _ = backend.partials_sum(curve.cid, part.reshape(1, -1))
+    b, _ = backend.partials_sum(curve.cid, part2.reshape(1, -1))
+    assert (a == b).all()
+    L.zl_ctx_destroy(lane)
