@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
     "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_poseidon_chain_witness", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
-    "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_verify", "zl_pairing",
+    "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_prove_circuits", "zl_ctx_drop_lanes", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
     "zl_point_bytes", "zl_point_to_bytes", "zl_point_from_bytes", "zl_groth16_proof_bytes", "zl_groth16_proof_to_bytes", "zl_groth16_proof_from_bytes",
     "zl_point_bytes_uncompressed", "zl_point_to_bytes_uncompressed", "zl_point_from_bytes_uncompressed", "zl_groth16_keys_to_bytes", "zl_groth16_keys_from_bytes", "zl_groth16_keys_parse",
@@ -123,6 +123,8 @@ def load_library(path: Optional[str] = None):
     L.zl_groth16_keys_pk.argtypes = [vp, C.POINTER(G16PkC)]
     L.zl_groth16_keys_trapdoor.argtypes = [vp, u64p]
     L.zl_groth16_prove_circuit.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(G16ProofC), u64p, u64p]
+    L.zl_groth16_prove_circuits.argtypes = [vp, vp, C.POINTER(vp), u64p, C.c_size_t, C.POINTER(G16ProofC)]
+    L.zl_ctx_drop_lanes.argtypes = [vp]
     L.zl_groth16_verify.argtypes = [vp, u64p, C.c_size_t, C.POINTER(G16ProofC), C.POINTER(C.c_int)]
     L.zl_pairing.argtypes = [C.c_int, u64p, u64p, u64p]
     L.zl_point_bytes.argtypes = [C.c_int, C.c_int]
@@ -868,6 +870,20 @@ class Groth16Keys:
         nq = FQ_LIMBS[self.circuit.curve]
         return (np.array(proof.a[: 2 * nq], dtype=np.uint64), proof.a_inf, np.array(proof.b[: 4 * nq], dtype=np.uint64), proof.b_inf,
                 np.array(proof.c[: 2 * nq], dtype=np.uint64), proof.c_inf), r, s
+
+    def prove_many(self, seeds, circuits=None):
+        """zl_groth16_prove_circuits: a stream of proofs over this key on two prover lanes (two host threads inside the library); proofs[i] is what
+        prove(seeds[i], circuits[i]) returns.  circuits: None (the keys' own compiler for every proof) or one compiler per seed."""
+        n = len(seeds)
+        circuits = list(circuits) if circuits is not None else [self.circuit] * n
+        assert len(circuits) == n
+        cs = (C.c_void_p * max(1, n))(*[c._c for c in circuits])
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        out = (G16ProofC * max(1, n))()
+        self.backend._check(self.L.zl_groth16_prove_circuits(self.backend._ctx, self._k, cs, _p64(sd), n, out), "zl_groth16_prove_circuits")
+        nq = FQ_LIMBS[self.circuit.curve]
+        return [(np.array(p.a[: 2 * nq], dtype=np.uint64), p.a_inf, np.array(p.b[: 4 * nq], dtype=np.uint64), p.b_inf, np.array(p.c[: 2 * nq], dtype=np.uint64), p.c_inf)
+                for p in out[:n]]
 
     def verify(self, proof, public_inputs: np.ndarray) -> bool:
         """Groth16::verify(vk, input, proof) with the host pairing; proof = (a, a_inf, b, b_inf, c, c_inf)"""

@@ -82,8 +82,18 @@ int zl_ctx_fork(zl_ctx* parent, zl_ctx** out) {
     return ZL_OK;
 }
 
+int zl_ctx_drop_lanes(zl_ctx* ctx) {
+    if (!ctx) return ZL_EINVAL;
+    if (ctx->pipeline_busy.load()) return ZL_EINVAL;
+    zl_ctx* l = ctx->stream_lane_ctx;
+    ctx->stream_lane_ctx = nullptr;
+    if (l) zl_ctx_destroy(l);
+    return ZL_OK;
+}
+
 void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->stream_lane_ctx) { zl_ctx* l = ctx->stream_lane_ctx; ctx->stream_lane_ctx = nullptr; zl_ctx_destroy(l); }
     if (ctx->parent) {
         std::unique_lock<std::shared_mutex> lk(ctx->parent->maps_mu);
         auto& fl = ctx->parent->fork_list;

@@ -169,6 +169,7 @@ struct zl_ctx {
     void* pinned = nullptr;  // pinned host staging for pipelined results
     size_t pinned_cap = 0;
     zl_ctx* aux2 = nullptr;  // second auxiliary context (Groth16: the witness map runs beside the witness-only MSMs)
+    zl_ctx* stream_lane_ctx = nullptr;  // the fork zl_groth16_prove_circuits keeps for its second host thread (zl_ctx_drop_lanes / zl_ctx_destroy release it)
     zl_ctx* aux = nullptr;  // auxiliary stream + scratch set (Groth16: the G2 MSM overlaps the G1 MSMs)
     void* fb_table[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base window tables of the generators (per group config, built on first use)
     zl_worker* workers[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // persistent host threads of this ctx: 0 witness-map issue, 1 G2 MSM (Groth16); 2..5 one per lane stream (side-by-side MSM batches)

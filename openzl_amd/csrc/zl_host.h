@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <utility>
 #include <vector>
+#include <mutex>
 #include "zl_ctx.h"
 #include "zl_pairing.h"
 
@@ -207,6 +208,8 @@ public:
     // fingerprint differs: two different circuits of the same shape must not silently share device matrices.  Rows are append-only, so
     // the value is cached per (row count, variable counts): prove() pays for it once per compiler.
     uint64_t structure_digest() const {
+        static std::mutex digest_mu;  // one compiler may be proven from several lanes at once (Groth16::prove(..., lane)): the cache below is filled once, under this lock
+        std::lock_guard<std::mutex> lk(digest_mu);
         if (digest_rows_ == A_.size() && digest_inst_ == instance_.size() && digest_wit_ == witness_.size()) return digest_;
         uint64_t h = 0xCBF29CE484222325ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };

@@ -691,6 +691,46 @@ struct zl_g16_keys {
     Groth16<Bn254>::VerifyingContext vk_bn;
 };
 
+template <class E> static const R1CS<typename E::FrP>* cs_of(const zl_circuit* c);
+template <> const R1CS<BLS12_381_Fr>* cs_of<Bls12_381>(const zl_circuit* c) { return c->bls; }
+template <> const R1CS<BN254_Fr>* cs_of<Bn254>(const zl_circuit* c) { return c->bn; }
+// A stream of proofs over one key on two prover lanes (include/zl_backend.h): two host threads draw indices from one counter; thread 0 is the caller's
+template <class E>
+static int prove_circuits_t(zl_ctx* ctx, const typename Groth16<E>::ProvingContext& pc, const zl_circuit* const* circuits, const uint64_t* seeds, size_t count,
+                            zl_g16_proof* proofs) {
+    if (pc.ctx != ctx || ctx->parent || !pc.r1cs) return ZL_EINVAL;
+    if (count > 1 && !ctx->stream_lane_ctx) {
+        const int rc = zl_ctx_fork(ctx, &ctx->stream_lane_ctx);
+        if (rc) return rc;
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{ZL_OK};
+    auto work = [&](zl_ctx* lane) {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= count || first_err.load() != ZL_OK) return;
+            const zl_circuit* c = circuits[i];
+            int rc = ZL_EINVAL;
+            if (c && c->curve == E::curve) {
+                SplitMix64 rng(seeds[i]);
+                const auto* cs = cs_of<E>(c);
+                auto res = Groth16<E>::prove(pc, *cs, rng, nullptr, nullptr, lane);
+                rc = res.ok ? ZL_OK : res.error.code;
+                if (res.ok) proofs[i] = res.value;
+            }
+            if (rc != ZL_OK) { int exp = ZL_OK; first_err.compare_exchange_strong(exp, rc); return; }
+        }
+    };
+    if (count > 1) {
+        std::thread second(work, ctx->stream_lane_ctx);
+        work(ctx);
+        second.join();
+    } else {
+        work(ctx);
+    }
+    return first_err.load();
+}
+
 extern "C" {
 
 int zl_circuit_poseidon_chain(zl_curve_t curve, uint32_t k, const uint64_t* x0, const uint64_t* x1, zl_circuit** out) {
@@ -849,6 +889,12 @@ int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit
         if (s_out) memcpy(s_out, s.l, 32);
     }
     return ZL_OK;
+}
+
+int zl_groth16_prove_circuits(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* const* circuits, const uint64_t* seeds, size_t count, zl_g16_proof* proofs) {
+    if (!ctx || !k || (count && (!circuits || !seeds || !proofs))) return ZL_EINVAL;
+    if (k->curve == ZL_BLS12_381) return prove_circuits_t<Bls12_381>(ctx, k->pc_bls, circuits, seeds, count, proofs);
+    return prove_circuits_t<Bn254>(ctx, k->pc_bn, circuits, seeds, count, proofs);
 }
 
 // ---- ProvingContext / VerifyingKey wire formats (Groth16<E>::encode / decode / encode_verifying_key) ------------------------------

@@ -155,3 +155,33 @@ def test_parent_destroyed_before_its_lane_orphans_it(backend):
     b, _ = backend.partials_sum(curve.cid, part2.reshape(1, -1))
     assert (a == b).all()
     L.zl_ctx_destroy(lane)
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+def test_prove_many_is_a_stream_of_single_proofs(backend, curve):
+    """zl_groth16_prove_circuits (two host threads inside the library, the ctx and a fork it keeps): proofs[i] == prove(seeds[i], circuits[i]) byte for byte;
+    the error of a bad element comes back; the kept lane pins the key until zl_ctx_drop_lanes"""
+    k = 6
+    full = Circuit(curve.cid, k)
+    wits = [Circuit(curve.cid, k, x0=10 + j, x1=j, witness_only=True) for j in range(3)]
+    wrong = Circuit(curve.cid, k + 1, witness_only=True)
+    keys = Groth16Keys(backend, full, seed=77)
+    try:
+        seeds = list(range(100, 111))
+        circs = [None if i % 4 == 0 else wits[i % 3] for i in range(len(seeds))]
+        single = [keys.prove(seed=s, circuit=c)[0] for s, c in zip(seeds, circs)]
+        many = keys.prove_many(seeds, [c or full for c in circs])
+        assert len(many) == len(single) and all(_same(a, b) for a, b in zip(single, many))
+        assert keys.verify(many[1], wits[1].arrays()["assignment"][1:2])
+        assert keys.prove_many([]) == [] and _same(keys.prove_many([100])[0], single[0])
+        with pytest.raises(BackendError):
+            keys.prove_many(seeds[:4], [full, wits[0], wrong, wits[1]])
+        assert all(_same(a, b) for a, b in zip(single, keys.prove_many(seeds, [c or full for c in circs])))  # usable after an error
+        with pytest.raises(BackendError):
+            backend.bases_free(keys.pk.a_query)   # the kept lane reads it
+        assert backend.L.zl_ctx_drop_lanes(backend._ctx) == 0
+    finally:
+        backend.L.zl_ctx_drop_lanes(backend._ctx)
+        keys.close()
+        for c in [full, wrong] + wits:
+            c.close()
