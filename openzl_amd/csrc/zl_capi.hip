@@ -121,6 +121,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
     for (auto& t : ctx->stream_tail) if (t) (void)hipStreamDestroy(t);
     for (auto& t : ctx->stream_lane) if (t) (void)hipStreamDestroy(t);
+    for (auto& t : ctx->stream_lane_lo) if (t) (void)hipStreamDestroy(t);
     if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
@@ -132,6 +133,7 @@ void zl_ctx_destroy(zl_ctx* ctx) {
         if (a->stream_sort) (void)hipStreamDestroy(a->stream_sort);
         for (auto& t : a->stream_tail) if (t) (void)hipStreamDestroy(t);
         for (auto& t : a->stream_lane) if (t) (void)hipStreamDestroy(t);
+        for (auto& t : a->stream_lane_lo) if (t) (void)hipStreamDestroy(t);
         if (a->pinned) (void)hipHostFree(a->pinned);
         zl_ntt_free(a);
         for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);

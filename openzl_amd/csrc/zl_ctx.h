@@ -164,6 +164,7 @@ struct zl_ctx {
     uint64_t ntt_clock = 0;
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
+    hipStream_t stream_lane_lo[4] = {nullptr, nullptr, nullptr, nullptr};  // the lanes of SMALL side-by-side jobs: low priority class = a hardware-queue pool of their own (zl_msm.hip)
     hipStream_t stream_tail[3] = {nullptr, nullptr, nullptr};  // one tail stream per buffer set: the tails of consecutive small jobs run side by side
     hipStream_t stream_copy = nullptr;  // zl_msm with host scalars: chunked H2D copies that run under the MSMs of the earlier chunks
     void* pinned = nullptr;  // pinned host staging for pipelined results

@@ -175,7 +175,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // wins (2^24: 36.3 against 37.3 ms)
     const bool carried = specs[0].carried_total != 0;
     const bool side = !carried && biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
-    const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
+    const bool small_side = side && biggest < ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 2) != 0;
+    const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, small_side ? zl_tune("ZL_TUNE_SMALL_LANES", 3) : zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
     // carried shards: every shard plans with the window width of the whole MSM (same windows, same bucket ids) and without the endomorphism split
     struct ForceC {
         zl_ctx* c;
@@ -195,9 +196,23 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         t6 = std::max(t6, a6);
         max_sets = std::max<uint32_t>(max_sets, jobs[i].SETS * jobs[i].roots_per_set);
     }
+    // SMALL side-by-side jobs (the MSMs of a small proof: chains of ~25 kernels of 5-20 us) get lane streams of their own in the HIGH priority class: the runtime
+    // keeps one pool of hardware queues per priority class (GPU_MAX_HW_QUEUES = 4 each), and the default class is already shared by the ctx's own stream, the G2
+    // MSM's, the witness map's and the large-job lanes -- two chains on one hardware queue run one after the other (tools/queue_chains.hip: 4.7 us per step
+    // of a kernel chain for 1-2 streams, 9.3 for 3-6, 13.7 for 8 at the default of four queues).  The high class holds only the sort / tail / copy streams of the
+    // three-phase pipeline, idle while small jobs run.  Measured (profiles/r05_small_lanes_ab.log, r05_small_lanes_hi_ab.log; 40 proofs each, two interleaved passes): three
+    // high-class lanes 235 constraints 1.26-1.37 -> 1.05-1.07 ms, 14 977 constraints 2.57-2.65 -> 2.13 ms; four: 1.3-1.4 / 2.9; the low class: 1.4 / 3.0 (starved by
+    // the default-class chains).  ZL_TUNE_SMALL_LANE_PRIO = 0: the shared default-class lanes as before, 1: low class, 2: high class.
+    const bool small_lanes = small_side;
+    hipStream_t* const lanes = small_lanes ? ctx->stream_lane_lo : ctx->stream_lane;
     if (side) {
-        for (size_t k = 0; k < NS; k++)
-            if (!ctx->stream_lane[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_lane[k], hipStreamNonBlocking));
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        for (size_t k = 0; k < 4; k++)  // (all four at once, whatever NS: consecutive creations take consecutive queues of the pool)
+            if (!lanes[k]) {
+                if (small_lanes) ZL_HIP(ctx, hipStreamCreateWithPriority(&lanes[k], hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 2) == 1 ? prio_lo : prio_hi));
+                else ZL_HIP(ctx, hipStreamCreateWithFlags(&lanes[k], hipStreamNonBlocking));
+            }
     }
     // all buffers up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i: the first pass
     // grows every slot to its largest user, the second binds the final pointers.  Three sets: the tail of job i runs beside the
@@ -266,13 +281,13 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     he = hipEventRecord(ev_begin, s_acc);
     if (he == hipSuccess) he = hipStreamWaitEvent(s_sort, ev_begin, 0);
     if (side)
-        for (size_t k = 0; k < NS && he == hipSuccess; k++) he = hipStreamWaitEvent(ctx->stream_lane[k], ev_begin, 0);
+        for (size_t k = 0; k < NS && he == hipSuccess; k++) he = hipStreamWaitEvent(lanes[k], ev_begin, 0);
     static const bool jtrace = getenv("ZL_HOST_TRACE") != nullptr;
     const auto jt0 = std::chrono::steady_clock::now();
     // issue of one job: sort | accumulate | tail with the events between them.  pipelined: three phases on three streams; side by side: the
     // whole job on the stream of its buffer set (the waits are then between operations of one stream, i.e. no-ops)
     auto issue_sort = [&](size_t i) -> int {
-        hipStream_t js_sort = side ? ctx->stream_lane[i % NS] : s_sort;
+        hipStream_t js_sort = side ? lanes[i % NS] : s_sort;
         hipError_t e = hipSuccess;
         if (i >= NS) e = hipStreamWaitEvent(js_sort, ev_tail[i - NS], 0);  // buffer set i % NS is free again
         if (recorded && specs[i].wait) {
@@ -288,8 +303,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         return ZL_OK;
     };
     auto issue_acc_tail = [&](size_t i) -> int {
-        hipStream_t js_acc = side ? ctx->stream_lane[i % NS] : s_acc;
-        hipStream_t s_tail = side ? ctx->stream_lane[i % NS] : s_tails[i % 3];
+        hipStream_t js_acc = side ? lanes[i % NS] : s_acc;
+        hipStream_t s_tail = side ? lanes[i % NS] : s_tails[i % 3];
         hipError_t e = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
         if (e == hipSuccess && carried && i > 0) e = hipStreamWaitEvent(js_acc, jobs[i - 1].ev_merged, 0);  // the bucket sums of the previous shard are final
         if (e == hipSuccess && ctx->timing_on) e = hipEventRecord(ev_acc0[i], js_acc);
@@ -373,7 +388,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     }
     lanes_join();
     if (he == hipSuccess && rc == ZL_OK) {
-        hipStream_t last_tail = side ? ctx->stream_lane[(count - 1) % NS] : s_tails[(count - 1) % 3];
+        hipStream_t last_tail = side ? lanes[(count - 1) % NS] : s_tails[(count - 1) % 3];
         for (size_t back = 1; back < NS && back < count && he == hipSuccess; back++) he = hipStreamWaitEvent(last_tail, ev_tail[count - 1 - back], 0);
         if (he == hipSuccess) he = hipEventRecord(ev_end, last_tail);
     }
@@ -414,7 +429,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     }
     if (side)
         for (size_t k = 0; k < NS; k++) {
-            const hipError_t hs = hipStreamSynchronize(ctx->stream_lane[k]);
+            const hipError_t hs = hipStreamSynchronize(lanes[k]);
             if (he == hipSuccess) he = hs;
         }
     if (he == hipSuccess && rc == ZL_OK && ctx->timing_on) {
