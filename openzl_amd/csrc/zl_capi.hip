@@ -14,6 +14,45 @@ zl_pool& zl_pool_get() {
     return pool;
 }
 
+// aux (G2 MSM): default priority, like the G1 accumulation stream (the short sort / tail kernels of both run on highest-priority streams, so nothing waits behind
+// the long G2 accumulate; lowest priority measured 1 ms slower); aux2 (witness map): highest, h gates the last MSM
+int zl_ctx_aux_init(zl_ctx* ctx) {
+    for (zl_ctx** ax : {&ctx->aux, &ctx->aux2}) {
+        if (*ax) continue;
+        zl_ctx* a = new (std::nothrow) zl_ctx();
+        if (!a) return ZL_ENOMEM;
+        a->device = ctx->device;
+        a->cu_count = ctx->cu_count;
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : (zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
+        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
+        a->stream = a->own_stream;
+        *ax = a;  // owned by ctx from here on (zl_ctx_destroy)
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
+    }
+    return ZL_OK;
+}
+// Every stream of the ctx at once, in one fixed order.  The runtime multiplexes the streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4)
+// by the order in which they come into being, and two kernel chains on one hardware queue run in turn (tools/queue_chains.hip) -- created lazily, the lanes of a
+// small proof landed on different queues depending on which legs of a process had run before (bench.py after its MSM legs: 235 constraints 1.5-1.8 ms; a fresh
+// process: 1.05-1.3).  With the whole population created here, a ctx behaves the same whatever it was used for first.  ZL_TUNE_EAGER_STREAMS=0: lazily as before.
+int zl_ctx_streams_init(zl_ctx* ctx) {
+    if (!zl_tune("ZL_TUNE_EAGER_STREAMS", 1)) return ZL_OK;
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const int hi = zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0;
+    int rc = zl_ctx_aux_init(ctx);
+    if (rc) return rc;
+    for (auto& t : ctx->stream_lane) if (!t) ZL_HIP(ctx, hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+    if (!ctx->stream_sort) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, hi));
+    for (auto& t : ctx->stream_tail) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, hi));
+    if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
+    if (zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 || zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 2)
+        for (auto& t : ctx->stream_lane_lo) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 ? prio_lo : prio_hi));
+    return ZL_OK;
+}
+
 extern "C" {
 
 const char* zl_strerror(int code) {
@@ -59,6 +98,8 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
         return ZL_EHIP;
     }
     ctx->stream = ctx->own_stream;
+    const int rc_s = zl_ctx_streams_init(ctx);
+    if (rc_s) { zl_ctx_destroy(ctx); return rc_s; }
     *out = ctx;
     return ZL_OK;
 }
@@ -311,7 +352,7 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
         // H2D copies; priority means nothing to them.
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, (zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
     }
     std::vector<hipEvent_t> ev(K, nullptr);
     for (size_t j = 0; j < K; j++) {

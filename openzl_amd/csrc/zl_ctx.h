@@ -207,6 +207,10 @@ inline std::mutex& zl_bases_cache_mutex() {
     return m;
 }
 
+// the auxiliary contexts of a ctx (Groth16: aux = G2 MSM, aux2 = witness map) and EVERY stream the ctx will ever use, created together in one fixed order (zl_capi.hip)
+int zl_ctx_aux_init(zl_ctx* ctx);
+int zl_ctx_streams_init(zl_ctx* ctx);
+
 // developer tuning knob / deployment limit read from the environment (unset = the default)
 inline int zl_tune(const char* name, int dflt) {
     const char* v = getenv(name);

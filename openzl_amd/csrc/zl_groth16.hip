@@ -194,23 +194,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     // ---- witness map on its own context / stream: spmv, 3 x (ifft, coset fft), pointwise, coset ifft -> h -------------------------
     // It only needs z, like four of the five MSMs, so it runs beside them (memory- and latency-bound kernels in the shadow of the
     // bucket accumulation); the h MSM waits for ev_h inside the pipeline.
-    for (zl_ctx** ax : {&ctx->aux, &ctx->aux2}) {
-        if (*ax) continue;
-        zl_ctx* a = new (std::nothrow) zl_ctx();
-        if (!a) return ZL_ENOMEM;
-        a->device = ctx->device;
-        a->cu_count = ctx->cu_count;
-        // aux (G2 MSM): default priority, like the G1 accumulation stream (the short sort / tail kernels of both run on highest-priority
-        // streams, so nothing waits behind the long G2 accumulate any more; lowest priority measured 1 ms slower); aux2 (witness map):
-        // highest, h gates the last MSM
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : (zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
-        for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
-        a->stream = a->own_stream;
-        *ax = a;  // owned by ctx from here on (zl_ctx_destroy)
-        if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
-    }
+    { const int rc_aux = zl_ctx_aux_init(ctx); if (rc_aux) return rc_aux; }
     zl_ctx* wm = ctx->aux2;
     wm->ntt_fit_beside = wm_only ? 0 : 1;  // the witness map of a whole proof runs beside the G2 accumulation; on its own (sharded proofs) it takes the faster passes
     hipStream_t s_wm = wm->stream;

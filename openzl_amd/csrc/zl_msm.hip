@@ -175,7 +175,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // wins (2^24: 36.3 against 37.3 ms)
     const bool carried = specs[0].carried_total != 0;
     const bool side = !carried && biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
-    const bool small_side = side && biggest < ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 2) != 0;
+    const bool small_side = side && biggest < ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) != 0;
     const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, small_side ? zl_tune("ZL_TUNE_SMALL_LANES", 3) : zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
     // carried shards: every shard plans with the window width of the whole MSM (same windows, same bucket ids) and without the endomorphism split
     struct ForceC {
@@ -196,21 +196,23 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         t6 = std::max(t6, a6);
         max_sets = std::max<uint32_t>(max_sets, jobs[i].SETS * jobs[i].roots_per_set);
     }
-    // SMALL side-by-side jobs (the MSMs of a small proof: chains of ~25 kernels of 5-20 us) get lane streams of their own in the HIGH priority class: the runtime
-    // keeps one pool of hardware queues per priority class (GPU_MAX_HW_QUEUES = 4 each), and the default class is already shared by the ctx's own stream, the G2
-    // MSM's, the witness map's and the large-job lanes -- two chains on one hardware queue run one after the other (tools/queue_chains.hip: 4.7 us per step
-    // of a kernel chain for 1-2 streams, 9.3 for 3-6, 13.7 for 8 at the default of four queues).  The high class holds only the sort / tail / copy streams of the
-    // three-phase pipeline, idle while small jobs run.  Measured (profiles/r05_small_lanes_ab.log, r05_small_lanes_hi_ab.log; 40 proofs each, two interleaved passes): three
-    // high-class lanes 235 constraints 1.26-1.37 -> 1.05-1.07 ms, 14 977 constraints 2.57-2.65 -> 2.13 ms; four: 1.3-1.4 / 2.9; the low class: 1.4 / 3.0 (starved by
-    // the default-class chains).  ZL_TUNE_SMALL_LANE_PRIO = 0: the shared default-class lanes as before, 1: low class, 2: high class.
+    // SMALL side-by-side jobs (the MSMs of a small proof: chains of ~25 kernels of 5-20 us): which lane streams?  The runtime multiplexes the streams of a process
+    // onto a few hardware queues, and two chains on one queue run in turn (tools/queue_chains.hip).  Round 5 tried lanes of their own in the high and in the low
+    // stream-priority class and the idle tail streams as lanes (ZL_TUNE_SMALL_LANE_PRIO = 2 / 1 / 3): each won in one stream population and lost in another
+    // (profiles/r05_small_lanes_*_ab.log).  What made the difference was WHEN the streams had come into being; with every stream of a ctx created at
+    // zl_ctx_create (zl_ctx_streams_init) the ordinary default-class lanes are the best choice whatever ran before: 235 constraints 1.02-1.09 ms, 14 977
+    // constraints 2.14-2.23 ms (profiles/r05_small_lanes_eager_ab.log; 1.26-1.37 / 2.57-2.65 with lazily created streams).  Default 0 = those lanes.
     const bool small_lanes = small_side;
-    hipStream_t* const lanes = small_lanes ? ctx->stream_lane_lo : ctx->stream_lane;
+    // (ZL_TUNE_SMALL_LANE_PRIO=3, experiment: the three tail streams of the three-phase pipeline AS the small lanes -- the same streams whatever ran before)
+    const bool reuse_tails = small_lanes && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 3;
+    hipStream_t reuse[4] = {ctx->stream_tail[0], ctx->stream_tail[1], ctx->stream_tail[2], ctx->stream_sort};
+    hipStream_t* const lanes = reuse_tails ? reuse : (small_lanes ? ctx->stream_lane_lo : ctx->stream_lane);
     if (side) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (size_t k = 0; k < 4; k++)  // (all four at once, whatever NS: consecutive creations take consecutive queues of the pool)
             if (!lanes[k]) {
-                if (small_lanes) ZL_HIP(ctx, hipStreamCreateWithPriority(&lanes[k], hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 2) == 1 ? prio_lo : prio_hi));
+                if (small_lanes) ZL_HIP(ctx, hipStreamCreateWithPriority(&lanes[k], hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 ? prio_lo : prio_hi));
                 else ZL_HIP(ctx, hipStreamCreateWithFlags(&lanes[k], hipStreamNonBlocking));
             }
     }
