@@ -42,12 +42,24 @@ int zl_ctx_streams_init(zl_ctx* ctx) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int hi = zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0;
-    int rc = zl_ctx_aux_init(ctx);
-    if (rc) return rc;
-    for (auto& t : ctx->stream_lane) if (!t) ZL_HIP(ctx, hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
-    if (!ctx->stream_sort) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, hi));
-    for (auto& t : ctx->stream_tail) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, hi));
-    if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
+    // ZL_TUNE_STREAM_ORDER (developer sweep, profiles/r05_stream_order_ab.log): where the auxiliary contexts' streams stand among the lanes (default class) and among the
+    // sort / tail / copy streams (high class)
+    const int order = zl_tune("ZL_TUNE_STREAM_ORDER", 0);
+    int rc = ZL_OK;
+    auto lane = [&](int k) -> int { if (!ctx->stream_lane[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_lane[k], hipStreamNonBlocking)); return ZL_OK; };
+    auto high = [&]() -> int {
+        if (!ctx->stream_sort) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, hi));
+        for (auto& t : ctx->stream_tail) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, hi));
+        if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
+        return ZL_OK;
+    };
+    if (order == 2) { if ((rc = high())) return rc; }  // the high class before the witness map's stream
+    if (order == 1) { for (int k = 0; k < 4; k++) if ((rc = lane(k))) return rc; }  // the lanes before the G2 MSM's stream
+    if (order == 3) { if ((rc = lane(0))) return rc; }
+    if (order == 4) { if ((rc = lane(0)) || (rc = lane(1))) return rc; }
+    if ((rc = zl_ctx_aux_init(ctx))) return rc;
+    for (int k = 0; k < 4; k++) if ((rc = lane(k))) return rc;
+    if ((rc = high())) return rc;
     if (zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 || zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 2)
         for (auto& t : ctx->stream_lane_lo) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 ? prio_lo : prio_hi));
     return ZL_OK;
