@@ -33,3 +33,18 @@ def test_dry_run_single_gpu_and_small():
     assert d["n_gpus"] == 1 and d["launch"] == "python bench.py"
     assert not any(l["leg"] in ("config4", "strong") for l in d["legs_in_order"])
     assert d["hbm_total_per_rank_gb"] < 20
+
+
+def test_host_cores_respects_affinity_and_cgroup_quota():
+    """bench.py's cpu_baseline threads = the CPUs this process may really use (affinity mask capped by the cgroup quota), never the online count alone"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n = bench.host_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(1, int(q) // int(per))
+    except FileNotFoundError:
+        pass
