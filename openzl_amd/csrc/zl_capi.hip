@@ -86,7 +86,9 @@ int zl_ctx_create(zl_ctx** out, int device_id) {
     // (The library runs up to ~12 streams at once -- pipeline phases, side-by-side lanes, G2 MSM, witness map, tails -- which the HIP runtime
     // multiplexes onto GPU_MAX_HW_QUEUES hardware queues, default 4.  Measured with 8: a 235-constraint proof 1.26 -> 1.11 ms (median), the
     // 958 465-constraint proof 19.5 -> 20.25 ms (the G2 accumulation, one 416-register wave per SIMD, then runs beside the G1 accumulation instead
-    // of between two of them and both lose occupancy).  The default stays; a deployment of small circuits can set the variable itself.)
+    // of between two of them and both lose occupancy).  The default stays; a deployment of small circuits can set the variable itself.
+    // Round 5: with every stream of the ctx created here in one fixed order (zl_ctx_streams_init) the default of 4 beats 8 at every proof size -- 18.3 / 2.25 / 1.10 ms
+    // against 19.2 / 2.65 / 1.19 ms for 958 465 / 14 977 / 235 constraints: nothing to set.)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZL_ENODEV;
     if (device_id < 0 || device_id >= count) return ZL_EINVAL;
