@@ -1,8 +1,10 @@
 // zl_msm_accumulate.h -- step 3 of the MSM (zl_msm.hip): the bucket accumulation kernels, one lane (or one DPP quad) per chunk of the
 // bucket-sorted entry list.  Instantiated per group in zl_msm_acc.hip; zl_msm.hip only launches them (ZL_MSM_ACCUMULATE_KERNELS(extern, G)).
 #pragma once
+#include <type_traits>
 #include "zl_ctx.h"
 #include "zl_quad.h"
+#include "zl_fq2pair.h"
 #include "zl_msm_common.h"
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -136,6 +138,54 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
                                  reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
                                  reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
 }
+// Fq2 groups, TWO lanes per chunk (zl_fq2pair.h): lane i of a row of 16 holds the c0 components of the chunk's running sum and of the base it adds,
+// lane i ^ 8 the c1 components; a wave walks 32 chunks.  Registers per lane halve (416 -> two waves per SIMD), the instruction stream of one mixed
+// addition halves (5.3 k mads: it fits the instruction cache), the mads per addition stay the same.  Same chunks, same buckets, same partials as
+// zl_accumulate_chunk: the merge and reduction kernels do not know which of the two wrote them.
+#ifndef ZL_ACC_PAIR_WAVES
+#define ZL_ACC_PAIR_WAVES 2
+#endif
+template <class G>
+__global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
+                                                        const Affine<typename G::F>* __restrict__ bases_,
+                                                        XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                        XYZZ<typename G::F>* __restrict__ partials, uint32_t ZL_CHUNK,
+                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
+    using B = typename PairBase<typename G::F>::type;
+    if constexpr (!std::is_void<B>::value) {
+        using H = Fp2H<B>;
+        const int half = zl::pair_half();
+        const uint32_t t = blockIdx.x * 32u + ((threadIdx.x >> 4) << 3) + (threadIdx.x & 7u);
+        const uint32_t E = offsets[NB];
+        const Affine<typename G::F>* __restrict__ phib = phib_ - n_real;  // GLS: virtual point n_real + i = psi^j(P_i); else n_real = 2^32 - 1 (never selected)
+        const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
+        if (start64 >= E) return;
+        const uint32_t start = (uint32_t)start64;
+        const uint32_t end = (uint32_t)min((uint64_t)E, start64 + ZL_CHUNK);
+        uint32_t b = zl_upper_bound(offsets, NB + 1, start) - 1;
+        uint32_t b_start = offsets[b], b_end = offsets[b + 1];
+        XYZZ<H> acc = XYZZ<H>::inf();
+        for (uint32_t e = start; e < end; e++) {  // (the flat loop of zl_accumulate_chunk)
+            while (e == b_end) {
+                if (b_end > b_start) {
+                    if (b_start >= start) pair_store(&bucket_sums[b], half, acc);
+                    else pair_store(&partials[(size_t)2 * t], half, acc);
+                    acc = XYZZ<H>::inf();
+                }
+                b++;
+                b_start = b_end;
+                b_end = offsets[b + 1];
+            }
+            const uint32_t ent = entries[e];
+            const uint32_t idx = ent & 0x7fffffffu;
+            const Affine<H> P = pair_load(&(G::GLV && idx >= n_real ? phib : bases_)[idx], half);
+            if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+        }
+        const bool complete = (b_start >= start) && (b_end <= end);
+        if (complete) pair_store(&bucket_sums[b], half, acc);
+        else pair_store(&partials[(size_t)2 * t + (b_start <= start ? 0 : 1)], half, acc);
+    }
+}
 // The same chunks on a grid that does NOT fill the register file (pipelined batches): k_msm_accumulate at three waves per SIMD holds 498 of
 // the 512 registers of every SIMD for as long as it runs, so the sort of the next MSM and the tail of the previous one only get onto the
 // machine when it ends (rocprofv3 of a batch, profiles/r03_glv_ab.log: 3.5 ms between consecutive accumulations in which those two run alone).
@@ -161,6 +211,7 @@ __global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accu
 #define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
     X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_pair<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_carry<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*, uint32_t); \
     X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);

@@ -465,6 +465,9 @@ struct MsmJob {
         else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // four lanes per chunk while that still fits the machine at three waves per SIMD
             hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
+        else if (G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)
+            hipLaunchKernelGGL((k_msm_accumulate_pair<G>), dim3((nchunks + 31) / 32), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (G::COORDS == 1 && ctx->acc_clk && (size_t)((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK) * 32 <= ctx->acc_clk_cap) {  // armed by the measurement hook zl_test_acc_clock only
             ctx->acc_clk_waves = (nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK;
             hipLaunchKernelGGL((k_msm_accumulate_clk<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
