@@ -483,7 +483,10 @@ struct MsmJob {
         // four lanes per group operation (zl_quad.h) in every tail launch that does not fill the machine
         const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
         const uint32_t carry = carry_in ? 1u : 0u;
-        if (NB <= quad_max)
+        const bool pair_tails = G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value && zl_tune("ZL_TUNE_G2_PAIR_TAILS", 1);  // Fq2 groups: two lanes per item where a launch fills the machine
+        if (pair_tails && NB > quad_max)
+            hipLaunchKernelGGL((k_msm_merge_pair<G>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+        else if (NB <= quad_max)
             hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
@@ -508,14 +511,18 @@ struct MsmJob {
             const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
             const uint32_t leaves = SETS * red_blocks;
             X* cur = red_levels == 0 ? d_sets : d_segs;
-            if (leaves <= quad_max)
+            if (pair_tails && leaves > quad_max)
+                hipLaunchKernelGGL((k_msm_reduce_level0_pair<G>), dim3((leaves + 31) / 32), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
+            else if (leaves <= quad_max)
                 hipLaunchKernelGGL((k_msm_reduce_level0<G, true>), dim3((4 * leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
             else
             hipLaunchKernelGGL((k_msm_reduce_level0<G>), dim3((leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
             for (uint32_t lv = 1; lv <= red_levels; lv++) {
                 const uint32_t nodes = red_blocks >> lv, lanes = SETS * nodes * (lv + 2);
                 X* nxt = lv == red_levels ? d_sets : ((lv & 1) ? d_stage1 : d_segs);
-                if (lanes <= quad_max)
+                if (pair_tails && lanes > quad_max)
+                    hipLaunchKernelGGL((k_msm_reduce_tree_pair<G>), dim3((lanes + 31) / 32), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
+                else if (lanes <= quad_max)
                     hipLaunchKernelGGL((k_msm_reduce_tree<G, true>), dim3((4 * lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
                 else
                 hipLaunchKernelGGL((k_msm_reduce_tree<G>), dim3((lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
