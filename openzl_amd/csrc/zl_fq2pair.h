@@ -14,6 +14,7 @@
 // raw_zero) is combined over the pair, so control flow stays uniform inside a pair -- which is all DPP needs.
 #pragma once
 #include "zl_curve.h"
+#include "zl_quad.h"
 
 namespace zl {
 // (the host pass of a HIP unit parses these bodies too: it sees plain moves)
@@ -115,6 +116,14 @@ __device__ __forceinline__ Fp2H<B> muladd(const Fp2H<B>& a, const Fp2H<B>& b, co
     pair_route(d.c, Sd, Td);
     return Fp2H<B>{muladd4(a.c, Sb, pair_other(a.c), Tb, c.c, Sd, pair_other(c.c), Td)};
 }
+// four lanes per group operation (zl_quad.h) ON TOP of the pair split: the quads {4k .. 4k+3} and {4k+8 .. 4k+11} of a row hold the two halves of one
+// element, quad_perm moves stay inside a quad and row_ror:8 maps quad k onto quad k + 2 lane for lane -- eight lanes per Fq2 group operation
+template <int SRC, class B>
+__device__ __forceinline__ Fp2H<B> quad_bcast(const Fp2H<B>& v) { return Fp2H<B>{quad_bcast<SRC>(v.c)}; }
+template <class B>
+__device__ __forceinline__ Fp2H<B> quad_sel(int sub, const Fp2H<B>& x0, const Fp2H<B>& x1, const Fp2H<B>& x2, const Fp2H<B>& x3) {
+    return Fp2H<B>{quad_sel(sub, x0.c, x1.c, x2.c, x3.c)};
+}
 }  // namespace zl
 
 using zl::Fp2H;
@@ -147,3 +156,7 @@ __device__ __forceinline__ Affine<Fp2H<B>> pair_load(const Affine<Fp2LT<B, false
 // the component type of an Fq2 field on 28-bit limbs (void for every other field: the pair kernels exist for those groups only)
 template <class F> struct PairBase { using type = void; };
 template <class B, bool I> struct PairBase<Fp2LT<B, I>> { using type = B; };
+
+// item / position of a lane in the pair kernels: 32 items per wave (PAIR: lanes i, i ^ 8), or 8 items per wave with four lanes per half (OCTET: a quad and the quad eight lanes on)
+#define ZL_PAIR_ITEM() (blockIdx.x * 32u + ((threadIdx.x >> 4) << 3) + (threadIdx.x & 7u))
+#define ZL_OCTET_ITEM() (blockIdx.x * 8u + ((threadIdx.x >> 4) << 1) + ((threadIdx.x >> 2) & 1u))

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
 #ifndef ZL_ACC_PAIR_WAVES
 #define ZL_ACC_PAIR_WAVES 2
 #endif
-template <class G>
+// QUAD: eight lanes per chunk (four per half) for lists that do not fill the machine
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                         const Affine<typename G::F>* __restrict__ bases_,
                                                         XYZZ<typename G::F>* __restrict__ bucket_sums,
@@ -154,8 +155,8 @@ __global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(c
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         using H = Fp2H<B>;
-        const int half = zl::pair_half();
-        const uint32_t t = blockIdx.x * 32u + ((threadIdx.x >> 4) << 3) + (threadIdx.x & 7u);
+        const int half = zl::pair_half(), sub = (int)(threadIdx.x & 3u);
+        const uint32_t t = QUAD ? ZL_OCTET_ITEM() : ZL_PAIR_ITEM();
         const uint32_t E = offsets[NB];
         const Affine<typename G::F>* __restrict__ phib = phib_ - n_real;  // GLS: virtual point n_real + i = psi^j(P_i); else n_real = 2^32 - 1 (never selected)
         const uint64_t start64 = (uint64_t)t * ZL_CHUNK;
@@ -179,7 +180,10 @@ __global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(c
             const uint32_t ent = entries[e];
             const uint32_t idx = ent & 0x7fffffffu;
             const Affine<H> P = pair_load(&(G::GLV && idx >= n_real ? phib : bases_)[idx], half);
-            if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+            if (!P.is_inf()) {
+                if constexpr (QUAD) zl::add_mixed_quad(acc, P.x, P.y, (ent >> 31) != 0, sub);
+                else zl::add_mixed(acc, P.x, P.y, (ent >> 31) != 0);
+            }
         }
         const bool complete = (b_start >= start) && (b_end <= end);
         if (complete) pair_store(&bucket_sums[b], half, acc);
@@ -211,7 +215,8 @@ __global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accu
 #define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
     X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
-    X template __global__ void k_msm_accumulate_pair<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_pair<G, true>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_accumulate_pair<G, false>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_carry<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*, uint32_t); \
     X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);

@@ -453,6 +453,7 @@ struct MsmJob {
         (void)ctx;
         return ZL_OK;
     }
+    static constexpr bool pair_ok() { return G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value; }  // an Fq2 group on 28-bit limbs: the lane-pair kernels exist
     // wg_per_cu > 0: the persistent form (pipelined batches) on wg_per_cu x CUs workgroups
     int accumulate(zl_ctx* ctx, hipStream_t st, int wg_per_cu = 0) {
         const uint32_t lanes_persist = (uint32_t)wg_per_cu * (uint32_t)ctx->cu_count * ZL_ACC_PERSIST_BLOCK;
@@ -462,11 +463,14 @@ struct MsmJob {
         else if (carry_in)
             hipLaunchKernelGGL((k_msm_accumulate_carry<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
+        else if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
+            hipLaunchKernelGGL((k_msm_accumulate_pair<G, true>), dim3((nchunks + 7) / 8), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // four lanes per chunk while that still fits the machine at three waves per SIMD
             hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
-        else if (G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)
-            hipLaunchKernelGGL((k_msm_accumulate_pair<G>), dim3((nchunks + 31) / 32), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
+        else if (pair_ok() && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)
+            hipLaunchKernelGGL((k_msm_accumulate_pair<G, false>), dim3((nchunks + 31) / 32), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (G::COORDS == 1 && ctx->acc_clk && (size_t)((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK) * 32 <= ctx->acc_clk_cap) {  // armed by the measurement hook zl_test_acc_clock only
             ctx->acc_clk_waves = (nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK;
@@ -483,9 +487,11 @@ struct MsmJob {
         // four lanes per group operation (zl_quad.h) in every tail launch that does not fill the machine
         const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
         const uint32_t carry = carry_in ? 1u : 0u;
-        const bool pair_tails = G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value && zl_tune("ZL_TUNE_G2_PAIR_TAILS", 1);  // Fq2 groups: two lanes per item where a launch fills the machine
+        const bool pair_tails = pair_ok() && zl_tune("ZL_TUNE_G2_PAIR_TAILS", 1), octet = pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1);  // Fq2 groups: two lanes per item where a launch fills the machine
         if (pair_tails && NB > quad_max)
-            hipLaunchKernelGGL((k_msm_merge_pair<G>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+            hipLaunchKernelGGL((k_msm_merge_pair<G, false>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+        else if (octet && NB <= quad_max)
+            hipLaunchKernelGGL((k_msm_merge_pair<G, true>), dim3((NB + 7) / 8), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else if (NB <= quad_max)
             hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else
@@ -512,7 +518,9 @@ struct MsmJob {
             const uint32_t leaves = SETS * red_blocks;
             X* cur = red_levels == 0 ? d_sets : d_segs;
             if (pair_tails && leaves > quad_max)
-                hipLaunchKernelGGL((k_msm_reduce_level0_pair<G>), dim3((leaves + 31) / 32), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
+                hipLaunchKernelGGL((k_msm_reduce_level0_pair<G, false>), dim3((leaves + 31) / 32), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
+            else if (octet && leaves <= quad_max)
+                hipLaunchKernelGGL((k_msm_reduce_level0_pair<G, true>), dim3((leaves + 7) / 8), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
             else if (leaves <= quad_max)
                 hipLaunchKernelGGL((k_msm_reduce_level0<G, true>), dim3((4 * leaves + 63) / 64), dim3(64), 0, st, d_buckets, H, red_g0, red_blocks, leaves, fset, flog, cur);
             else
@@ -521,7 +529,9 @@ struct MsmJob {
                 const uint32_t nodes = red_blocks >> lv, lanes = SETS * nodes * (lv + 2);
                 X* nxt = lv == red_levels ? d_sets : ((lv & 1) ? d_stage1 : d_segs);
                 if (pair_tails && lanes > quad_max)
-                    hipLaunchKernelGGL((k_msm_reduce_tree_pair<G>), dim3((lanes + 31) / 32), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
+                    hipLaunchKernelGGL((k_msm_reduce_tree_pair<G, false>), dim3((lanes + 31) / 32), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
+                else if (octet && lanes <= quad_max)
+                    hipLaunchKernelGGL((k_msm_reduce_tree_pair<G, true>), dim3((lanes + 7) / 8), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
                 else if (lanes <= quad_max)
                     hipLaunchKernelGGL((k_msm_reduce_tree<G, true>), dim3((4 * lanes + 63) / 64), dim3(64), 0, st, cur, nxt, lv, nodes, lanes);
                 else

@@ -234,8 +234,8 @@ __global__ void __launch_bounds__(64) k_msm_reduce_tree(const XYZZ<typename G::F
 // The same three kernels with TWO lanes per item (lane i of a row of 16: the c0 components, lane i ^ 8: the c1 components), for launches that fill the
 // machine: the one-lane forms above hold three Fq2 points across out-of-line product calls -- 512 registers and 540-780 B of scratch per lane, one wave per
 // SIMD -- where a half-point lane stays inside 256 registers with the product scans inlined.  Same buffers, same item numbering.
-#define ZL_PAIR_ITEM() (blockIdx.x * 32u + ((threadIdx.x >> 4) << 3) + (threadIdx.x & 7u))
-template <class G>
+// QUAD: eight lanes per item (zl_fq2pair.h: four per half) for launches that do NOT fill the machine -- the chain of a small G2 MSM
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, 2) k_msm_merge_pair(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
@@ -244,33 +244,35 @@ __global__ void __launch_bounds__(64, 2) k_msm_merge_pair(const uint32_t* __rest
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
         using X = XYZZ<Fp2H<B>>;
-        const int half = zl::pair_half();
-        const uint32_t b = ZL_PAIR_ITEM();
+        const int half = zl::pair_half(), sub = (int)(threadIdx.x & 3u);
+        const uint32_t b = QUAD ? ZL_OCTET_ITEM() : ZL_PAIR_ITEM();
         if (b >= NB) return;
         const uint32_t s = offsets[b], e = offsets[b + 1];
         if (s == e) { if (!carry) pair_store(&bucket_sums[b], half, X::inf()); return; }
         const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
         if (t0 == t1) return;
-        if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (half == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
-        if (t1 - t0 + 1 > big_span) { if (half == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
+        const bool first = half == 0 && (!QUAD || sub == 0);
+        if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (first) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
+        if (t1 - t0 + 1 > big_span) { if (first) big_list[atomicAdd(big_count, 1u)] = b; return; }
         X acc = X::inf();
         if (carry) acc = pair_load(&bucket_sums[b], half);
         for (uint32_t t = t0; t <= t1; t++) {
             const X p = pair_load(&partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)], half);
-            zl::add_full(acc, p);
+            if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
+            else zl::add_full(acc, p);
         }
         pair_store(&bucket_sums[b], half, acc);
     }
 }
-template <class G>
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, 2) k_msm_reduce_level0_pair(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log, XYZZ<typename G::F>* __restrict__ out) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
         using X = XYZZ<Fp2H<B>>;
-        const int half = zl::pair_half();
-        const uint32_t t = ZL_PAIR_ITEM();
+        const int half = zl::pair_half(), sub = (int)(threadIdx.x & 3u);
+        const uint32_t t = QUAD ? ZL_OCTET_ITEM() : ZL_PAIR_ITEM();
         if (t >= total_blocks) return;
         const uint32_t set = t / blocks_per_set, blk = t % blocks_per_set;
         const uint32_t i0 = blk * group, i1 = min(H, i0 + group);
@@ -279,23 +281,28 @@ __global__ void __launch_bounds__(64, 2) k_msm_reduce_level0_pair(const XYZZ<typ
         X run = X::inf(), wsum = X::inf();
         for (uint32_t i = i1; i > i0; i--) {
             const X Bk = pair_load(&buckets[base + (i - 1)], half);
-            zl::add_full(run, Bk);
-            if (!flat) zl::add_full(wsum, run);
+            if constexpr (QUAD) {
+                zl::add_full_quad(run, Bk, sub);
+                if (!flat) zl::add_full_quad(wsum, run, sub);
+            } else {
+                zl::add_full(run, Bk);
+                if (!flat) zl::add_full(wsum, run);
+            }
         }
         pair_store(&out[(size_t)2 * t], half, run);
         if (flat) pair_store(&out[(size_t)2 * t + 1], half, run);
         else pair_store(&out[(size_t)2 * t + 1], half, wsum);
     }
 }
-template <class G>
+template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, 2) k_msm_reduce_tree_pair(const XYZZ<typename G::F>* __restrict__ in, XYZZ<typename G::F>* __restrict__ out, uint32_t level,
                                                          uint32_t nodes_out_per_set, uint32_t total_lanes) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
         using X = XYZZ<Fp2H<B>>;
-        const int half = zl::pair_half();
-        const uint32_t t = ZL_PAIR_ITEM();
+        const int half = zl::pair_half(), sub = (int)(threadIdx.x & 3u);
+        const uint32_t t = QUAD ? ZL_OCTET_ITEM() : ZL_PAIR_ITEM();
         if (t >= total_lanes) return;
         const uint32_t ch_out = level + 2, ch_in = level + 1;
         const uint32_t ch = t % ch_out, node = (t / ch_out) % nodes_out_per_set, set = t / (ch_out * nodes_out_per_set);
@@ -306,7 +313,8 @@ __global__ void __launch_bounds__(64, 2) k_msm_reduce_tree_pair(const XYZZ<typen
         }
         X acc = pair_load(&in[left + ch], half);
         const X o = pair_load(&in[right + ch], half);
-        zl::add_full(acc, o);
+        if constexpr (QUAD) zl::add_full_quad(acc, o, sub);
+        else zl::add_full(acc, o);
         pair_store(&out[t], half, acc);
     }
 }
@@ -357,7 +365,10 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
     X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_tree<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_reduce_tree<G, true>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge_pair<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_reduce_level0_pair<G>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
-    X template __global__ void k_msm_reduce_tree_pair<G>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_pair<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_pair<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_reduce_level0_pair<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
+    X template __global__ void k_msm_reduce_level0_pair<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
+    X template __global__ void k_msm_reduce_tree_pair<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_reduce_tree_pair<G, true>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_window_sum<G>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*, const uint32_t*);
