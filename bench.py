@@ -603,18 +603,28 @@ VALU_CYCLES_PER_MIXED_ADD = 17028 + 186  # profiles/r05_acc_instruction_budget.t
 NOMINAL_GHZ = 2.4
 
 
+IN_KERNEL_CLOCK_GHZ = 2.09  # profiles/r05_clock_probe_2_24.log (2.075-2.10 over three launches; the same kernel, the same 32.7-32.9 ms): re-measured by tools/clock_probe.py on a -DZL_MEASURE build
+
+
 def int_alu_clock(acc_clock, head, dom_ms):
-    """effective clock of the accumulation (in-kernel s_memtime / s_memrealtime) and what follows from it: SIMD cycles per wave-level mixed addition against
-    the ISA's VALU issue cycles, and the kernel against the same instruction stream at the nominal 2.4 GHz"""
-    if not acc_clock or "error" in acc_clock or not acc_clock.get("effective_clock_ghz"):
-        return {"effective_clock_ghz": None, "effective_clock_note": (acc_clock or {}).get("error", "not measured")}
-    f = acc_clock["effective_clock_ghz"]
+    """effective clock of the accumulation and what follows from it: SIMD cycles per wave-level mixed addition against the ISA's VALU issue cycles, and the
+    kernel against the same instruction stream at the nominal 2.4 GHz.  The clock is the IN-KERNEL reading (s_memtime / s_memrealtime per wave of the
+    clock-reading build of the same kernel), which since round 6 exists in -DZL_MEASURE builds only: this line quotes the committed
+    measurement and, beside it, what a sleeping probe wave per XCD reads during one more batch of this run.  During the NTT passes that probe reads 2.0-2.05 GHz;
+    during the accumulation it reads 2.40 where the kernel's own waves read 1.93-2.28 each (profiles/r05_clock_probe_2_24.log) and GRBM_GUI_ACTIVE / wall gives 2.05
+    (profiles/r05_pmc_clock_msm_2_24.json) -- the disagreement is not explained, so the probe's figure is reported under its own name and nothing is derived from it."""
+    f = IN_KERNEL_CLOCK_GHZ
     wave_adds_per_simd = head["entries"] / 64.0 / 1024.0
     cyc = f * 1e9 * dom_ms * 1e-3 / wave_adds_per_simd
     t_nominal_ms = wave_adds_per_simd * VALU_CYCLES_PER_MIXED_ADD / (NOMINAL_GHZ * 1e9) * 1e3
-    return {"effective_clock_ghz": f, "effective_clock_min_max_wave_ghz": [acc_clock["min_wave_ghz"], acc_clock["max_wave_ghz"]],
-            "effective_clock_source": "s_memtime / s_memrealtime deltas of every wave of one more launch of the same accumulation (k_msm_accumulate_clk), %.2f ms against %.2f ms un-instrumented"
-                                      % (acc_clock["accumulate_ms_clock_reading_build"], dom_ms),
+    probe = acc_clock if acc_clock and "error" not in acc_clock else None
+    return {"effective_clock_ghz": f,
+            "effective_clock_source": "in-kernel s_memtime / s_memrealtime deltas of every wave of the clock-reading build of this kernel (k_msm_accumulate_clk, -DZL_MEASURE builds only): "
+                                      "committed measurement profiles/r05_clock_probe_2_24.log, same kernel and same kernel time; NOT re-read by this run",
+            "sleeping_probe_clock_ghz": probe["effective_clock_ghz"] if probe else None,
+            "sleeping_probe_note": ("one sleeping wave per XCD on its own high-priority stream spanning one more pipelined batch of four steps (accumulation %.2f ms per step during the probe, "
+                                    "%.2f ms in the timed steps); disagrees with the in-kernel and the GRBM readings of the same kernel, nothing is derived from it" % (probe["accumulate_ms_during_probe"], dom_ms))
+                                   if probe else (acc_clock or {}).get("error", "not measured"),
             "simd_cycles_per_wave_mixed_add": cyc, "isa_valu_issue_cycles_per_wave_mixed_add": VALU_CYCLES_PER_MIXED_ADD,
             "valu_issue_efficiency_at_that_clock": VALU_CYCLES_PER_MIXED_ADD / cyc,
             "frac_vs_nominal_2p4ghz": t_nominal_ms / dom_ms,
@@ -715,7 +725,7 @@ def config2_leg(R: Run):
     n = 1 << 20
     inp = MsmInputs(R, n, 20)
     try:
-        leg = msm_leg(R, inp, 6, 2, True, False, "config 2")
+        leg = msm_leg(R, inp, 20, 2, True, False, "config 2")  # (a 20-step batch like the headline's default driver run: a 6-step batch of 3-ms jobs is one third ramp)
         d = inp.d_vecs[0]
         ts, dv, ac = [], [], []
         for _ in range(10):
@@ -1016,31 +1026,43 @@ def main():
             print(f"[bench] leg {name} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
     # ---- the headline: synthetic inputs generated per rank, resident in HBM before the timed region; gate; K timed steps ------------------
+    def _dbg_c2(where):  # ZL_BENCH_DBG_C2=1 (developer aid, tools/ab/r6_c2_bench.sh): the config-2 leg at several points of the run, to stderr
+        if os.environ.get("ZL_BENCH_DBG_C2") == "1" and rank == 0 and world == 1:
+            c = config2_leg(R)
+            print(f"[dbg c2 @ {where}] single {c['single_call_ms']:.3f} pipelined {c['pipelined_ms_per_msm']:.3f} dev {c['single_call_device_ms']:.3f}", file=sys.stderr, flush=True)
+
+    _dbg_c2("start")
     inp = MsmInputs(R, n, 0)
     h, k64, vecs, d_vecs, exp_xy = inp.h, inp.k64, inp.vecs, inp.d_vecs, inp.exp_xy
     t_generate = inp.t_generate
     head = msm_leg(R, inp, args.steps, args.warmup, not args.no_pipeline, True, "headline")
     elapsed, pipelined, single_ms = head["elapsed"], head["pipelined"], head["single_call_latency_ms"]
     tm = be.last_timing()
-    # effective shader clock of the dominant kernel, read from inside it: one more single-call MSM of the same input with the clock-reading build of the
-    # accumulation armed (k_msm_accumulate_clk = the product kernel + four scalar clock reads per wave; include/zl_backend_test.h), checked like every step
+    # effective shader clock while the dominant kernel runs: a sleeping one-wave-per-XCD probe on its own stream (include/zl_backend_test.h) spans one more pipelined
+    # batch of four steps, ~90 % of which is the accumulation (the rest: the sorts and tails between two accumulations); every step checked like the timed ones.
+    # (Round 5 read the clock inside a clock-reading build of the kernel, k_msm_accumulate_clk; that kernel now exists in -DZL_MEASURE builds only -- VERDICT r5
+    # item 7 -- and tools/clock_probe.py still uses it there: profiles/r05_clock_probe_2_24.log has both readings side by side.)
     acc_clock = None
     if rank == 0:
         try:
-            from openzl_amd.backend import hook_acc_clock, hook_acc_clock_read
-            hook_acc_clock(be, True)
-            part_c = be.msm_partial_dev(h, d_vecs[0].data_ptr(), n)
+            from openzl_amd.backend import hook_clock_probe_launch, hook_clock_probe_read
+            cnt = 4
+            torch.cuda.synchronize()
+            hook_clock_probe_launch(be, max(100, int(0.92 * cnt * head["ms_per_step"] * 1e3)))
+            parts_c = be.msm_batch_partial_dev(h, [d_vecs[i % 2].data_ptr() for i in range(cnt)], n)
             tm_c = be.last_timing()
-            acc_clock = hook_acc_clock_read(be)
-            acc_clock["accumulate_ms_clock_reading_build"] = float(tm_c.dominant_ms)
-            hook_acc_clock(be, False)
-            xy_c, inf_c = fold_partials(inp.curve, part_c.reshape(1, -1))
-            if inf_c or not (np.asarray(xy_c) == exp_xy[0]).all():
-                raise SystemExit("MSM self-check failed (clock-reading build of the accumulation)")
+            torch.cuda.synchronize()
+            acc_clock = hook_clock_probe_read(be)
+            acc_clock["accumulate_ms_during_probe"] = float(tm_c.dominant_ms)
+            for i, part_c in enumerate(parts_c):
+                xy_c, inf_c = fold_partials(inp.curve, part_c.reshape(1, -1))
+                if inf_c or not (np.asarray(xy_c) == exp_xy[i % 2]).all():
+                    raise SystemExit("MSM self-check failed (batch under the clock probe)")
         except SystemExit:
             raise
-        except Exception as e:  # noqa: BLE001 -- small inputs run the four-lane kernel, which carries no clock reads
+        except Exception as e:  # noqa: BLE001
             acc_clock = {"error": f"{type(e).__name__}: {e}"}
+    _dbg_c2("after headline")
     scaling_model = None
     if rank == 0 and world == 1 and not args.no_configs and args.log_n >= 22:
         def _leg_scaling_model():
@@ -1392,7 +1414,9 @@ def main():
                             "multi_gpu_throughput": "not measured at N = 1 (see scaling.config4 of a --gpus N run)", "exchange": r4["exchange"],
                             "groth16_one_proof_over_8_virtual_ranks": r4.get("groth16_one_proof_over_ranks")}
 
+        _dbg_c2("before config 1")
         _guard("config1", _leg_c1)
+        _dbg_c2("after config 1")
         _guard("config2", _leg_c2)
         _guard("config4", _leg_c4)
         configs["3"] = "see ntt (2^24 BLS12-381 Fr forward + inverse)"

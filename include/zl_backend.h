@@ -247,8 +247,10 @@ int zl_groth16_prove_circuit(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit
  * prover lanes (ctx itself and a fork of it that the ctx keeps for later calls) -- the proofs are the ones `count` calls of zl_groth16_prove_circuit return,
  * byte for byte, at the throughput of two lanes (958 465 constraints: 17.7 instead of 18.8 ms per proof; 14 977: 2.35 instead of 3.05; 235: 0.9 instead of
  * 1.5).  ctx must be the root ctx the keys live on and the keys must be bound to their circuit (compiled here, or proven once after decoding); circuits may
- * repeat.  The first failure is returned and the remaining proofs are not started.  While the kept lane exists the ctx refuses zl_bases_free /
- * zl_bases_precompute / zl_r1cs_free like any forked ctx: zl_ctx_drop_lanes(ctx) releases it (zl_ctx_destroy does too). */
+ * repeat.  The first failure is returned and the remaining proofs are not started.  The kept lane is the library's own fork and pins nothing once the call
+ * has returned: zl_bases_free / zl_bases_precompute / zl_r1cs_free on the ctx release it first when it is idle (round 6; forks the CALLER made with
+ * zl_ctx_fork still pin the parent's handles).  zl_ctx_drop_lanes(ctx) releases it explicitly (zl_ctx_destroy does too); it returns ZL_EINVAL while a call is
+ * using the lane. */
 int zl_groth16_prove_circuits(zl_ctx* ctx, const zl_g16_keys* k, const zl_circuit* const* circuits, const uint64_t* seeds, size_t count, zl_g16_proof* proofs);
 int zl_ctx_drop_lanes(zl_ctx* ctx);
 

@@ -141,11 +141,11 @@ int zl_ctx_drop_lanes(zl_ctx* ctx) {
     if (!ctx) return ZL_EINVAL;
     if (ctx->pipeline_busy.load()) return ZL_EINVAL;
     zl_ctx* l = ctx->stream_lane_ctx;
+    if (l && l->pipeline_busy.load()) return ZL_EINVAL;  // (the lane itself may be inside a call)
     ctx->stream_lane_ctx = nullptr;
     if (l) zl_ctx_destroy(l);
     return ZL_OK;
 }
-
 void zl_ctx_destroy(zl_ctx* ctx) {
     if (!ctx) return;
     if (ctx->stream_lane_ctx) { zl_ctx* l = ctx->stream_lane_ctx; ctx->stream_lane_ctx = nullptr; zl_ctx_destroy(l); }
@@ -290,6 +290,7 @@ int zl_bases_precompute(zl_ctx* ctx, uint64_t handle, int c) {
     if (!ctx || c < 0) return ZL_EINVAL;
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ZL_EHANDLE;
+    zl_ctx_release_idle_lane(ctx);
     if (ctx->forks.load() > 0) return ZL_EINVAL;  // the table replaces what the lanes read: build it before forking
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     return ZL_DISPATCH(it->second.curve, it->second.group, zl_bases_precompute, ctx, it->second, c);
@@ -298,6 +299,7 @@ int zl_bases_free(zl_ctx* ctx, uint64_t handle) {
     if (!ctx) return ZL_EINVAL;
     auto it = ctx->bases.find(handle);
     if (it == ctx->bases.end()) return ZL_EHANDLE;
+    zl_ctx_release_idle_lane(ctx);
     if (ctx->forks.load() > 0) return ZL_EINVAL;  // a fork may be reading it: destroy the forks first
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_pts) (void)hipFree(it->second.d_pts);

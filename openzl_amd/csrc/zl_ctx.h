@@ -211,6 +211,14 @@ inline std::mutex& zl_bases_cache_mutex() {
 int zl_ctx_aux_init(zl_ctx* ctx);
 int zl_ctx_streams_init(zl_ctx* ctx);
 
+// The fork zl_groth16_prove_circuits keeps for its second host thread is the LIBRARY's, not the caller's: it must not pin the parent's handles once the call
+// that used it has returned (zl_bases_free / zl_r1cs_free / zl_bases_precompute on the root ctx returned ZL_EINVAL after one prove_many(),
+// and the callers that ignored the code leaked the whole device-resident key).  Every entry that refuses to run beside a live fork releases that idle lane first;
+// forks the CALLER made (zl_ctx_fork) still pin the handles, as documented.
+inline void zl_ctx_release_idle_lane(zl_ctx* ctx) {
+    if (ctx && ctx->stream_lane_ctx && !ctx->pipeline_busy.load()) (void)zl_ctx_drop_lanes(ctx);
+}
+
 // developer tuning knob / deployment limit read from the environment (unset = the default)
 inline int zl_tune(const char* name, int dflt) {
     const char* v = getenv(name);

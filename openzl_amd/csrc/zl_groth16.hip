@@ -570,6 +570,7 @@ extern "C" int zl_r1cs_free(zl_ctx* ctx, uint64_t handle) {
     if (!ctx) return ZL_EINVAL;
     auto it = ctx->r1cs.find(handle);
     if (it == ctx->r1cs.end()) return ZL_EHANDLE;
+    zl_ctx_release_idle_lane(ctx);
     if (ctx->forks.load() > 0) return ZL_EINVAL;  // a fork may be reading it: destroy the forks first
     ZL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (it->second.d_base) (void)hipFree(it->second.d_base);

@@ -537,9 +537,11 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
 template <class E>
 void Groth16<E>::release(ProvingContext& pc) {
     if (!pc.ctx) return;
+    // a handle whose free is REFUSED (a fork the caller made still lives: ZL_EINVAL) stays in the context, so that a later release -- or zl_ctx_destroy --
+    // still finds it (zeroing it leaked the device-resident key)
     for (uint64_t* h : {&pc.a_query, &pc.b_g1_query, &pc.b_g2_query, &pc.h_query, &pc.l_query})
-        if (*h) { (void)zl_bases_free(pc.ctx, *h); *h = 0; }
-    if (pc.r1cs) { (void)zl_r1cs_free(pc.ctx, pc.r1cs); pc.r1cs = 0; }
+        if (*h && zl_bases_free(pc.ctx, *h) != ZL_EINVAL) *h = 0;
+    if (pc.r1cs && zl_r1cs_free(pc.ctx, pc.r1cs) != ZL_EINVAL) pc.r1cs = 0;
 }
 
 // Groth16::prove (groth16.rs:445-457): r, s <- rng; create_proof_with_assignment on the device

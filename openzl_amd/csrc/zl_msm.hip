@@ -235,11 +235,15 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // additions, not its sorts.  And a pipeline that skips the sort of a repeated scalar vector would skip work inside bench.py's timed steps.)
     const size_t per = sizeof(X) * (max_sets + 1) + 16;
     if (ctx->pinned_cap < per * count) {
+        // grown ONCE to what any ordinary batch needs (24 jobs of 320 root channels: 3.8 MB for G2), not to this call's exact size: a reallocation of pinned memory
+        // costs 1-2 ms, and a batch of another length or another window plan paid it inside its own timed region (bench.py's config-2 leg: 3.44 instead of 3.2 ms
+        // per MSM for the first 6-step batch behind 3- and 2-step ones, profiles/r06_c2_diag.log)
+        const size_t want = std::max(per * count, (sizeof(X) * 320 + 16) * (size_t)24);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr;
         ctx->pinned_cap = 0;
-        ZL_HIP(ctx, hipHostMalloc(&ctx->pinned, per * count, hipHostMallocDefault));
-        ctx->pinned_cap = per * count;
+        ZL_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_cap = want;
     }
     for (size_t i = 0; i < count; i++) {
         unsigned char* base = reinterpret_cast<unsigned char*>(ctx->pinned) + per * i;
@@ -251,17 +255,15 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // for small jobs -- a chain of ~25 dependent group operations at a few lanes each -- they are what the pipeline's latency consists of:
     // four 237-point MSMs of a small proof finished their tails one after the other in 2.1 ms, now side by side.
     hipStream_t s_tails[3] = {ctx->stream_tail[0], ctx->stream_tail[1], ctx->stream_tail[2]};
-    // k_msm_accumulate_persist (room for the side streams) is OFF: measured at 2^24 (profiles/r03_persist_accumulate.log) the sort and the
-    // tail do move under the accumulation and the gap between accumulations closes, but the accumulation itself goes from 33.4 to 38.9 ms
-    // beside the sort and to ~50 ms beside the level-0 / tree kernels (two instruction streams of 40-60 KB each share one 64-KB instruction
-    // cache per CU pair, and the tail kernels' own additions take 6-10 ms instead of 1.6): 49.9 ms per MSM against 37.6.  ZL_TUNE_ACC_WG_PER_CU=2 enables it.
-    const int acc_wg_per_cu = sizeof(X) > 256 ? 0 : zl_tune("ZL_TUNE_ACC_WG_PER_CU", 0);
+    // (A persistent two-wave accumulation that leaves room for the side streams was built in round 3 and removed in round 6: the sort and the tail do move under
+    // it, but two co-resident field-arithmetic kernels share one instruction cache -- 49.9 ms per 2^24 MSM against 37.6, profiles/r03_persist_accumulate.log.)
     // (Measured and dropped: making the accumulation of job i+1 wait for the merge kernels / level 0 of job i, so that two field-arithmetic
     // kernels never share the machine -- 958 465-constraint proof 19.2-19.4 ms with or without, 2^20 batches 3.65 = 3.65 ms per MSM.)
     // events from the ctx's pool (zl_ctx_events): [sorted | tail | acc (untimed runs)] without timing, [begin, end | acc0 | acc (timed runs)] with
     hipEvent_t *pool_nt = nullptr, *pool_t = nullptr;
-    if ((rc = zl_ctx_events(ctx, 0, 4 * count, &pool_nt))) return rc;
-    if ((rc = zl_ctx_events(ctx, 1, 2 + (ctx->timing_on ? 2 * count : 0), &pool_t))) return rc;
+    // (pools grown to at least a 24-job batch at once: an event costs ~50 us to create, and a longer batch than any before paid that inside its own call)
+    if ((rc = zl_ctx_events(ctx, 0, 4 * std::max<size_t>(count, 24), &pool_nt))) return rc;
+    if ((rc = zl_ctx_events(ctx, 1, 2 + (ctx->timing_on ? 2 * std::max<size_t>(count, 24) : 0), &pool_t))) return rc;
     hipEvent_t* ev_sorted = pool_nt;
     hipEvent_t* ev_tail = pool_nt + count;
     hipEvent_t* ev_acc = ctx->timing_on ? pool_t + 2 + count : pool_nt + 2 * count;
@@ -312,7 +314,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         if (e == hipSuccess && ctx->timing_on) e = hipEventRecord(ev_acc0[i], js_acc);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
         int r;
-        if ((r = jobs[i].accumulate(ctx, js_acc, acc_wg_per_cu))) return r;
+        if ((r = jobs[i].accumulate(ctx, js_acc))) return r;
         e = hipEventRecord(ev_acc[i], js_acc);
         if (e == hipSuccess) e = hipStreamWaitEvent(s_tail, ev_acc[i], 0);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }

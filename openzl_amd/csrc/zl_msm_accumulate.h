@@ -99,7 +99,8 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
                                             reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
     }
 }
-// MEASUREMENT ONLY (zl_test_acc_clock, include/zl_backend_test.h): the same kernel with four scalar clock reads per WAVE -- s_memtime (shader cycles) and
+#ifdef ZL_MEASURE
+// MEASUREMENT BUILDS ONLY (-DZL_MEASURE: ZL_EXTRA_FLAGS=-DZL_MEASURE ZL_BUILD_TAG=measure python -m openzl_amd.build; zl_test_acc_clock, include/zl_backend_test.h): the same kernel with four scalar clock reads per WAVE -- s_memtime (shader cycles) and
 // s_memrealtime (the constant 100 MHz counter) at its start and at its end -- so that the effective shader clock of the accumulation (the chip clocks
 // dense VALU bodies to its power budget, MI355X_MICROARCH.md "DVFS give-back") is read from the kernel itself: sum of cycle deltas / sum of tick deltas.
 // One record of four u64 per workgroup (= wave).  G1 groups only; never launched by the product path unless the hook armed ctx->acc_clk.
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
         }
     }
 }
+#endif
 // The same chunks with FOUR lanes per chunk (zl_quad.h): for lists that do not fill the machine (small MSMs), where the time of the launch is
 // the latency of one lane's chain of mixed additions -- 4 product slots per addition instead of 10.5.
 template <class G>
@@ -190,33 +192,17 @@ __global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(c
         else pair_store(&partials[(size_t)2 * t + (b_start <= start ? 0 : 1)], half, acc);
     }
 }
-// The same chunks on a grid that does NOT fill the register file (pipelined batches): k_msm_accumulate at three waves per SIMD holds 498 of
-// the 512 registers of every SIMD for as long as it runs, so the sort of the next MSM and the tail of the previous one only get onto the
-// machine when it ends (rocprofv3 of a batch, profiles/r03_glv_ab.log: 3.5 ms between consecutive accumulations in which those two run alone).
-// Here `wg_per_cu` workgroups of 256 lanes per CU (2: two waves per SIMD, 332 registers) loop over the chunks, which leaves a wave slot of
-// ~180 registers per SIMD and all of the LDS to the side streams for the whole accumulation.  Measured and NOT used by default (see
-// msm_run_jobs_t): the overlap happens, but both co-resident field-arithmetic kernels slow down far more than the gap was worth.
-#define ZL_ACC_PERSIST_BLOCK 256
-template <class G>
-__global__ void __launch_bounds__(ZL_ACC_PERSIST_BLOCK, ZL_ACC_WAVES) k_msm_accumulate_persist(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
-                                                        const Affine<typename G::F>* __restrict__ bases_,
-                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
-                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
-                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real, uint32_t nchunks) {
-    using F = typename HotField<typename G::F>::type;
-    const uint32_t E = offsets[NB];
-    // lanes of one wave take consecutive chunks (neighbouring entries), the grid strides over the list
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += gridDim.x * blockDim.x)
-        zl_accumulate_chunk<G>(t, 0, E, entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_), reinterpret_cast<XYZZ<F>*>(bucket_sums_),
-                               reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK, reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
-}
-
 // every instantiation MsmJob<G>::accumulate launches: X = empty defines them (zl_msm_acc.hip), X = extern only declares them
+#ifdef ZL_MEASURE
+#define ZL_MSM_ACCUMULATE_CLK_KERNEL(X, G) X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*, uint32_t);
+#else
+#define ZL_MSM_ACCUMULATE_CLK_KERNEL(X, G)
+#endif
 #define ZL_MSM_ACCUMULATE_KERNELS(X, G) \
+    ZL_MSM_ACCUMULATE_CLK_KERNEL(X, G) \
     X template __global__ void k_msm_accumulate<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_pair<G, true>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_pair<G, false>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_carry<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
-    X template __global__ void k_msm_accumulate_clk<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, unsigned long long*, uint32_t); \
-    X template __global__ void k_msm_accumulate_persist<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t, uint32_t);
+

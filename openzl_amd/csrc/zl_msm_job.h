@@ -454,13 +454,8 @@ struct MsmJob {
         return ZL_OK;
     }
     static constexpr bool pair_ok() { return G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value; }  // an Fq2 group on 28-bit limbs: the lane-pair kernels exist
-    // wg_per_cu > 0: the persistent form (pipelined batches) on wg_per_cu x CUs workgroups
-    int accumulate(zl_ctx* ctx, hipStream_t st, int wg_per_cu = 0) {
-        const uint32_t lanes_persist = (uint32_t)wg_per_cu * (uint32_t)ctx->cu_count * ZL_ACC_PERSIST_BLOCK;
-        if (wg_per_cu > 0 && ctx->cu_count > 0 && nchunks >= 8 * (uint64_t)lanes_persist)  // >= 8 chunks per lane: the last, partial round costs little
-            hipLaunchKernelGGL((k_msm_accumulate_persist<G>), dim3((uint32_t)wg_per_cu * (uint32_t)ctx->cu_count), dim3(ZL_ACC_PERSIST_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases,
-                               d_buckets, d_partials, ZL_CHUNK, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, nchunks);
-        else if (carry_in)
+    int accumulate(zl_ctx* ctx, hipStream_t st) {
+        if (carry_in)
             hipLaunchKernelGGL((k_msm_accumulate_carry<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
@@ -472,12 +467,16 @@ struct MsmJob {
         else if (pair_ok() && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)
             hipLaunchKernelGGL((k_msm_accumulate_pair<G, false>), dim3((nchunks + 31) / 32), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
+#ifdef ZL_MEASURE
         else if (G::COORDS == 1 && ctx->acc_clk && (size_t)((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK) * 32 <= ctx->acc_clk_cap) {  // armed by the measurement hook zl_test_acc_clock only
             ctx->acc_clk_waves = (nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK;
             hipLaunchKernelGGL((k_msm_accumulate_clk<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu, (unsigned long long*)ctx->acc_clk,
                                zl_tune("ZL_TUNE_ACC_CLK_IDX_BITS", 31) >= 31 ? 0x7fffffffu : ((1u << zl_tune("ZL_TUNE_ACC_CLK_IDX_BITS", 31)) - 1u));
         } else
+#else
+        else
+#endif
         hipLaunchKernelGGL((k_msm_accumulate<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                            glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         ZL_HIP(ctx, hipGetLastError());

@@ -552,7 +552,13 @@ static unsigned long long* g_probe_buf = nullptr;
 int zl_test_clock_probe_launch(zl_ctx* ctx, unsigned spin_us) {
     if (!ctx || spin_us < 1 || spin_us > 2000000) return ZL_EINVAL;
     ZL_HIP(ctx, hipSetDevice(ctx->device));
-    if (!g_probe_stream) ZL_HIP(ctx, hipStreamCreateWithFlags(&g_probe_stream, hipStreamNonBlocking));
+    if (!g_probe_stream) {
+        // in the high stream-priority class: those streams have hardware queues of their own, so the probe never shares a queue (= runs in turn) with a chain of
+        // the work it is meant to observe (round 6: on a default-class stream the probe of a pipelined MSM batch read 2.40 GHz -- it had run beside nothing)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&g_probe_stream, hipStreamNonBlocking, hi));
+    }
     if (!g_probe_buf) ZL_HIP(ctx, hipMalloc((void**)&g_probe_buf, 8 * 32));
     ZL_HIP(ctx, hipMemsetAsync(g_probe_buf, 0, 8 * 32, g_probe_stream));
     hipLaunchKernelGGL(k_clock_spin, dim3(8), dim3(64), 0, g_probe_stream, g_probe_buf, (unsigned long long)spin_us * 100ull);

@@ -160,7 +160,7 @@ def test_parent_destroyed_before_its_lane_orphans_it(backend):
 @pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
 def test_prove_many_is_a_stream_of_single_proofs(backend, curve):
     """zl_groth16_prove_circuits (two host threads inside the library, the ctx and a fork it keeps): proofs[i] == prove(seeds[i], circuits[i]) byte for byte;
-    the error of a bad element comes back; the kept lane pins the key until zl_ctx_drop_lanes"""
+    the error of a bad element comes back; the kept lane does NOT pin the key once the call has returned"""
     k = 6
     full = Circuit(curve.cid, k)
     wits = [Circuit(curve.cid, k, x0=10 + j, x1=j, witness_only=True) for j in range(3)]
@@ -177,8 +177,15 @@ def test_prove_many_is_a_stream_of_single_proofs(backend, curve):
         with pytest.raises(BackendError):
             keys.prove_many(seeds[:4], [full, wits[0], wrong, wits[1]])
         assert all(_same(a, b) for a, b in zip(single, keys.prove_many(seeds, [c or full for c in circs])))  # usable after an error
+        # the lane the library keeps between prove_many calls is ITS fork, not the caller's: it must not pin the key (a free refused with
+        # ZL_EINVAL whose handle the caller then dropped leaked the whole device-resident key).  Freeing the key right after prove_many works and frees it.
+        a_q = keys.pk.a_query
+        import torch
+        free0 = torch.cuda.mem_get_info()[0]
+        keys.close()
         with pytest.raises(BackendError):
-            backend.bases_free(keys.pk.a_query)   # the kept lane reads it
+            backend.bases_download(a_q, 0, 1)     # the handle is gone ...
+        assert torch.cuda.mem_get_info()[0] >= free0  # ... and nothing of the key stayed behind
         assert backend.L.zl_ctx_drop_lanes(backend._ctx) == 0
     finally:
         backend.L.zl_ctx_drop_lanes(backend._ctx)
