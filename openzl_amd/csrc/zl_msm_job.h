@@ -20,7 +20,7 @@ static int zl_pick_window(size_t n, int sc_bits, bool wide16 = false /* c = 16 a
     // bucket range and is the slower sort at large n) + ~5.7 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
     // single-call times at 2^20 .. 2^24, both curves (profiles/r02_msm_sweep_plain.log, r02_msm_sweep_bn254.log): picks 16 up to 2^21,
     // 18 at 2^22 - 2^23, 19 at 2^24.  c = 17..20 run the three-level sort over W bucket sets (<= 255 sort groups).
-    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 57) / 10.0;
+    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 52) / 10.0;
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 20; c++) {
