@@ -10,7 +10,7 @@
  */
 #ifndef ZL_BACKEND_TEST_H
 #define ZL_BACKEND_TEST_H
-#include "zl_backend.h"
+#include "zl_backend_ext.h"
 #ifdef __cplusplus
 extern "C" {
 #endif

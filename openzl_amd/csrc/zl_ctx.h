@@ -9,7 +9,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <vector>
-#include "../../include/zl_backend.h"
+#include "../../include/zl_backend_ext.h"
 #include "zl_curve.h"
 #include "zl_pool.h"
 

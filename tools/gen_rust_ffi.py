@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate plugins/arkworks-mi355x/src/ffi.rs -- the complete `extern "C"` block of include/zl_backend.h (every function, struct,
+"""Generate plugins/arkworks-mi355x/src/ffi.rs -- the complete `extern "C"` block of include/zl_backend.h + include/zl_backend_ext.h (every function, struct,
 enum constant and flag) -- so that the Rust shim can never drift from the header: tests/test_abi.py regenerates it and compares.
     python tools/gen_rust_ffi.py [--check]
 The Rust itself cannot be compiled in this image (no cargo / rustc); the generator guarantees names, arity and pointer shapes only."""
@@ -8,7 +8,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HDR = os.path.join(ROOT, "include", "zl_backend.h")
+HDR = os.path.join(ROOT, "include", "zl_backend.h")          # the drop-in boundary
+HDR_EXT = os.path.join(ROOT, "include", "zl_backend_ext.h")  # everything beyond it (same library)
 OUT = os.path.join(ROOT, "plugins", "arkworks-mi355x", "src", "ffi.rs")
 
 SCALAR = {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "size_t": "usize", "long": "core::ffi::c_long", "uint64_t": "u64", "uint32_t": "u32",
@@ -117,9 +118,10 @@ def constants(text_raw: str, text: str):
 
 
 def generate() -> str:
-    raw = open(HDR).read()
+    raw = open(HDR).read() + "\n" + open(HDR_EXT).read()
     text = strip_comments(raw)
-    lines = ["// GENERATED by tools/gen_rust_ffi.py from include/zl_backend.h -- do not edit; tests/test_abi.py::test_rust_ffi_matches_header",
+    boundary = {n for n, _, _ in functions(strip_comments(open(HDR).read()))}
+    lines = ["// GENERATED by tools/gen_rust_ffi.py from include/zl_backend.h (the boundary) and include/zl_backend_ext.h -- do not edit; tests/test_abi.py::test_rust_ffi_matches_header",
              "// regenerates this file and fails on any difference.  UNTESTED as Rust: this image has no cargo / rustc.",
              "#![allow(non_camel_case_types, dead_code)]", ""]
     for o in OPAQUE:
@@ -137,9 +139,14 @@ def generate() -> str:
     lines.append("")
     lines.append('#[link(name = "zl_backend")]')
     lines.append('extern "C" {')
-    for name, ps, ret in functions(text):
-        args = ", ".join(f"{n}: {t}" for n, t in ps)
-        lines.append(f"    pub fn {name}({args})" + (f" -> {ret};" if ret else ";"))
+    fns = functions(text)
+    for part, title in ((True, "include/zl_backend.h: the drop-in boundary"), (False, "include/zl_backend_ext.h: pipelines, shards, lanes, host-mirror hooks, codecs, timing")):
+        lines.append(f"    // ---- {title}")
+        for name, ps, ret in fns:
+            if (name in boundary) != part:
+                continue
+            args = ", ".join(f"{n}: {t}" for n, t in ps)
+            lines.append(f"    pub fn {name}({args})" + (f" -> {ret};" if ret else ";"))
     lines.append("}")
     return "\n".join(lines) + "\n"
 
