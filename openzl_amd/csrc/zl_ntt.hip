@@ -57,11 +57,24 @@ __device__ __forceinline__ void lds_store(uint32_t* sh, uint32_t pos, const F& v
 #pragma unroll
     for (int k = 0; k < F::N; k++) sh[k * NTT_TILE + pos] = v.l[k];
 }
+#ifndef ZL_NTT_ROW_SWIZZLE
+#define ZL_NTT_ROW_SWIZZLE 0  // measured: conflicts 57 % -> 0, time +1 % (the passes are bound by VALU issue, the LDS cycles were hidden): off; -DZL_NTT_ROW_SWIZZLE=1 rebuilds it
+#endif
 __device__ __forceinline__ uint32_t tile_pos(uint32_t row, uint32_t col, uint32_t logC) {
     // swizzle columns so that consecutive rows of one column fall into different LDS banks
     uint32_t C = 1u << logC;
     uint32_t rows_per_wrap_log = logC >= 5 ? 0 : 5 - logC;
     uint32_t cs = (col + (row >> rows_per_wrap_log)) & (C - 1);
+#if ZL_NTT_ROW_SWIZZLE
+    // Round 6 (profiles/r06_ntt_lds_counters.txt: SQ_LDS_BANK_CONFLICT = 57 % of SQ_LDS_IDX_ACTIVE in a 2^8-point pass): with four-column rows (the 2^8 x 4 tiles
+    // of every pass of a 2^24 transform) a row owns the four banks (row mod 8) * 4 .. + 3 of the 32 that ds_read2_b32 / ds_write see, and the column swizzle
+    // above only permutes inside that group.  The rows a half-wave (32 lanes = 8 rows x 4 columns, the conflict domain) touches at once differ in row bits
+    // {0,1,2} (load phase, butterfly distances 64 and 16), {0,1,4} (distance 4), {2,3,4} (distance 1) and {5,6,7} (store phase: bit-reversed rows) -- the
+    // last three put 2, 4 and 8 rows on one bank group.  XOR-ing the low three row bits with b0 = r4 ^ r5, b1 = r3 ^ r6, b2 = r4 ^ r7 makes the bank group a
+    // GF(2)-linear function of the row whose restriction to each of those four bit sets is invertible: eight distinct groups in every phase; and
+    // row -> row ^ f(row >> 3) is a bijection, so the tile stays a permutation of itself.
+    if (logC == 2) row ^= (((row >> 4) ^ (row >> 5)) & 1u) | ((((row >> 3) ^ (row >> 6)) & 1u) << 1) | ((((row >> 4) ^ (row >> 7)) & 1u) << 2);
+#endif
     return (row << logC) | cs;
 }
 template <class F>
