@@ -151,6 +151,12 @@ public:
     }
     // multiplication: one constraint a * b = out with a fresh witness; constants fold
     FpVar<FrP> mul(const FpVar<FrP>& a, const FpVar<FrP>& b) {
+        // Constant folding: the full compiler decides from the linear combination (no variable term left), the witness-only compiler -- it forms no
+        // linear combinations -- from the `konst` flag the operations above propagate.  The two rules differ for a combination whose variable terms CANCEL
+        // (x - x: constant for the full compiler, konst = false); a circuit that contains one would allocate witnesses differently in the two modes and a
+        // witness-only assignment would not line up with the resident matrices.  The full compiler therefore records any disagreement, and a
+        // proving context bound from such a compiler refuses witness-only compilers (Groth16::prove).
+        if (!witness_only() && (a.lc.is_constant() != a.konst || b.lc.is_constant() != b.konst)) fold_rules_disagree_ = true;
         if (witness_only() ? a.konst : a.lc.is_constant()) return mul_const(b, a.value);
         if (witness_only() ? b.konst : b.lc.is_constant()) return mul_const(a, b.value);
         FpVar<FrP> out = new_witness(zl::mul(a.value, b.value));
@@ -167,6 +173,8 @@ public:
         C_.push_back(b.lc);
     }
     bool equalities_hold() const { return equal_ok_; }  // witness-only: every enforce_equal saw equal values
+    // full compiler: every multiplication folded constants the way a witness-only run of the same circuit code will (see mul)
+    bool witness_only_compatible() const { return !fold_rules_disagree_; }
     // Measure (openzl-crypto/src/constraint.rs:151-188; plugin impl constraint/mod.rs:169-177)
     size_t constraint_count() const { return A_.size(); }
     size_t public_variable_count() const { return instance_.size() - 1; }
@@ -237,7 +245,7 @@ public:
 private:
     explicit R1CS(Mode m) : mode_(m) { instance_.push_back(F::one()); }
     Mode mode_;
-    bool equal_ok_ = true;
+    bool equal_ok_ = true, fold_rules_disagree_ = false;
     std::vector<F> instance_, witness_;
     std::vector<LC> A_, B_, C_;
     mutable uint64_t digest_ = 0;
@@ -424,6 +432,7 @@ struct Groth16 {
         mutable uint64_t r1cs = 0;
         mutable size_t n_constraints = 0;
         mutable uint64_t circuit_digest = 0;
+        mutable bool witness_only_ok = true;  // the bound circuit folds constants alike in both compiler modes (R1CS::witness_only_compatible)
         std::vector<uint64_t> alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2;
         size_t n_instance = 0, n_witness = 0, domain_size = 0;
         Trapdoor trapdoor;  // kept ONLY so tests can recompute proofs in the exponent; a real setup drops it

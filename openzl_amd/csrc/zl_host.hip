@@ -252,6 +252,7 @@ Result<std::pair<typename Groth16<E>::ProvingContext, typename Groth16<E>::Verif
         rc = zl_r1cs_upload(ctx, E::curve, exported ? &exported->view : &own.view, &pc.r1cs);
         pc.n_constraints = nc;
         pc.circuit_digest = cs.structure_digest();
+        pc.witness_only_ok = cs.witness_only_compatible();
     }
     lap("r1cs export + upload");
     // alpha*G1, beta*G1, delta*G1, beta*G2, delta*G2
@@ -553,6 +554,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
     if (cs.mode() == Compiler::Mode::Setup) return res;  // the reference panics when a setup-mode compiler reaches prove
     if (cs.num_instance_variables() != pc.n_instance || cs.secret_variable_count() != pc.n_witness) return res;
     if (cs.witness_only() && !pc.r1cs) return res;  // a witness-only compiler has no rows to bind an unbound context to
+    if (cs.witness_only() && !pc.witness_only_ok) return res;  // the bound circuit allocates witnesses differently without its rows (R1CS::mul)
     const F r = sample_canonical<FrP>(rng), s = sample_canonical<FrP>(rng);
     if (r_out) *r_out = r;
     if (s_out) *s_out = s;
@@ -570,6 +572,7 @@ Result<typename Groth16<E>::Proof> Groth16<E>::prove(const ProvingContext& pc, c
         if (rc_up) { res.error = Error{rc_up}; return res; }
         pc.n_constraints = nc;
         pc.circuit_digest = cs.structure_digest();
+        pc.witness_only_ok = cs.witness_only_compatible();
     }
     // only the assignment travels per proof; the matrices and the proving key are device-resident.  It goes to the device straight from the
     // compiler's two vectors (Montgomery limbs as held): no host-side concatenation

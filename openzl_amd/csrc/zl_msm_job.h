@@ -487,7 +487,14 @@ struct MsmJob {
         const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
         const uint32_t carry = carry_in ? 1u : 0u;
         const bool pair_tails = pair_ok() && zl_tune("ZL_TUNE_G2_PAIR_TAILS", 1), octet = pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1);  // Fq2 groups: two lanes per item where a launch fills the machine
-        if (pair_tails && NB > quad_max)
+        const bool by_cuts = !carry && NB > quad_max && nchunks > 1 && zl_tune("ZL_TUNE_MERGE_CUTS", 1);  // one lane (pair) per chunk boundary: every surviving lane folds one bucket
+        if (by_cuts) {
+            hipLaunchKernelGGL((k_msm_fill_empty<G>), dim3((NB + 255) / 256), dim3(256), 0, st, d_offsets, NB, d_buckets);
+            if (pair_tails)
+                hipLaunchKernelGGL((k_msm_merge_cuts_pair<G>), dim3((nchunks + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, nchunks);
+            else
+                hipLaunchKernelGGL((k_msm_merge_cuts<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, nchunks);
+        } else if (pair_tails && NB > quad_max)
             hipLaunchKernelGGL((k_msm_merge_pair<G, false>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else if (octet && NB <= quad_max)
             hipLaunchKernelGGL((k_msm_merge_pair<G, true>), dim3((NB + 7) / 8), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);

@@ -46,6 +46,54 @@ __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 25
     }
     if (sub == 0) bucket_sums[b] = acc;
 }
+// The same merge with one lane per CHUNK BOUNDARY instead of one per bucket (round 6, launches that fill the machine): a bucket is cut where a chunk boundary
+// p = t * ZL_CHUNK falls strictly inside it, and with tens of entries per bucket and 64-128 per chunk only every third to fourth bucket is -- in k_msm_merge
+// three lanes of four leave at once and the additions of the rest run at a quarter of the wave (1.27 ms for 1.7 M additions at 2^24, c = 20: 1.3 additions
+// per ns where the level-0 kernel sustains 5.5).  Here lane t looks up the bucket that holds entry p (the binary search the accumulation does per chunk) and
+// folds its partials iff p is the FIRST boundary inside that bucket, so every lane that passes the two tests has exactly one bucket to fold.  Empty buckets
+// are written by k_msm_fill_empty (memory-bound, no field arithmetic).  Same partials, same lists, same sums as k_msm_merge (carry = 0 only).
+__device__ __forceinline__ uint32_t zl_bucket_of_entry(const uint32_t* __restrict__ offsets, uint32_t NB, uint32_t p) {
+    uint32_t lo = 0, hi = NB + 1;  // first index with offsets[idx] > p, minus one: offsets[b] <= p < offsets[b + 1] (never an empty bucket)
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= p) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+template <class G>
+__global__ void __launch_bounds__(256) k_msm_fill_empty(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums) {
+    ZL_SIDE_PRIO();
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB || offsets[b] != offsets[b + 1]) return;
+    bucket_sums[b] = XYZZ<typename G::F>::inf();
+}
+template <class G>
+__global__ void __launch_bounds__(64, sizeof(XYZZ<typename G::F>) <= 256 ? 3 : 1) k_msm_merge_cuts(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
+                                                   const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
+                                                   uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
+                                                   uint32_t ZL_CHUNK, uint32_t big_span, uint32_t nchunks) {
+    ZL_SIDE_PRIO();
+    using F = TailF<typename G::F>;
+    XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
+    const XYZZ<F>* __restrict__ partials = reinterpret_cast<const XYZZ<F>*>(partials_);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;  // boundary between chunks t - 1 and t
+    if (t >= nchunks) return;
+    const uint64_t p64 = (uint64_t)t * ZL_CHUNK;
+    if (p64 >= offsets[NB]) return;
+    const uint32_t p = (uint32_t)p64;
+    const uint32_t b = zl_bucket_of_entry(offsets, NB, p);
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    if (s == p || s / ZL_CHUNK != t - 1) return;  // not cut here, or an earlier boundary of the same bucket owns it
+    const uint32_t t0 = t - 1, t1 = (e - 1) / ZL_CHUNK;
+    if (t1 - t0 + 1 > ZL_GIANT_SPAN) { giant_list[atomicAdd(giant_count, 1u)] = b; return; }
+    if (t1 - t0 + 1 > big_span) { big_list[atomicAdd(big_count, 1u)] = b; return; }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t tt = t0; tt <= t1; tt++) {
+        const XYZZ<F> q = partials[(size_t)2 * tt + (s <= tt * ZL_CHUNK ? 0 : 1)];
+        zl::add_full(acc, q);
+    }
+    bucket_sums[b] = acc;
+}
 // lanes of the block-tree kernels: 256 for G1, 128 for G2 (384-B points: a 256-lane block is capped at 256 VGPRs and spills)
 template <class G>
 struct TreeLanes { static constexpr int N = sizeof(XYZZ<typename G::F>) > 256 ? 128 : 256; };
@@ -264,6 +312,35 @@ __global__ void __launch_bounds__(64, 2) k_msm_merge_pair(const uint32_t* __rest
         pair_store(&bucket_sums[b], half, acc);
     }
 }
+template <class G>
+__global__ void __launch_bounds__(64, 2) k_msm_merge_cuts_pair(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                   const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
+                                                   uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
+                                                   uint32_t ZL_CHUNK, uint32_t big_span, uint32_t nchunks) {
+    using B = typename PairBase<typename G::F>::type;
+    if constexpr (!std::is_void<B>::value) {
+        ZL_SIDE_PRIO();
+        using X = XYZZ<Fp2H<B>>;
+        const int half = zl::pair_half();
+        const uint32_t t = ZL_PAIR_ITEM() + 1;  // (k_msm_merge_cuts: one lane PAIR per chunk boundary)
+        if (t >= nchunks) return;
+        const uint64_t p64 = (uint64_t)t * ZL_CHUNK;
+        if (p64 >= offsets[NB]) return;
+        const uint32_t p = (uint32_t)p64;
+        const uint32_t b = zl_bucket_of_entry(offsets, NB, p);
+        const uint32_t s = offsets[b], e = offsets[b + 1];
+        if (s == p || s / ZL_CHUNK != t - 1) return;
+        const uint32_t t0 = t - 1, t1 = (e - 1) / ZL_CHUNK;
+        if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (half == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
+        if (t1 - t0 + 1 > big_span) { if (half == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
+        X acc = X::inf();
+        for (uint32_t tt = t0; tt <= t1; tt++) {
+            const X q = pair_load(&partials[(size_t)2 * tt + (s <= tt * ZL_CHUNK ? 0 : 1)], half);
+            zl::add_full(acc, q);
+        }
+        pair_store(&bucket_sums[b], half, acc);
+    }
+}
 template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, 2) k_msm_reduce_level0_pair(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log, XYZZ<typename G::F>* __restrict__ out) {
@@ -365,6 +442,9 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
     X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_tree<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_reduce_tree<G, true>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_fill_empty<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*); \
+    X template __global__ void k_msm_merge_cuts<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_cuts_pair<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_pair<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_pair<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_reduce_level0_pair<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
