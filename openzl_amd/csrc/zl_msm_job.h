@@ -145,6 +145,11 @@ struct MsmJob {
         // (128 once there are >= 2^20 lanes of that length: half as many cut buckets to merge; 32.8 -> 32.2 ms per pipelined 2^24 MSM)
         ZL_CHUNK = (maxE >> 7) >= (1u << 20) ? 128u : (uint32_t)ZL_CHUNK_MAX;
         while (ZL_CHUNK > 8 && maxE / ZL_CHUNK < (1u << 18)) ZL_CHUNK >>= 1;
+        // ... but never so short that an average bucket is cut into more than ~4 chunks: beyond ZL_BIG_SPAN_SMALL = 8 chunks a bucket leaves the lane-serial fold of
+        // k_msm_merge for one WORKGROUP per bucket (k_msm_merge_big), which is meant for the few heavy buckets of a skewed input, not for all of them.  Round 6 found
+        // the case in a sweep: a 2^14-point G2 MSM (GLS: 65 536 quarter-scalars, c = 11, 64 entries per bucket, 8-entry chunks) spent 3 of its 3.5 ms there --
+        // slower than the 2^16-point MSM (1.4 ms).
+        while (ZL_CHUNK < (uint32_t)ZL_CHUNK_MAX && maxE / std::max<uint64_t>(1, (uint64_t)SETS * H) > (uint64_t)4 * ZL_CHUNK) ZL_CHUNK <<= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         // bucket reduction (k_msm_reduce_level0 + k_msm_reduce_tree): blocks of 8 buckets (4 / 2 for smaller inputs: more lanes, shorter chains)
