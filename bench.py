@@ -1217,7 +1217,7 @@ def main():
             ntt_cpu["parity_full_size"] = True
             del X_cpu, X_gpu
         ntt_traffic, ntt_traffic_src = None, None
-        for cand in ("r05_pmc_traffic_ntt.json", "r04_pmc_traffic_ntt.json"):
+        for cand in ("r06_pmc_traffic_ntt.json", "r05_pmc_traffic_ntt.json", "r04_pmc_traffic_ntt.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if ln == int(pmc["log_n"]):
@@ -1452,7 +1452,7 @@ def main():
                     ntt_info["roofline"]["traffic_detail"] = det
                 except Exception as e:  # noqa: BLE001
                     leg_errors["live_traffic_ntt"] = f"{type(e).__name__}: {e}"
-        for cand in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
+        for cand in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):  # (r03 and earlier hold the un-corrected FETCH + WRITE sum)
             if traffic is not None:
                 break
             try:
@@ -1638,7 +1638,7 @@ def dry_run_plan(args) -> dict:
     N = args.gpus
     n = 1 << args.log_n
     ref, ref_name = None, None
-    for cand in ("r05_bench_final.json", "r04_bench_final.json"):
+    for cand in ("r06_bench_final.json", "r05_bench_final.json", "r04_bench_final.json"):
         try:
             ref = json.loads(open(os.path.join(ROOT, "profiles", cand)).read().strip().split("\n")[-1])
             ref_name = cand

@@ -25,7 +25,7 @@ int zl_ctx_aux_init(zl_ctx* ctx) {
         a->cu_count = ctx->cu_count;
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : (zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
+        hipError_t e = hipStreamCreateWithPriority(&a->own_stream, hipStreamNonBlocking, ax == &ctx->aux ? 0 : prio_hi);
         for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&a->ev[i]);
         a->stream = a->own_stream;
         *ax = a;  // owned by ctx from here on (zl_ctx_destroy)
@@ -36,32 +36,19 @@ int zl_ctx_aux_init(zl_ctx* ctx) {
 // Every stream of the ctx at once, in one fixed order.  The runtime multiplexes the streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4)
 // by the order in which they come into being, and two kernel chains on one hardware queue run in turn (tools/queue_chains.hip) -- created lazily, the lanes of a
 // small proof landed on different queues depending on which legs of a process had run before (bench.py after its MSM legs: 235 constraints 1.5-1.8 ms; a fresh
-// process: 1.05-1.3).  With the whole population created here, a ctx behaves the same whatever it was used for first.  ZL_TUNE_EAGER_STREAMS=0: lazily as before.
+// process: 1.05-1.3).  With the whole population created here, a ctx behaves the same whatever it was used for first.
 int zl_ctx_streams_init(zl_ctx* ctx) {
-    if (!zl_tune("ZL_TUNE_EAGER_STREAMS", 1)) return ZL_OK;
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const int hi = zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0;
-    // ZL_TUNE_STREAM_ORDER (developer sweep, profiles/r05_stream_order_ab.log): where the auxiliary contexts' streams stand among the lanes (default class) and among the
-    // sort / tail / copy streams (high class)
-    const int order = zl_tune("ZL_TUNE_STREAM_ORDER", 0);
+    // The order is the one round 5's sweep of five creation orders found best at all three proof sizes (profiles/r05_stream_order_ab.log): the G2 MSM's and the
+    // witness map's streams, then the four lanes (default class), then sort / tails / copy (high class).  It depends on the HIP runtime's creation-order -> queue
+    // mapping and is not tuned further; the sweep's knobs were removed in round 6.
     int rc = ZL_OK;
-    auto lane = [&](int k) -> int { if (!ctx->stream_lane[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_lane[k], hipStreamNonBlocking)); return ZL_OK; };
-    auto high = [&]() -> int {
-        if (!ctx->stream_sort) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, hi));
-        for (auto& t : ctx->stream_tail) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, hi));
-        if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
-        return ZL_OK;
-    };
-    if (order == 2) { if ((rc = high())) return rc; }  // the high class before the witness map's stream
-    if (order == 1) { for (int k = 0; k < 4; k++) if ((rc = lane(k))) return rc; }  // the lanes before the G2 MSM's stream
-    if (order == 3) { if ((rc = lane(0))) return rc; }
-    if (order == 4) { if ((rc = lane(0)) || (rc = lane(1))) return rc; }
     if ((rc = zl_ctx_aux_init(ctx))) return rc;
-    for (int k = 0; k < 4; k++) if ((rc = lane(k))) return rc;
-    if ((rc = high())) return rc;
-    if (zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 || zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 2)
-        for (auto& t : ctx->stream_lane_lo) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 ? prio_lo : prio_hi));
+    for (int k = 0; k < 4; k++) if (!ctx->stream_lane[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_lane[k], hipStreamNonBlocking));
+    if (!ctx->stream_sort) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, prio_hi));
+    for (auto& t : ctx->stream_tail) if (!t) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prio_hi));
+    if (!ctx->stream_copy) ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, prio_hi));
     return ZL_OK;
 }
 
@@ -176,7 +163,6 @@ void zl_ctx_destroy(zl_ctx* ctx) {
     if (ctx->stream_sort) (void)hipStreamDestroy(ctx->stream_sort);
     for (auto& t : ctx->stream_tail) if (t) (void)hipStreamDestroy(t);
     for (auto& t : ctx->stream_lane) if (t) (void)hipStreamDestroy(t);
-    for (auto& t : ctx->stream_lane_lo) if (t) (void)hipStreamDestroy(t);
     if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     zl_ntt_free(ctx);
@@ -188,7 +174,6 @@ void zl_ctx_destroy(zl_ctx* ctx) {
         if (a->stream_sort) (void)hipStreamDestroy(a->stream_sort);
         for (auto& t : a->stream_tail) if (t) (void)hipStreamDestroy(t);
         for (auto& t : a->stream_lane) if (t) (void)hipStreamDestroy(t);
-        for (auto& t : a->stream_lane_lo) if (t) (void)hipStreamDestroy(t);
         if (a->pinned) (void)hipHostFree(a->pinned);
         zl_ntt_free(a);
         for (auto& ev : a->ev) if (ev) (void)hipEventDestroy(ev);
@@ -368,7 +353,7 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
         // H2D copies; priority means nothing to them.
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, zl_tune("ZL_TUNE_COPY_PRIO", 1) == 2 ? prio_lo : ((zl_tune("ZL_TUNE_COPY_PRIO", 1) && zl_tune("ZL_TUNE_STREAM_PRIO", 1)) ? prio_hi : 0)));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_copy, hipStreamNonBlocking, prio_hi));
     }
     std::vector<hipEvent_t> ev(K, nullptr);
     for (size_t j = 0; j < K; j++) {

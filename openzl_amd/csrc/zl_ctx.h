@@ -116,7 +116,7 @@ struct zl_twiddles {
     void* d_lo = nullptr;  // w^i, i < 2^lo_bits
     void* d_hi = nullptr;  // w^(i << lo_bits)
     void* d_small = nullptr;  // per-radix tables
-    void* d_small_limbs = nullptr;  // the per-radix tables as limbs (ZL_TUNE_NTT_ROOTS_GLOBAL experiment)
+    void* d_small_limbs = nullptr;  // the per-radix tables as limbs (read by the lazy passes' butterflies)
     void* d_last = nullptr;   // combined inter-factor twiddles of the last pass, one per element (multi-pass sizes, built on first use)
     void* d_row[4] = {nullptr, nullptr, nullptr, nullptr};  // per-row twiddles of a MIDDLE pass (index: pass - 1), one row per value of the tile's high index; lazy passes only
     size_t last_bytes = 0;    // ... its size, and when it was last used: the tables of one ctx share a byte budget (ZL_TUNE_NTT_LAST_MB), least recently used first out
@@ -164,7 +164,6 @@ struct zl_ctx {
     uint64_t ntt_clock = 0;
     hipStream_t stream_sort = nullptr;  // pipelined MSM batches: sort | accumulate (ctx->stream) | tail
     hipStream_t stream_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // batches of SMALL MSMs: every job runs sort, accumulation and tail on the stream of its buffer set, the jobs side by side
-    hipStream_t stream_lane_lo[4] = {nullptr, nullptr, nullptr, nullptr};  // the lanes of SMALL side-by-side jobs: low priority class = a hardware-queue pool of their own (zl_msm.hip)
     hipStream_t stream_tail[3] = {nullptr, nullptr, nullptr};  // one tail stream per buffer set: the tails of consecutive small jobs run side by side
     hipStream_t stream_copy = nullptr;  // zl_msm with host scalars: chunked H2D copies that run under the MSMs of the earlier chunks
     void* pinned = nullptr;  // pinned host staging for pipelined results

@@ -602,7 +602,6 @@ template struct R1csExport<BN254_Fr>;
 // the same circuit code run by a witness-only compiler (R1CS::for_witness): every link through the gadget, values only
 template <class FrP>
 static R1CS<FrP> poseidon_chain_witness(uint32_t k, const Fp<FrP>& x0_canon, const Fp<FrP>& x1_canon) {
-    using F = Fp<FrP>;
     static const poseidon::Constants<FrP> consts;
     R1CS<FrP> cs = R1CS<FrP>::for_witness();
     FpVar<FrP> cur = cs.new_witness(zl::to_mont(x0_canon));

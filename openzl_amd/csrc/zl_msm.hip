@@ -155,8 +155,8 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         // highest priority: the short sort / tail kernels must get wave slots as the long accumulation kernel frees them
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
-        for (auto& t : ctx->stream_tail) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, zl_tune("ZL_TUNE_STREAM_PRIO", 1) ? prio_hi : 0));
+        ZL_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream_sort, hipStreamNonBlocking, prio_hi));
+        for (auto& t : ctx->stream_tail) ZL_HIP(ctx, hipStreamCreateWithPriority(&t, hipStreamNonBlocking, prio_hi));
     }
     std::vector<MsmJob<G>> jobs(count);
     size_t t5 = 0, t6 = 0;
@@ -175,8 +175,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // wins (2^24: 36.3 against 37.3 ms)
     const bool carried = specs[0].carried_total != 0;
     const bool side = !carried && biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
-    const bool small_side = side && biggest < ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) != 0;
-    const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, small_side ? zl_tune("ZL_TUNE_SMALL_LANES", 3) : zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
+    const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
     // carried shards: every shard plans with the window width of the whole MSM (same windows, same bucket ids) and without the endomorphism split
     struct ForceC {
         zl_ctx* c;
@@ -196,25 +195,15 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         t6 = std::max(t6, a6);
         max_sets = std::max<uint32_t>(max_sets, jobs[i].SETS * jobs[i].roots_per_set);
     }
-    // SMALL side-by-side jobs (the MSMs of a small proof: chains of ~25 kernels of 5-20 us): which lane streams?  The runtime multiplexes the streams of a process
-    // onto a few hardware queues, and two chains on one queue run in turn (tools/queue_chains.hip).  Round 5 tried lanes of their own in the high and in the low
-    // stream-priority class and the idle tail streams as lanes (ZL_TUNE_SMALL_LANE_PRIO = 2 / 1 / 3): each won in one stream population and lost in another
-    // (profiles/r05_small_lanes_*_ab.log).  What made the difference was WHEN the streams had come into being; with every stream of a ctx created at
-    // zl_ctx_create (zl_ctx_streams_init) the ordinary default-class lanes are the best choice whatever ran before: 235 constraints 1.02-1.09 ms, 14 977
-    // constraints 2.14-2.23 ms (profiles/r05_small_lanes_eager_ab.log; 1.26-1.37 / 2.57-2.65 with lazily created streams).  Default 0 = those lanes.
-    const bool small_lanes = small_side;
-    // (ZL_TUNE_SMALL_LANE_PRIO=3, experiment: the three tail streams of the three-phase pipeline AS the small lanes -- the same streams whatever ran before)
-    const bool reuse_tails = small_lanes && zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 3;
-    hipStream_t reuse[4] = {ctx->stream_tail[0], ctx->stream_tail[1], ctx->stream_tail[2], ctx->stream_sort};
-    hipStream_t* const lanes = reuse_tails ? reuse : (small_lanes ? ctx->stream_lane_lo : ctx->stream_lane);
+    // SMALL side-by-side jobs (the MSMs of a small proof: chains of ~25 kernels of 5-20 us) run on the ordinary default-class lanes.  The runtime multiplexes the
+    // streams of a process onto a few hardware queues, and two chains on one queue run in turn (tools/queue_chains.hip).  Round 5 tried lanes of their own in the high
+    // and in the low stream-priority class and the idle tail streams as lanes: each won in one stream population and lost in another
+    // (profiles/r05_small_lanes_*_ab.log); what made the difference was WHEN the streams had come into being, and with every stream of a ctx created at zl_ctx_create
+    // (zl_ctx_streams_init) the default-class lanes are the best choice whatever ran before.  The knobs of those experiments were removed in round 6.
+    hipStream_t* const lanes = ctx->stream_lane;
     if (side) {
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (size_t k = 0; k < 4; k++)  // (all four at once, whatever NS: consecutive creations take consecutive queues of the pool)
-            if (!lanes[k]) {
-                if (small_lanes) ZL_HIP(ctx, hipStreamCreateWithPriority(&lanes[k], hipStreamNonBlocking, zl_tune("ZL_TUNE_SMALL_LANE_PRIO", 0) == 1 ? prio_lo : prio_hi));
-                else ZL_HIP(ctx, hipStreamCreateWithFlags(&lanes[k], hipStreamNonBlocking));
-            }
+            if (!lanes[k]) ZL_HIP(ctx, hipStreamCreateWithFlags(&lanes[k], hipStreamNonBlocking));
     }
     // all buffers up front (growth synchronises and frees: nothing may be in flight), then bind set i % 3 to job i: the first pass
     // grows every slot to its largest user, the second binds the final pointers.  Three sets: the tail of job i runs beside the
@@ -337,44 +326,25 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     // removed: the G2 accumulation held back until those sorts had finished (the sort kernels need 104 - 160 registers per SIMD and stall beside the
     // 416-register G2 wave): the a accumulation then starts 3 ms earlier, the G2 accumulation 3 ms later, and the proof takes the same 18.1 ms --
     // the proof is bound by the sum of its group additions, whatever their order.
-    const bool phased = side && count <= NS && biggest >= ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17)) && zl_tune("ZL_TUNE_LANE_THREADS", 0) == 0;
-    // issued[i]: 0 not yet, 1 issued, < 0 failed (-code).  Side by side, every lane stream CAN be fed by its own persistent host thread
-    // (ZL_TUNE_LANE_THREADS=1): the ~25 launches of a small job are ~80 us of host time, four jobs 0.3 ms.  Measured (k = 1 proof, 40 runs): all
-    // four jobs then reach the device within 0.15 ms, but finish together and later than the staggered jobs of a single issuing thread
-    // (median 1.40 against 1.16 ms per proof at GPU_MAX_HW_QUEUES=8, 1.52 against 1.35 at the runtime's default of 4) -- off by default.  (Lanes in
-    // different stream-priority classes, i.e. different queue pools, measured no better either.)
+    const bool phased = side && count <= NS && biggest >= ((uint64_t)1 << zl_tune("ZL_TUNE_PHASED_MIN_LOG", 17));
+    // issued[i]: 0 not yet, 1 issued, < 0 failed (-code).  (Round 3 also built one persistent issuing thread per lane: all four jobs of a small proof then reach the
+    // device within 0.15 ms, but finish together and later than the staggered jobs of a single issuing thread -- median 1.40 against 1.16 ms per proof; removed in round 6.)
     std::unique_ptr<std::atomic<int>[]> issued(new std::atomic<int>[count]);
     for (size_t i = 0; i < count; i++) issued[i].store(0);
-    const bool lanes_threaded = side && count > 1 && he == hipSuccess && zl_tune("ZL_TUNE_LANE_THREADS", 0) != 0;
-    if (lanes_threaded) {
-        for (size_t k = 0; k < NS; k++)
-            zl_ctx_worker(ctx, 2 + (int)k).run([&, k]() {
-                int r = hipSetDevice(ctx->device) == hipSuccess ? ZL_OK : ZL_EHIP;
-                for (size_t i = k; i < count; i += NS) {
-                    if (r == ZL_OK) r = issue_job(i);
-                    issued[i].store(r == ZL_OK ? 1 : -r, std::memory_order_release);
-                }
-            });
+    if (phased) {
+        for (size_t i = 0; i < count; i++)
+            if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_sort(i);
+        for (size_t i = 0; i < count; i++)
+            if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_acc_tail(i);
+        for (size_t i = 0; i < count; i++)
+            if (specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
+        for (size_t i = 0; i < count; i++) issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
     } else {
-        if (phased) {
-            for (size_t i = 0; i < count; i++)
-                if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_sort(i);
-            for (size_t i = 0; i < count; i++)
-                if (!specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_acc_tail(i);
-            for (size_t i = 0; i < count; i++)
-                if (specs[i].wait && he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
-            for (size_t i = 0; i < count; i++) issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
-        } else {
         for (size_t i = 0; i < count; i++) {
             if (he == hipSuccess && rc == ZL_OK) rc = issue_job(i);
             issued[i].store(he == hipSuccess && rc == ZL_OK ? 1 : -(rc ? rc : (int)ZL_EHIP), std::memory_order_release);
         }
-        }
     }
-    auto lanes_join = [&]() {
-        if (lanes_threaded)
-            for (size_t k = 0; k < NS; k++) zl_ctx_worker(ctx, 2 + (int)k).wait();
-    };
     // Host tails: this thread waits for the jobs' tail events in order (a job's root channels are then in pinned memory) and hands every
     // finished job to a helper thread that runs its window Horner and delivers the result -- while the device works on the later jobs.  Small
     // jobs, which the device finishes faster than the host, get their Horners side by side; `on_done` is delivered in job order.  (The helpers
@@ -390,7 +360,6 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         while ((st = issued[i].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
         if (st < 0 && rc == ZL_OK) rc = -st;
     }
-    lanes_join();
     if (he == hipSuccess && rc == ZL_OK) {
         hipStream_t last_tail = side ? lanes[(count - 1) % NS] : s_tails[(count - 1) % 3];
         for (size_t back = 1; back < NS && back < count && he == hipSuccess; back++) he = hipStreamWaitEvent(last_tail, ev_tail[count - 1 - back], 0);

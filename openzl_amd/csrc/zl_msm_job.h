@@ -442,7 +442,7 @@ struct MsmJob {
         const uint32_t RB = (H + ranges - 1) / ranges;
         // (the digit row of a window can be walked by `parts` blocks, slice-aligned: measured 1 = 2 = 4 = 8 at 2^18 .. 2^21 -- the kernel is bound by
         // its 4-byte scattered stores, 16.8 M of them in 0.19 ms at 2^20, not by the length of the row, the load latency or the LDS atomics)
-        const uint32_t parts = (uint32_t)std::max(1, std::min<int>((int)nslices, zl_tune("ZL_TUNE_SCATTER_PARTS", 1)));
+        const uint32_t parts = 1;
         hipLaunchKernelGGL(k_msm_scatter_range, dim3(8 * ((W + 7) / 8), ranges, parts), dim3(1024), (size_t)RB * 4, st, d_digits, (uint32_t)n, H, RB, d_offsets, d_entries,
                            (const uint32_t*)d_slice_counts, NB, nslices, per_slice, parts, (uint32_t)W);
         return ZL_OK;

@@ -38,7 +38,7 @@ struct NttArgs {
     uint32_t pre_coset, post_scale, post_coset, to_mont, from_mont;
     const void *t_lo, *t_hi;  // w^lo, w^(hi << L)
     const void* w_small;      // w_(2^s)^i, i < 2^(s-1)
-    const void* w_unpacked;   // lazy passes, optional (ZL_TUNE_NTT_ROOTS_GLOBAL=1): the same roots as limbs (4 L bytes each), read from global memory instead of LDS
+    const void* w_unpacked;   // lazy passes: the same roots as limbs (4 L bytes each), read from global memory instead of LDS
     const void *g_lo, *g_hi;  // coset powers (hi table carries n^-1 for the inverse)
     const void* row_tw;       // middle pass (lazy form): w_N^((r K0(hi)) << shift) for every (hi, r), hi = the tile's high index (or null: combined per tile)
     const void* last_tw;      // last pass of a multi-pass transform: the complete inter-factor twiddle of every element, in load order (or null)
@@ -813,7 +813,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     }
     // Round 4: the passes run on lazily reduced 28-bit limbs (k_ntt_pass28) unless ZL_NTT_NO_LAZY is set (developer A/B switch; the 32-bit passes stay)
     static const bool lazy = getenv("ZL_NTT_NO_LAZY") == nullptr;
-    static const bool roots_global = zl_tune("ZL_TUNE_NTT_ROOTS_GLOBAL", 1) != 0;  // round 5: on (2^24: 2.16 -> 2.13 ms, profiles/r05_ntt_fr29_ab2.log)
+    const bool roots_global = true;  // round 5: the butterfly roots as limbs from global memory (2^24: 2.16 -> 2.13 ms, profiles/r05_ntt_fr29_ab2.log); the LDS-staged path stays in the kernel for w_unpacked == nullptr
     zl_twiddles* tw;
     int rc;
     if ((rc = ntt_tables<FrP>(ctx, curve, n, inverse, &tw, lazy))) return rc;
