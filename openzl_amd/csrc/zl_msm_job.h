@@ -507,11 +507,19 @@ struct MsmJob {
             hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
-        hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
+        if (pair_tails && zl_tune("ZL_TUNE_G2_PAIR_BLOCKS", 1)) {  // Fq2 groups: the block-tree kernels of the heavy buckets on lane pairs
+            hipLaunchKernelGGL((k_msm_merge_big_pair<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
+                               d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
+            hipLaunchKernelGGL((k_msm_merge_giant_pair<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
+                               d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
+            hipLaunchKernelGGL((k_msm_merge_giant2_pair<G>), dim3(std::min<uint32_t>(max_giant, 64)), dim3(2 * ZL_GIANT_PARTS), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+        } else {
+            hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
-        hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
+            hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                            d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-        hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+            hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+        }
         if (ev_merged) ZL_HIP(ctx, hipEventRecord(ev_merged, st));  // the bucket sums of this shard are final
         // scalar-1 bases: window-0 table entries are the bases themselves
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,

@@ -395,6 +395,108 @@ __global__ void __launch_bounds__(64, 2) k_msm_reduce_tree_pair(const XYZZ<typen
         pair_store(&out[t], half, acc);
     }
 }
+// The block-tree kernels on lane pairs (round 6): the heavy buckets of a skewed input -- and a Groth16 witness IS skewed: the table-mode G2 MSM of the 958 465-constraint
+// proof spent 0.56 ms in k_msm_merge_big<BlsG2> and 1.3 ms in k_msm_merge_giant<BlsG2> per proof, one-lane kernels at 512 registers + 716 B of scratch
+// (profiles/r06_kernel_stats_groth16.txt).  A block of 2 N lanes holds N items (ZL_PAIR_ITEM_IN_BLOCK); the LDS tree stores each item as the XYZZ<Fq2> it is in
+// global memory, every lane moving the component of its half.
+#define ZL_PAIR_ITEM_IN_BLOCK() (((threadIdx.x >> 4) << 3) + (threadIdx.x & 7u))
+template <class G, int N>
+__device__ __forceinline__ void zl_block_tree_pair(XYZZ<typename G::F>* sh, XYZZ<Fp2H<typename PairBase<typename G::F>::type>>& acc, uint32_t item, int half) {
+    using X = XYZZ<Fp2H<typename PairBase<typename G::F>::type>>;
+    pair_store(&sh[item], half, acc);
+    __syncthreads();
+    for (uint32_t off = N / 2; off > 0; off >>= 1) {
+        if (item < off) {
+            X a = pair_load(&sh[item], half);
+            const X o = pair_load(&sh[item + off], half);
+            zl::add_full(a, o);
+            pair_store(&sh[item], half, a);
+        }
+        __syncthreads();
+    }
+    acc = pair_load(&sh[0], half);
+    __syncthreads();
+}
+template <class G>
+__global__ void __launch_bounds__(2 * TreeLanes<G>::N) k_msm_merge_big_pair(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
+                                                        const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK, uint32_t carry) {
+    using B = typename PairBase<typename G::F>::type;
+    if constexpr (!std::is_void<B>::value) {
+        ZL_SIDE_PRIO();
+        using X = XYZZ<Fp2H<B>>;
+        constexpr uint32_t N = TreeLanes<G>::N;
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+        XYZZ<typename G::F>* sh = reinterpret_cast<XYZZ<typename G::F>*>(smem);
+        const int half = zl::pair_half();
+        const uint32_t item = ZL_PAIR_ITEM_IN_BLOCK();
+        for (uint32_t it = blockIdx.x; it < *big_count; it += gridDim.x) {
+            const uint32_t b = big_list[it];
+            const uint32_t s = offsets[b], e = offsets[b + 1];
+            const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+            X acc = X::inf();
+            if (carry && item == 0) acc = pair_load(&bucket_sums[b], half);
+            for (uint32_t t = t0 + item; t <= t1; t += N) {
+                const X p = pair_load(&partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)], half);
+                zl::add_full(acc, p);
+            }
+            zl_block_tree_pair<G, N>(sh, acc, item, half);
+            if (item == 0) pair_store(&bucket_sums[b], half, acc);
+        }
+    }
+}
+template <class G>
+__global__ void __launch_bounds__(2 * TreeLanes<G>::N) k_msm_merge_giant_pair(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ giant_list,
+                                                          const uint32_t* __restrict__ giant_count, uint32_t ZL_CHUNK) {
+    using B = typename PairBase<typename G::F>::type;
+    if constexpr (!std::is_void<B>::value) {
+        ZL_SIDE_PRIO();
+        using X = XYZZ<Fp2H<B>>;
+        constexpr uint32_t N = TreeLanes<G>::N;
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+        XYZZ<typename G::F>* sh = reinterpret_cast<XYZZ<typename G::F>*>(smem);
+        const int half = zl::pair_half();
+        const uint32_t item = ZL_PAIR_ITEM_IN_BLOCK();
+        const uint32_t part = blockIdx.x % ZL_GIANT_PARTS;
+        for (uint32_t it = blockIdx.x / ZL_GIANT_PARTS; it < *giant_count; it += gridDim.x / ZL_GIANT_PARTS) {
+            const uint32_t b = giant_list[it];
+            const uint32_t s = offsets[b], e = offsets[b + 1];
+            const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
+            const uint32_t per = (t1 - t0 + ZL_GIANT_PARTS) / ZL_GIANT_PARTS;
+            const uint32_t lo = t0 + part * per, hi = min(t1 + 1, lo + per);
+            X acc = X::inf();
+            for (uint32_t t = lo + item; t < hi; t += N) {
+                const X p = pair_load(&partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)], half);
+                zl::add_full(acc, p);
+            }
+            zl_block_tree_pair<G, N>(sh, acc, item, half);
+            if (item == 0) pair_store(&giant_tmp[(size_t)it * ZL_GIANT_PARTS + part], half, acc);
+        }
+    }
+}
+// stage 2: one block of ZL_GIANT_PARTS pairs per giant bucket (the one-lane kernel folds the 32 sums serially: 32 Fq2 additions of latency)
+template <class G>
+__global__ void __launch_bounds__(2 * ZL_GIANT_PARTS) k_msm_merge_giant2_pair(XYZZ<typename G::F>* __restrict__ bucket_sums, XYZZ<typename G::F>* __restrict__ giant_tmp,
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count, uint32_t carry) {
+    using B = typename PairBase<typename G::F>::type;
+    if constexpr (!std::is_void<B>::value) {
+        ZL_SIDE_PRIO();
+        using X = XYZZ<Fp2H<B>>;
+        const int half = zl::pair_half();
+        const uint32_t item = ZL_PAIR_ITEM_IN_BLOCK();
+        for (uint32_t it = blockIdx.x; it < *giant_count; it += gridDim.x) {
+            XYZZ<typename G::F>* sh = giant_tmp + (size_t)it * ZL_GIANT_PARTS;  // the tree runs in place over the bucket's 32 part sums (global memory: 16 KB, once per giant bucket)
+            X acc = pair_load(&sh[item], half);
+            __syncthreads();
+            zl_block_tree_pair<G, ZL_GIANT_PARTS>(sh, acc, item, half);
+            if (item == 0) {
+                if (carry) { const X old = pair_load(&bucket_sums[giant_list[it]], half); zl::add_full(acc, old); }
+                pair_store(&bucket_sums[giant_list[it]], half, acc);
+            }
+        }
+    }
+}
 // tree-sum of segment results.  Block b belongs to set (b / parts) and sums `count` consecutive elements starting at
 // set * set_stride + (b % parts) * count (clipped to the set): parts = 1 -> one block per set; parts > 1 -> stage 1 of a
 // two-stage sum for sets with many segments.
@@ -445,6 +547,9 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
     X template __global__ void k_msm_fill_empty<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_merge_cuts<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_cuts_pair<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_big_pair<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_giant_pair<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
+    X template __global__ void k_msm_merge_giant2_pair<G>(XYZZ<typename G::F>*, XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
     X template __global__ void k_msm_merge_pair<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_pair<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_reduce_level0_pair<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
