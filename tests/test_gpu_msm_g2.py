@@ -81,6 +81,40 @@ def test_g2_known_discrete_log_2_18(backend, curve, table):
 
 
 @pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n", [13, 17])
+def test_g2_heavy_buckets_known_discrete_log(backend, curve, log_n):
+    """Skewed scalars, as a Groth16 witness has them: half of the scalars are ONE value (a bucket per window cut into thousands of chunks: the giant path at 2^17,
+    the big path at 2^13), a quarter comes from eight values (big buckets), the rest is uniform.  Since round 6 those buckets are folded by the lane-pair block-tree
+    kernels (k_msm_merge_big_pair / _giant_pair / _giant2_pair); exact against (sum s_i k_i mod r) G2, and equal to the one-lane kernels' result."""
+    import os
+
+    n, r = 1 << log_n, curve.fr.p
+    rng = np.random.Generator(np.random.PCG64(61 + log_n))
+    k64 = rng.integers(1, 1 << 63, size=n, dtype=np.uint64)
+    k = np.zeros((n, 4), dtype=np.uint64)
+    k[:, 0] = k64
+    S = ol.random_scalars(curve, n, 62 + log_n)
+    vals = ol.random_scalars(curve, 9, 63)
+    who = rng.permutation(n)
+    S[who[: n // 2]] = vals[8]
+    S[who[n // 2: 3 * n // 4]] = vals[rng.integers(0, 8, size=n // 4)]
+    h = backend.bases_generate(curve.cid, k, group=ZL_G2)
+    try:
+        got, inf = backend.msm(h, S)
+        os.environ["ZL_TUNE_G2_PAIR_BLOCKS"] = "0"
+        old, old_inf = backend.msm(h, S)
+    finally:
+        os.environ.pop("ZL_TUNE_G2_PAIR_BLOCKS", None)
+        backend.bases_free(h)
+    s32 = np.ascontiguousarray(S).view(np.uint32).reshape(-1, 8).astype(object)
+    dot = 0
+    for a in range(8):
+        dot += int((s32[:, a] * k64.astype(object)).sum()) << (32 * a)
+    assert inf == 0 and (got == gu.g2_mul_gen(curve, [dot % r])[0]).all()
+    assert old_inf == 0 and (old == got).all()
+
+
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
 def test_g2_precomputed_table_and_skew(backend, curve):
     """zl_bases_precompute on a G2 handle (merged bucket set) + the scalar-1 bypass and a giant bucket, against the oracle."""
     n = 2500
