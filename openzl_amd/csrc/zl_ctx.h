@@ -127,6 +127,7 @@ struct zl_r1cs_dev {  // device-resident R1CS matrices (CSR; coefficients in Mon
     void* d_base = nullptr;
     size_t off_ptr[3] = {0, 0, 0}, off_col[3] = {0, 0, 0}, off_val[3] = {0, 0, 0};
     uint32_t n_constraints = 0, n_instance = 0, n_witness = 0;
+    size_t nnz[3] = {0, 0, 0};  // non-zeros of A, B, C (the witness map picks the row-parallel product for matrices with long rows)
     int curve = 0;
 };
 struct zl_ctx {

@@ -45,6 +45,33 @@ __global__ void __launch_bounds__(256) k_r1cs_spmv(const uint32_t* __restrict__ 
     }
     out[i] = acc;
 }
+// The same product with EIGHT lanes per row (round 6): a row of the Poseidon circuit's A and B holds up to ~150 terms (the linear layers are merged into the rows), and one
+// lane per row walks them as a chain of dependent multiply-adds -- 91 + 68 us for the 235 rows of a one-hash proof, on the critical path in front of the h MSM.  Lane j of
+// a group takes the terms k = first + j, + 8, ...; the eight partial sums are folded by three xor-shuffle steps (fully reduced Fr: addition is exact in any order).
+template <class FrP>
+__global__ void __launch_bounds__(256) k_r1cs_spmv8(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ col, const Fp<FrP>* __restrict__ val,
+                                                     const Fp<FrP>* __restrict__ z, uint32_t n_rows, uint32_t tail, uint32_t N,
+                                                     Fp<FrP>* __restrict__ out) {
+    using F = Fp<FrP>;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gt >> 3, j = gt & 7u;
+    if (i >= N) return;  // (N is a multiple of 32: whole groups leave together)
+    F acc = F::zero();
+    if (i < n_rows) {
+        const uint32_t e = ptr[i + 1];
+        for (uint32_t k = ptr[i] + j; k < e; k += 8) acc = zl::add(acc, zl::mul(val[k], z[col[k]]));
+    } else if (j == 0 && i - n_rows < tail) {
+        acc = z[i - n_rows];
+    }
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+        F o;
+#pragma unroll
+        for (int w = 0; w < F::N; w++) o.l[w] = (uint32_t)__shfl_xor((int)acc.l[w], d, 8);
+        acc = zl::add(acc, o);
+    }
+    if (j == 0) out[i] = acc;
+}
 // a = (a*b - c) * zinv
 template <class FrP>
 __global__ void __launch_bounds__(256) k_qap_pointwise(Fp<FrP>* __restrict__ a, const Fp<FrP>* __restrict__ b, const Fp<FrP>* __restrict__ c,
@@ -94,6 +121,7 @@ static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
         out->off_ptr[m] = take((size_t)(nc + 1) * 4);
         out->off_col[m] = take(nnz[m] * 4);
         out->off_val[m] = take(nnz[m] * 32);
+        out->nnz[m] = nnz[m];
     }
     void* base = nullptr;
     ZL_HIP(ctx, hipMalloc(&base, bytes ? bytes : 256));
@@ -212,9 +240,15 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     w_wm.run([&]() {
         auto fail = [&](int code) { rc_wm = code; h_recorded.store(-1, std::memory_order_release); };
         if (hipSetDevice(ctx->device) != hipSuccess || hipStreamWaitEvent(s_wm, ev_z, 0) != hipSuccess) return fail(ZL_EHIP);
-        for (int m = 0; m < 3; m++)
-            hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
-                               (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+        for (int m = 0; m < 3; m++) {
+            // rows of >= 4 terms on average (A and B of the Poseidon circuit: ~13): eight lanes per row; C (one term per row): one lane
+            if (cs->nnz[m] >= (size_t)4 * nc && zl_tune("ZL_TUNE_SPMV8", 1))
+                hipLaunchKernelGGL((k_r1cs_spmv8<FrP>), dim3((uint32_t)(((uint64_t)N * 8 + 255) / 256)), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
+                                   (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+            else
+                hipLaunchKernelGGL((k_r1cs_spmv<FrP>), dim3((N + 255) / 256), dim3(256), 0, s_wm, (const uint32_t*)(dm + off_ptr[m]), (const uint32_t*)(dm + off_col[m]),
+                                   (const Fr*)(dm + off_val[m]), d_zm, nc, m == 0 ? ni : 0u, N, dv[m]);
+        }
         if (hipGetLastError() != hipSuccess) return fail(ZL_EHIP);
         int r;
         for (int m = 0; m < 3; m++) {

@@ -69,8 +69,7 @@ static int msm_run_t(zl_ctx* ctx, const zl_bases& bs, size_t first, const void* 
                 ZL_HIP(ctx, hipHostMalloc(&ctx->pinned, need + 4096, hipHostMallocDefault));
                 ctx->pinned_cap = need + 4096;
             }
-            job.hw = reinterpret_cast<X*>(ctx->pinned);
-            job.hE = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(ctx->pinned) + sizeof(X) * ((size_t)job.SETS * job.roots_per_set + 1));
+            job.set_host_buffer(reinterpret_cast<X*>(ctx->pinned));  // (need = the root channels + the scalar-1 sum + 16 bytes: the status words fit behind them)
         }
         const auto tp1 = std::chrono::steady_clock::now();
         hipStream_t st = ctx->stream;
@@ -236,8 +235,7 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     }
     for (size_t i = 0; i < count; i++) {
         unsigned char* base = reinterpret_cast<unsigned char*>(ctx->pinned) + per * i;
-        jobs[i].hw = reinterpret_cast<X*>(base);
-        jobs[i].hE = reinterpret_cast<uint32_t*>(base + sizeof(X) * (max_sets + 1));
+        jobs[i].set_host_buffer(reinterpret_cast<X*>(base));  // (per = the largest job's root channels + scalar-1 sum + 16 bytes: every job's status words fit behind its own)
     }
     hipStream_t s_sort = ctx->stream_sort, s_acc = ctx->stream;
     // The tail of job i runs on the tail stream of its buffer set: consecutive tails are independent (own buckets, partials, tree nodes), and

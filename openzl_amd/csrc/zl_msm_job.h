@@ -94,7 +94,11 @@ struct MsmJob {
     X* hw = nullptr;
     uint32_t* hE = nullptr;  // [0] = entries accumulated, [1] = non-canonical-scalar flag
     std::vector<X> hw_own;
-    uint32_t hE_own[2] = {0, 0};
+    // result buffer (pinned when pipelined): SETS * roots_per_set root channels, the scalar-1 sum, then the two status words k_msm_ones leaves behind it
+    void set_host_buffer(X* buf) {
+        hw = buf;
+        hE = reinterpret_cast<uint32_t*>(buf + (size_t)SETS * roots_per_set + 1);
+    }
 
     // phi_slot_: scratch slot for the endomorphism image of the bases when this job computes it (GLV); -1 = never use the endomorphism
     int plan(zl_ctx* ctx, const zl_bases& bs, size_t first_, const void* d_scalars, size_t n_, int phi_slot_ = -1) {
@@ -183,9 +187,8 @@ struct MsmJob {
         d_bases = pre ? reinterpret_cast<const Affine<F>*>(bs.d_table) : reinterpret_cast<const Affine<F>*>(bs.d_pts) + first;
         d_inf = bs.d_inf ? reinterpret_cast<const uint8_t*>(bs.d_inf) + first : nullptr;
         sc = reinterpret_cast<const uint32_t*>(d_scalars);
-        hw_own.assign((size_t)SETS * roots_per_set + 1, X::inf());
-        hw = hw_own.data();
-        hE = hE_own;
+        hw_own.assign((size_t)SETS * roots_per_set + 2, X::inf());  // (+ one element of room for the two status words behind the result)
+        set_host_buffer(hw_own.data());
         return ZL_OK;
     }
     // buffer set 0, 1 or 2 (slots 0..3 + 4 / 10..13 + 19 / 14..17 + 23); the sort temporaries (slots 5, 6) are shared: the sorts of consecutive
@@ -235,7 +238,7 @@ struct MsmJob {
         d_segs = (X*)p;                    // tree nodes, even levels (level 0 = leaves)
         d_stage1 = d_segs + leaf_elems;    // tree nodes, odd levels
         d_sets = d_stage1 + lvl1_elems;    // the root channels of every set, then the sum of the scalar-1 bases
-        d_ones_parts = d_sets + root_elems + 1;
+        d_ones_parts = d_sets + root_elems + 2;  // (one element of room behind the scalar-1 sum: the two status words k_msm_ones writes there)
         d_giant_tmp = d_ones_parts + ZL_ONES_BLOCKS;
         if (glv) {
             // The images depend on the bases only: kept with the handle (one range per handle; another range of the same handle falls back to
@@ -308,7 +311,7 @@ struct MsmJob {
         // the bucket counters are written in full by the LDS path (k_msm_slice_prefix) and by the wide path (k_msm_fine_hist); only the
         // global-atomics sort counts into them
         if (!wide && c > 16) ZL_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)(NB + 1) * 4, st));
-        ZL_HIP(ctx, hipMemsetAsync(d_big_count, 0, 32, st));  // big, ones, giant counts; [4..5]: oversized sub-group queue head (u64)
+        hipLaunchKernelGGL(k_msm_zero_words, dim3(1), dim3(64), 0, st, d_big_count, 8u);  // big, ones, giant counts, bad-scalar flag; [4..5]: oversized sub-group queue head (u64); [6]: k_msm_ones' ticket
         const uint32_t nblk = (uint32_t)((n + 255) / 256);
         // GLV front end: half-scalars behind the slot-5 temporaries, phi image of the bases (once per call for a batch over one key)
         const uint32_t* sc_eff = sc;
@@ -507,29 +510,29 @@ struct MsmJob {
             hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
         else
         hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+        // a bucket cut into more than big_span (ZL_GIANT_SPAN) chunks needs that many chunks to exist: small jobs skip the launches (three of the ~22 of a small MSM's chain)
+        const bool may_big = nchunks > big_span, may_giant = nchunks > (uint32_t)ZL_GIANT_SPAN;
         if (pair_tails && zl_tune("ZL_TUNE_G2_PAIR_BLOCKS", 1)) {  // Fq2 groups: the block-tree kernels of the heavy buckets on lane pairs
-            hipLaunchKernelGGL((k_msm_merge_big_pair<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
+            if (may_big) hipLaunchKernelGGL((k_msm_merge_big_pair<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                                d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
-            hipLaunchKernelGGL((k_msm_merge_giant_pair<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant_pair<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                                d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-            hipLaunchKernelGGL((k_msm_merge_giant2_pair<G>), dim3(std::min<uint32_t>(max_giant, 64)), dim3(2 * ZL_GIANT_PARTS), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2_pair<G>), dim3(std::min<uint32_t>(max_giant, 64)), dim3(2 * ZL_GIANT_PARTS), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
         } else {
-            hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
+            if (may_big) hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
                            d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
-            hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                            d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-            hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
         }
         if (ev_merged) ZL_HIP(ctx, hipEventRecord(ev_merged, st));  // the bucket sums of this shard are final
         // scalar-1 bases: window-0 table entries are the bases themselves
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
-                           pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
-        hipLaunchKernelGGL((k_msm_window_sum<G>), dim3(1), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_parts, (uint32_t)ZL_ONES_BLOCKS,
-                           (uint32_t)ZL_ONES_BLOCKS, 1u, d_sets + (size_t)SETS * roots_per_set, (const uint32_t*)d_ones_count);
+                           pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu,
+                           d_sets + (size_t)SETS * roots_per_set, d_big_count + 6, (const uint32_t*)(d_offsets + NB));  // (+ the final sum and the two status words: see the kernel)
         if (!reduce) {  // an earlier shard of a carried bucket set: only the sum of its scalar-1 bases travels
             ZL_HIP(ctx, hipGetLastError());
-            ZL_HIP(ctx, hipMemcpyAsync(hw + (size_t)SETS * roots_per_set, d_sets + (size_t)SETS * roots_per_set, sizeof(X), hipMemcpyDeviceToHost, st));
-            ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 8, hipMemcpyDeviceToHost, st));
+            ZL_HIP(ctx, hipMemcpyAsync(hw + (size_t)SETS * roots_per_set, d_sets + (size_t)SETS * roots_per_set, sizeof(X) + 8, hipMemcpyDeviceToHost, st));
             return ZL_OK;
         }
         {
@@ -559,8 +562,7 @@ struct MsmJob {
             }
         }
         ZL_HIP(ctx, hipGetLastError());
-        ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * ((size_t)SETS * roots_per_set + 1), hipMemcpyDeviceToHost, st));
-        ZL_HIP(ctx, hipMemcpyAsync(hE, d_offsets + NB, 8, hipMemcpyDeviceToHost, st));
+        ZL_HIP(ctx, hipMemcpyAsync(hw, d_sets, sizeof(X) * ((size_t)SETS * roots_per_set + 1) + 8, hipMemcpyDeviceToHost, st));  // root channels, scalar-1 sum, the two status words
         return ZL_OK;
     }
     // The window sum of set w is V_w = A_w + g0 * sum_b 2^b S_(w,b) (the root channels T, A, S_0 .. of its reduction tree); the result is

@@ -181,27 +181,66 @@ __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __
 // sum of the bases whose scalar is 1 (list built by the recoder): strided mixed adds per lane, block tree -> out[block]
 #define ZL_ONES_BLOCKS 128
 
+// Round 6: the kernel also FINISHES the sum (the last block to arrive folds the blocks' partial sums: no k_msm_window_sum launch behind it) and copies the job's two
+// status words (entries accumulated, non-canonical-scalar flag) behind the result, so that one device-to-host copy fetches everything: two launches fewer on the
+// latency-bound chain of a small MSM.  `done`: a per-job counter word, zero at launch.
+template <class X>
+__device__ __forceinline__ X zl_load_volatile(const X* p) {  // a value another workgroup of the same launch wrote (behind __threadfence + an atomic ticket)
+    X r;
+    const volatile uint32_t* s = reinterpret_cast<const volatile uint32_t*>(p);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(X) / 4); i++) d[i] = s[i];
+    return r;
+}
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_ones(const uint32_t* __restrict__ ones_list, const uint32_t* __restrict__ ones_count,
                                                    const Affine<typename G::F>* __restrict__ bases, XYZZ<typename G::F>* __restrict__ out,
-                                                   const Affine<typename G::F>* __restrict__ phib, uint32_t n_real) {
+                                                   const Affine<typename G::F>* __restrict__ phib, uint32_t n_real, XYZZ<typename G::F>* __restrict__ final_out,
+                                                   uint32_t* __restrict__ done, const uint32_t* __restrict__ status_in) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    __shared__ uint32_t last_flag;
     const uint32_t cnt = *ones_count;
-    if (cnt == 0) {  // the usual case for uniform scalars: no block tree over 128 / 256 points at infinity (15 us of the tail of a small G2 MSM)
-        if (threadIdx.x == 0) out[blockIdx.x] = XYZZ<F>::inf();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the status words travel with the result (final_out + 1: room for them in every result buffer)
+        uint32_t* st = reinterpret_cast<uint32_t*>(final_out + 1);
+        st[0] = status_in[0];
+        st[1] = status_in[1];
+    }
+    if (cnt == 0) {  // the usual case for uniform scalars
+        if (blockIdx.x == 0 && threadIdx.x == 0) *final_out = XYZZ<F>::inf();
         return;
     }
+    const uint32_t nparts = min(gridDim.x, (cnt + blockDim.x - 1) / blockDim.x);  // blocks that have any index to add
+    if (blockIdx.x >= nparts) return;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += gridDim.x * blockDim.x) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += nparts * blockDim.x) {
         const uint32_t idx = ones_list[j];
         const Affine<F> P = (G::GLV && idx >= n_real) ? phib[idx - n_real] : bases[idx];  // GLV: a half-scalar k2 = 1 names phi(P)
         if (!P.is_inf()) zl::add_mixed(acc, P.x, P.y, false);
     }
+    if (cnt > 1) zl_block_tree<G>(sh, acc);  // (cnt == 1 -- a proof's constant ONE -- : lane 0 holds the point)
+    if (nparts == 1) {
+        if (threadIdx.x == 0) *final_out = acc;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = acc;
+        __threadfence();
+        last_flag = atomicAdd(done, 1u) == nparts - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    acc = XYZZ<F>::inf();
+    for (uint32_t s = threadIdx.x; s < nparts; s += blockDim.x) {
+        const XYZZ<F> p = zl_load_volatile(&out[s]);
+        zl::add_full(acc, p);
+    }
     zl_block_tree<G>(sh, acc);
-    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+    if (threadIdx.x == 0) *final_out = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ bucket reduction
@@ -539,7 +578,7 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
     X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_giant<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
     X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
-    X template __global__ void k_msm_ones<G>(const uint32_t*, const uint32_t*, const Affine<typename G::F>*, XYZZ<typename G::F>*, const Affine<typename G::F>*, uint32_t); \
+    X template __global__ void k_msm_ones<G>(const uint32_t*, const uint32_t*, const Affine<typename G::F>*, XYZZ<typename G::F>*, const Affine<typename G::F>*, uint32_t, XYZZ<typename G::F>*, uint32_t*, const uint32_t*); \
     X template __global__ void k_msm_reduce_level0<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_tree<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \

@@ -8,6 +8,8 @@
 #define SCAN_ITEMS 16
 #define SCAN_BLOCK 256
 
+// the eight per-job counter words in ONE launch (a 32-byte hipMemsetAsync at a 4-byte-aligned address runs as three fill kernels: 14 us of a small job's chain)
+__global__ void __launch_bounds__(64) k_msm_zero_words(uint32_t* __restrict__ p, uint32_t n);
 template <int MODE>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ counters, uint32_t* __restrict__ entries,

@@ -31,6 +31,9 @@ __device__ __forceinline__ uint32_t zl_take_sign(uint32_t& top_word, int glv) {
     return sg;
 }
 // MODE 0: histogram; MODE 1: scatter (cursor initialised with the bucket offsets)
+__global__ void __launch_bounds__(64) k_msm_zero_words(uint32_t* __restrict__ p, uint32_t n) {
+    if (threadIdx.x < n) p[threadIdx.x] = 0u;
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ counters, uint32_t* __restrict__ entries,
