@@ -603,7 +603,7 @@ VALU_CYCLES_PER_MIXED_ADD = 17028 + 186  # profiles/r05_acc_instruction_budget.t
 NOMINAL_GHZ = 2.4
 
 
-IN_KERNEL_CLOCK_GHZ = 2.09  # profiles/r05_clock_probe_2_24.log (2.075-2.10 over three launches; the same kernel, the same 32.7-32.9 ms): re-measured by tools/clock_probe.py on a -DZL_MEASURE build
+IN_KERNEL_CLOCK_GHZ = 2.09  # profiles/r06_clock_probe_2_24.log (2.088-2.094 over three launches of the c = 20 accumulation on a -DZL_MEASURE build of this round's code; r05: 2.075-2.10 at c = 19): tools/clock_probe.py
 
 
 def int_alu_clock(acc_clock, head, dom_ms):
@@ -620,7 +620,7 @@ def int_alu_clock(acc_clock, head, dom_ms):
     probe = acc_clock if acc_clock and "error" not in acc_clock else None
     return {"effective_clock_ghz": f,
             "effective_clock_source": "in-kernel s_memtime / s_memrealtime deltas of every wave of the clock-reading build of this kernel (k_msm_accumulate_clk, -DZL_MEASURE builds only): "
-                                      "committed measurement profiles/r05_clock_probe_2_24.log, same kernel and same kernel time; NOT re-read by this run",
+                                      "committed measurement profiles/r06_clock_probe_2_24.log (2.088-2.094 GHz), same kernel and same kernel time; NOT re-read by this run",
             "sleeping_probe_clock_ghz": probe["effective_clock_ghz"] if probe else None,
             "sleeping_probe_note": ("one sleeping wave per XCD on its own high-priority stream spanning one more pipelined batch of four steps (accumulation %.2f ms per step during the probe, "
                                     "%.2f ms in the timed steps); disagrees with the in-kernel and the GRBM readings of the same kernel, nothing is derived from it" % (probe["accumulate_ms_during_probe"], dom_ms))
