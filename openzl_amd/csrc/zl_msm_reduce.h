@@ -380,8 +380,11 @@ __global__ void __launch_bounds__(64, 2) k_msm_merge_cuts_pair(const uint32_t* _
         pair_store(&bucket_sums[b], half, acc);
     }
 }
+#ifndef ZL_L0_PAIR_WAVES
+#define ZL_L0_PAIR_WAVES 2  // (1 = no scratch at one wave per SIMD: the A/B of profiles/r06_l0_pair_waves_ab.log)
+#endif
 template <class G, bool QUAD = false>
-__global__ void __launch_bounds__(64, 2) k_msm_reduce_level0_pair(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
+__global__ void __launch_bounds__(64, ZL_L0_PAIR_WAVES) k_msm_reduce_level0_pair(const XYZZ<typename G::F>* __restrict__ buckets, uint32_t H, uint32_t group, uint32_t blocks_per_set,
                                                            uint32_t total_blocks, uint32_t flat_set, uint32_t flat_log, XYZZ<typename G::F>* __restrict__ out) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
