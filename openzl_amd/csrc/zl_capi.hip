@@ -379,22 +379,15 @@ static int msm_host_chunked(zl_ctx* ctx, const zl_bases& b, size_t first, const 
     std::vector<const void*> js(K);
     for (size_t j = 0; j < K; j++) { jf[j] = first + off[j]; jn[j] = len[j]; js[j] = reinterpret_cast<unsigned char*>(d_sc) + off[j] * 32; }
     std::vector<uint64_t> parts(K * ZL_PARTIAL_WORDS);
-    // Round 5 built the alternative the earlier rounds had only costed: the shards as jobs over ONE carried bucket set with the windows of
-    // the whole MSM (zl_msm_run_shards: k_msm_accumulate_carry continues a bucket's sum, the merge adds cut buckets' partials to it, only the last shard
-    // reduces).  Exact (tests/test_gpu_msm.py::test_msm_host_scalars_on_a_carried_bucket_set) and SLOWER: 42.6-42.9 ms against 40.4-40.9 for the independent jobs
-    // on one box, for every shard plan tried (profiles/r05_host_carry_ab.log) -- a 2^20-point shard spread over the 3.67 M buckets of c = 19 has 4 entries per
-    // bucket, so its accumulation loads and stores a 256-byte sum per 4 additions and crosses a bucket boundary in every iteration of every lane, its sort scans
-    // 3.67 M counters for 14.7 M entries, and the next shard's accumulation must wait for its merge.  The independent jobs (own, narrower windows per shard) stay
-    // the default; ZL_TUNE_HOST_CARRY=1 selects the carried set.
-    const bool carry = b.group == ZL_G1 && zl_tune("ZL_TUNE_HOST_CARRY", 0) != 0;
-    int rc;
-    if (carry) rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_shards, ctx, b, jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded);
-    else rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_jobs, ctx, jb.data(), jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded, (const std::function<void(size_t)>*)nullptr);
+    // (Round 5 built the alternative the earlier rounds had only costed -- the shards as jobs over ONE carried bucket set with the windows of the whole MSM -- and
+    // measured it slower for every shard plan tried, 42.6-42.9 ms against 40.4-40.9 for these independent jobs: a 2^20-point shard spread over the 3.67 M buckets
+    // of c = 19 has 4 entries per bucket.  profiles/r05_host_carry_ab.log; the code was removed in round 6.)
+    const int rc = ZL_DISPATCH(b.curve, b.group, zl_msm_run_jobs, ctx, jb.data(), jf.data(), js.data(), jn.data(), ev.data(), K, parts.data(), &recorded, (const std::function<void(size_t)>*)nullptr);
     copier.join();
     (void)hipStreamSynchronize(sc);
     for (auto x : ev) (void)hipEventDestroy(x);
     if (rc) return rc;
-    return zl_partials_sum((zl_curve_t)b.curve, (zl_group_t)b.group, parts.data(), carry ? 1 : K, out_xy, out_inf);
+    return zl_partials_sum((zl_curve_t)b.curve, (zl_group_t)b.group, parts.data(), K, out_xy, out_inf);
 }
 
 int zl_msm(zl_ctx* ctx, uint64_t bases, size_t first, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf) {

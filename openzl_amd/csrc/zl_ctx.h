@@ -266,7 +266,6 @@ inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
     int zl_msm_run_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial); \
     int zl_msm_run_batch_##G(zl_ctx* ctx, const zl_bases& b, size_t first, const void* const* d_scalars, size_t n, size_t count, uint64_t* out_partials); \
     int zl_msm_run_jobs_##G(zl_ctx* ctx, const zl_bases* const* bases, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait, size_t count, uint64_t* out_partials, const std::atomic<int>* recorded, const std::function<void(size_t)>* on_done); \
-    int zl_msm_run_shards_##G(zl_ctx* ctx, const zl_bases& b, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait, size_t count, uint64_t* out_partial, const std::atomic<int>* recorded); \
     int zl_partial_to_affine_##G(const uint64_t* partial, uint64_t* out_xy, uint8_t* out_inf);                              \
     int zl_partials_fold_##G(const uint64_t* partials, size_t count, uint64_t* out_partial);                                \
     int zl_partial_from_affine_##G(const uint64_t* xy, uint64_t* out_partial);                                \

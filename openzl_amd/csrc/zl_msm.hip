@@ -115,9 +115,6 @@ struct MsmSpec {
     const void* d_scalars;
     size_t n;
     hipEvent_t wait;  // optional: the scalars of this job are ready when this event (recorded on another stream) has fired
-    // the jobs of this call are SHARDS OF ONE MSM (ranges of one handle, zl_msm with host scalars): they run with the window width of `carried_total` points
-    // over one carried bucket set -- shard j's accumulation continues the bucket sums of shard j - 1, only the last shard reduces (zl_msm_job.h)
-    size_t carried_total = 0;
 };
 // `recorded` (optional): the wait events are recorded by ANOTHER host thread (zl_msm's copy thread); job i may only be issued once
 // *recorded > i, because hipStreamWaitEvent on a not-yet-recorded event does not wait.  Negative = that thread failed.
@@ -172,21 +169,11 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     for (size_t i = 0; i < count; i++) biggest = std::max<uint64_t>(biggest, (uint64_t)specs[i].n);
     // measured (round 3, batches of 6): 2^16 0.69 -> 0.50 ms per MSM, 2^20 3.31 -> 3.10; equal at 2^18 - 2^19; from 2^21 on the three-phase pipeline
     // wins (2^24: 36.3 against 37.3 ms)
-    const bool carried = specs[0].carried_total != 0;
-    const bool side = !carried && biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
+    const bool side = biggest <= ((uint64_t)1 << zl_tune("ZL_TUNE_SIDE_BY_SIDE_LOG", 20));
     const size_t NS = side ? std::min<size_t>(count, (size_t)std::min(4, std::max(1, zl_tune("ZL_TUNE_SIDE_LANES", 4)))) : 3;
-    // carried shards: every shard plans with the window width of the whole MSM (same windows, same bucket ids) and without the endomorphism split
-    struct ForceC {
-        zl_ctx* c;
-        int saved;
-        bool on;
-        ForceC(zl_ctx* ctx_, bool on_, int want) : c(ctx_), saved(ctx_->msm_c), on(on_) { if (on && c->msm_c <= 0) c->msm_c = want; }
-        ~ForceC() { if (on) c->msm_c = saved; }
-    } force_c(ctx, carried, carried ? zl_pick_window(specs[0].carried_total, (int)G::SC_BITS, false) : 0);
     for (size_t i = 0; i < count; i++) {
         // (side by side every job computes its own phi image: there is no common stream that would order a borrower behind the owner)
-        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, carried ? -1 : ((one_key && !side) ? 18 : MsmJob<G>::phi_slot_of((int)(i % NS)))))) return rc;
-        if (carried && (jobs[i].NB != jobs[0].NB || jobs[i].c != jobs[0].c || jobs[i].pre || jobs[i].glv)) return ZL_EINVAL;
+        if ((rc = jobs[i].plan(ctx, *specs[i].bs, specs[i].first, specs[i].d_scalars, specs[i].n, (one_key && !side) ? 18 : MsmJob<G>::phi_slot_of((int)(i % NS))))) return rc;
         if (one_key && !side && i > 0) jobs[i].phi_owner = false;
         size_t a5, a6;
         jobs[i].sort_tmp_sizes(a5, a6);
@@ -256,15 +243,6 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
     hipEvent_t* ev_acc = ctx->timing_on ? pool_t + 2 + count : pool_nt + 2 * count;
     hipEvent_t* ev_acc0 = ctx->timing_on ? pool_t + 2 : nullptr;
     hipEvent_t ev_begin = pool_t[0], ev_end = pool_t[1];
-    if (carried) {
-        // one bucket set for all shards (the first job's); shard i adds into what shard i - 1 left, the last one reduces
-        for (size_t i = 0; i < count; i++) {
-            jobs[i].d_buckets = jobs[0].d_buckets;
-            jobs[i].carry_in = i > 0;
-            jobs[i].reduce = i + 1 == count;
-            jobs[i].ev_merged = pool_nt[3 * count + i];
-        }
-    }
     auto cleanup = [&]() {};  // (the events stay with the ctx)
     hipError_t he = hipSuccess;
     rc = ZL_OK;
@@ -297,7 +275,6 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
         hipStream_t js_acc = side ? lanes[i % NS] : s_acc;
         hipStream_t s_tail = side ? lanes[i % NS] : s_tails[i % 3];
         hipError_t e = hipStreamWaitEvent(js_acc, ev_sorted[i], 0);
-        if (e == hipSuccess && carried && i > 0) e = hipStreamWaitEvent(js_acc, jobs[i - 1].ev_merged, 0);  // the bucket sums of the previous shard are final
         if (e == hipSuccess && ctx->timing_on) e = hipEventRecord(ev_acc0[i], js_acc);
         if (e != hipSuccess) { ctx->last_hip = (int)e; return ZL_EHIP; }
         int r;
@@ -542,18 +519,6 @@ int ZL_GNAME(zl_msm_run_jobs)(zl_ctx* ctx, const zl_bases* const* bases, const s
 }
 template <class G>
 static int partials_sum_t(const uint64_t* partials, size_t count, uint64_t* out_partial);
-// shards of ONE MSM over ranges of one handle, on a carried bucket set (zl_msm with host scalars): one partial for the whole MSM
-int ZL_GNAME(zl_msm_run_shards)(zl_ctx* ctx, const zl_bases& b, const size_t* first, const void* const* d_scalars, const size_t* n, const hipEvent_t* wait,
-                                size_t count, uint64_t* out_partial, const std::atomic<int>* recorded) {
-    size_t total = 0;
-    for (size_t i = 0; i < count; i++) total += n[i];
-    std::vector<MsmSpec> specs(count);
-    for (size_t i = 0; i < count; i++) specs[i] = MsmSpec{&b, first[i], d_scalars[i], n[i], wait ? wait[i] : nullptr, count > 1 ? total : 0};
-    std::vector<uint64_t> parts(count * ZL_PARTIAL_WORDS);
-    int rc = msm_run_jobs_t<ZL_G>(ctx, specs.data(), count, parts.data(), recorded);
-    if (rc) return rc;
-    return partials_sum_t<ZL_G>(parts.data(), count, out_partial);  // the last shard's reduced buckets + every shard's scalar-1 bases
-}
 int ZL_GNAME(zl_msm_run)(zl_ctx* ctx, const zl_bases& b, size_t first, const void* d_scalars, size_t n, uint64_t* out_partial) {
     return msm_run_t<ZL_G>(ctx, b, first, d_scalars, n, out_partial);
 }

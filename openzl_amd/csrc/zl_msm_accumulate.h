@@ -25,9 +25,7 @@ __device__ __forceinline__ uint32_t zl_upper_bound(const uint32_t* __restrict__ 
 #define ZL_ACC_BLOCK 64
 #endif
 // one lane, one chunk: entries [t * ZL_CHUNK, (t + 1) * ZL_CHUNK) of the bucket-sorted list
-// CARRY (round 5, host-scalar shards): the bucket sums already hold the sums of the EARLIER shards of the same MSM (same windows, same bucket sets): a bucket
-// that lies inside this chunk starts from its old sum instead of infinity (buckets cut by a chunk boundary get theirs in k_msm_merge).
-template <class G, bool QUAD = false, bool CARRY = false>
+template <class G, bool QUAD = false>
 __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_t E, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
                                                     const Affine<typename HotField<typename G::F>::type>* __restrict__ bases,
                                                     XYZZ<typename HotField<typename G::F>::type>* __restrict__ bucket_sums,
@@ -56,9 +54,6 @@ __device__ __forceinline__ void zl_accumulate_chunk(uint32_t t, int sub, uint32_
             b_start = b_end;
             b_end = offsets[b + 1];
         }
-        if constexpr (CARRY) {
-            if (e == b_start && b_end <= end) acc = bucket_sums[b];  // first entry of a bucket that ends inside this chunk: continue the earlier shards' sum
-        }
         const uint32_t ent = entries[e];
         const uint32_t idx = ent & idx_mask;  // (the product kernels pass the literal: the sign bit off; the measurement kernel may fold the gather into a cache-resident prefix)
         const Affine<F> P = (G::GLV && idx >= n_real ? phib : bases)[idx];
@@ -85,19 +80,6 @@ __global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK
     zl_accumulate_chunk<G>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
                            reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
                            reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
-}
-template <class G>
-__global__ void __launch_bounds__(ZL_ACC_BLOCK, ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK > 0 ? ZL_ACC_WAVES * 64 / ZL_ACC_BLOCK : 1) k_msm_accumulate_carry(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets, uint32_t NB,
-                                                        const Affine<typename G::F>* __restrict__ bases_,
-                                                        XYZZ<typename G::F>* __restrict__ bucket_sums_,
-                                                        XYZZ<typename G::F>* __restrict__ partials_, uint32_t ZL_CHUNK,
-                                                        const Affine<typename G::F>* __restrict__ phib_, uint32_t n_real) {
-    if constexpr (G::COORDS == 1) {  // (host-scalar shards are G1 MSMs; the G2 groups only instantiate an empty kernel)
-        using F = typename HotField<typename G::F>::type;
-        zl_accumulate_chunk<G, false, true>(blockIdx.x * blockDim.x + threadIdx.x, 0, offsets[NB], entries, offsets, NB, reinterpret_cast<const Affine<F>*>(bases_),
-                                            reinterpret_cast<XYZZ<F>*>(bucket_sums_), reinterpret_cast<XYZZ<F>*>(partials_), ZL_CHUNK,
-                                            reinterpret_cast<const Affine<F>*>(phib_) - n_real, n_real);
-    }
 }
 #ifdef ZL_MEASURE
 // MEASUREMENT BUILDS ONLY (-DZL_MEASURE: ZL_EXTRA_FLAGS=-DZL_MEASURE ZL_BUILD_TAG=measure python -m openzl_amd.build; zl_test_acc_clock, include/zl_backend_test.h): the same kernel with four scalar clock reads per WAVE -- s_memtime (shader cycles) and
@@ -204,5 +186,4 @@ __global__ void __launch_bounds__(64, ZL_ACC_PAIR_WAVES) k_msm_accumulate_pair(c
     X template __global__ void k_msm_accumulate_quad<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_pair<G, true>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
     X template __global__ void k_msm_accumulate_pair<G, false>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
-    X template __global__ void k_msm_accumulate_carry<G>(const uint32_t*, const uint32_t*, uint32_t, const Affine<typename G::F>*, XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, const Affine<typename G::F>*, uint32_t); \
 

@@ -57,11 +57,6 @@ template <class G>
 struct MsmJob {
     using F = typename G::F;
     using X = XYZZ<F>;
-    // carried bucket set (host-scalar shards, zl_capi.hip msm_host_chunked): the shards of ONE MSM run as jobs with the same windows over the SAME bucket sums;
-    // carry_in: this job adds into the sums the earlier shards left (k_msm_accumulate_carry, merge kernels with carry = 1); reduce = false: no bucket
-    // reduction after this job (only the last shard reduces) -- its result is just the sum of its scalar-1 bases
-    bool carry_in = false, reduce = true;
-    hipEvent_t ev_merged = nullptr;  // recorded behind the merge kernels of tail(): the next shard's accumulation waits for it
     // plan
     bool pre = false;
     int c = 0, W = 0;
@@ -463,13 +458,10 @@ struct MsmJob {
     }
     static constexpr bool pair_ok() { return G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value; }  // an Fq2 group on 28-bit limbs: the lane-pair kernels exist
     int accumulate(zl_ctx* ctx, hipStream_t st) {
-        if (carry_in)
-            hipLaunchKernelGGL((k_msm_accumulate_carry<G>), dim3((nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
-                               glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
-        else if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
+        if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
             hipLaunchKernelGGL((k_msm_accumulate_pair<G, true>), dim3((nchunks + 7) / 8), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
-        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152) && reduce)  // four lanes per chunk while that still fits the machine at three waves per SIMD
+        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // four lanes per chunk while that still fits the machine at three waves per SIMD
             hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (pair_ok() && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)
@@ -493,9 +485,8 @@ struct MsmJob {
     int tail(zl_ctx* ctx, hipStream_t st) {
         // four lanes per group operation (zl_quad.h) in every tail launch that does not fill the machine
         const uint32_t quad_max = (uint32_t)zl_tune("ZL_TUNE_QUAD_LANES", 65536);
-        const uint32_t carry = carry_in ? 1u : 0u;
         const bool pair_tails = pair_ok() && zl_tune("ZL_TUNE_G2_PAIR_TAILS", 1), octet = pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1);  // Fq2 groups: two lanes per item where a launch fills the machine
-        const bool by_cuts = !carry && NB > quad_max && nchunks > 1 && zl_tune("ZL_TUNE_MERGE_CUTS", 1);  // one lane (pair) per chunk boundary: every surviving lane folds one bucket
+        const bool by_cuts = NB > quad_max && nchunks > 1 && zl_tune("ZL_TUNE_MERGE_CUTS", 1);  // one lane (pair) per chunk boundary: every surviving lane folds one bucket
         if (by_cuts) {
             hipLaunchKernelGGL((k_msm_fill_empty<G>), dim3((NB + 255) / 256), dim3(256), 0, st, d_offsets, NB, d_buckets);
             if (pair_tails)
@@ -503,38 +494,32 @@ struct MsmJob {
             else
                 hipLaunchKernelGGL((k_msm_merge_cuts<G>), dim3((nchunks + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, nchunks);
         } else if (pair_tails && NB > quad_max)
-            hipLaunchKernelGGL((k_msm_merge_pair<G, false>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+            hipLaunchKernelGGL((k_msm_merge_pair<G, false>), dim3((NB + 31) / 32), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         else if (octet && NB <= quad_max)
-            hipLaunchKernelGGL((k_msm_merge_pair<G, true>), dim3((NB + 7) / 8), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+            hipLaunchKernelGGL((k_msm_merge_pair<G, true>), dim3((NB + 7) / 8), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         else if (NB <= quad_max)
-            hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+            hipLaunchKernelGGL((k_msm_merge<G, true>), dim3((4 * NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         else
-        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span, carry);
+        hipLaunchKernelGGL((k_msm_merge<G>), dim3((NB + 63) / 64), dim3(64), 0, st, d_offsets, NB, d_buckets, d_partials, d_big_list, d_big_count, d_giant_list, d_giant_count, ZL_CHUNK, big_span);
         // a bucket cut into more than big_span (ZL_GIANT_SPAN) chunks needs that many chunks to exist: small jobs skip the launches (three of the ~22 of a small MSM's chain)
         const bool may_big = nchunks > big_span, may_giant = nchunks > (uint32_t)ZL_GIANT_SPAN;
         if (pair_tails && zl_tune("ZL_TUNE_G2_PAIR_BLOCKS", 1)) {  // Fq2 groups: the block-tree kernels of the heavy buckets on lane pairs
             if (may_big) hipLaunchKernelGGL((k_msm_merge_big_pair<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
-                               d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
+                               d_partials, d_big_list, d_big_count, ZL_CHUNK);
             if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant_pair<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(2 * TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                                d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2_pair<G>), dim3(std::min<uint32_t>(max_giant, 64)), dim3(2 * ZL_GIANT_PARTS), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2_pair<G>), dim3(std::min<uint32_t>(max_giant, 64)), dim3(2 * ZL_GIANT_PARTS), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count);
         } else {
             if (may_big) hipLaunchKernelGGL((k_msm_merge_big<G>), dim3(std::min<uint32_t>(max_big, 1024)), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_offsets, d_buckets,
-                           d_partials, d_big_list, d_big_count, ZL_CHUNK, carry);
+                           d_partials, d_big_list, d_big_count, ZL_CHUNK);
             if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant<G>), dim3(std::min<uint32_t>(max_giant, 16) * ZL_GIANT_PARTS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st,
                            d_offsets, d_giant_tmp, d_partials, d_giant_list, d_giant_count, ZL_CHUNK);
-            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count, carry);
+            if (may_giant) hipLaunchKernelGGL((k_msm_merge_giant2<G>), dim3((max_giant + 63) / 64), dim3(64), 0, st, d_buckets, d_giant_tmp, d_giant_list, d_giant_count);
         }
-        if (ev_merged) ZL_HIP(ctx, hipEventRecord(ev_merged, st));  // the bucket sums of this shard are final
         // scalar-1 bases: window-0 table entries are the bases themselves
         hipLaunchKernelGGL((k_msm_ones<G>), dim3(ZL_ONES_BLOCKS), dim3(TreeLanes<G>::N), TreeLanes<G>::N * sizeof(X), st, d_ones_list, d_ones_count,
                            pre ? d_bases + first : d_bases, d_ones_parts, glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu,
                            d_sets + (size_t)SETS * roots_per_set, d_big_count + 6, (const uint32_t*)(d_offsets + NB));  // (+ the final sum and the two status words: see the kernel)
-        if (!reduce) {  // an earlier shard of a carried bucket set: only the sum of its scalar-1 bases travels
-            ZL_HIP(ctx, hipGetLastError());
-            ZL_HIP(ctx, hipMemcpyAsync(hw + (size_t)SETS * roots_per_set, d_sets + (size_t)SETS * roots_per_set, sizeof(X) + 8, hipMemcpyDeviceToHost, st));
-            return ZL_OK;
-        }
         {
             const uint32_t fset = spread_t >= 0 ? (uint32_t)(W - 1) : 0xFFFFFFFFu, flog = (uint32_t)std::max(spread_t, 0);
             const uint32_t leaves = SETS * red_blocks;
@@ -589,7 +574,6 @@ struct MsmJob {
         return v;
     }
     X finish(bool parallel = true) const {
-        if (!reduce) return hw[(size_t)SETS * roots_per_set];
         std::vector<X> V(SETS);
         if (parallel && SETS >= 4) zl_pool_get().parallel_for(SETS, [&](size_t w) { V[w] = window_value((int)w); });
         else for (uint32_t w = 0; w < SETS; w++) V[w] = window_value((int)w);

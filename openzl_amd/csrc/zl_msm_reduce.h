@@ -20,9 +20,7 @@ template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 256) ? 3 : 1) k_msm_merge(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums_,
                                                    const XYZZ<typename G::F>* __restrict__ partials_, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
-                                                   uint32_t ZL_CHUNK, uint32_t big_span, uint32_t carry) {
-    // carry != 0 (host-scalar shards, zl_msm_accumulate.h): the bucket sums hold the earlier shards' sums -- an empty bucket keeps its sum, a cut bucket adds its
-    // partials to it
+                                                   uint32_t ZL_CHUNK, uint32_t big_span) {
     ZL_SIDE_PRIO();
     using F = TailF<typename G::F>;
     XYZZ<F>* __restrict__ bucket_sums = reinterpret_cast<XYZZ<F>*>(bucket_sums_);
@@ -32,13 +30,12 @@ __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 25
     const int sub = QUAD ? (int)(gt & 3u) : 0;
     if (b >= NB) return;
     const uint32_t s = offsets[b], e = offsets[b + 1];
-    if (s == e) { if (sub == 0 && !carry) bucket_sums[b] = XYZZ<F>::inf(); return; }
+    if (s == e) { if (sub == 0) bucket_sums[b] = XYZZ<F>::inf(); return; }
     const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
     if (t0 == t1) return;  // written directly by msm_accumulate
     if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (sub == 0) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
     if (t1 - t0 + 1 > big_span) { if (sub == 0) big_list[atomicAdd(big_count, 1u)] = b; return; }
     XYZZ<F> acc = XYZZ<F>::inf();
-    if (carry) acc = bucket_sums[b];
     for (uint32_t t = t0; t <= t1; t++) {
         const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
         if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
@@ -51,7 +48,7 @@ __global__ void __launch_bounds__(64, (QUAD && sizeof(XYZZ<typename G::F>) <= 25
 // three lanes of four leave at once and the additions of the rest run at a quarter of the wave (1.27 ms for 1.7 M additions at 2^24, c = 20: 1.3 additions
 // per ns where the level-0 kernel sustains 5.5).  Here lane t looks up the bucket that holds entry p (the binary search the accumulation does per chunk) and
 // folds its partials iff p is the FIRST boundary inside that bucket, so every lane that passes the two tests has exactly one bucket to fold.  Empty buckets
-// are written by k_msm_fill_empty (memory-bound, no field arithmetic).  Same partials, same lists, same sums as k_msm_merge (carry = 0 only).
+// are written by k_msm_fill_empty (memory-bound, no field arithmetic).  Same partials, same lists, same sums as k_msm_merge.
 __device__ __forceinline__ uint32_t zl_bucket_of_entry(const uint32_t* __restrict__ offsets, uint32_t NB, uint32_t p) {
     uint32_t lo = 0, hi = NB + 1;  // first index with offsets[idx] > p, minus one: offsets[b] <= p < offsets[b + 1] (never an empty bucket)
     while (lo < hi) {
@@ -118,7 +115,7 @@ __device__ __forceinline__ void zl_block_tree(XYZZ<typename G::F>* sh, XYZZ<type
 template <class G>
 __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
-                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK, uint32_t carry) {
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +125,6 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_big(const uint32_
         const uint32_t s = offsets[b], e = offsets[b + 1];
         const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
         XYZZ<F> acc = XYZZ<F>::inf();
-        if (carry && threadIdx.x == 0) acc = bucket_sums[b];
         for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
             const XYZZ<F> p = partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)];
             zl::add_full(acc, p);
@@ -165,13 +161,12 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_merge_giant(const uint3
 }
 template <class G>
 __global__ void __launch_bounds__(64) k_msm_merge_giant2(XYZZ<typename G::F>* __restrict__ bucket_sums, const XYZZ<typename G::F>* __restrict__ giant_tmp,
-                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count, uint32_t carry) {
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
     ZL_SIDE_PRIO();
     using F = typename G::F;
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= *giant_count) return;
     XYZZ<F> acc = XYZZ<F>::inf();
-    if (carry) acc = bucket_sums[giant_list[item]];
     for (uint32_t k = 0; k < ZL_GIANT_PARTS; k++) {
         const XYZZ<F> p = giant_tmp[(size_t)item * ZL_GIANT_PARTS + k];
         zl::add_full(acc, p);
@@ -326,7 +321,7 @@ template <class G, bool QUAD = false>
 __global__ void __launch_bounds__(64, 2) k_msm_merge_pair(const uint32_t* __restrict__ offsets, uint32_t NB, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                    const XYZZ<typename G::F>* __restrict__ partials, uint32_t* __restrict__ big_list,
                                                    uint32_t* __restrict__ big_count, uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
-                                                   uint32_t ZL_CHUNK, uint32_t big_span, uint32_t carry) {
+                                                   uint32_t ZL_CHUNK, uint32_t big_span) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
@@ -335,14 +330,13 @@ __global__ void __launch_bounds__(64, 2) k_msm_merge_pair(const uint32_t* __rest
         const uint32_t b = QUAD ? ZL_OCTET_ITEM() : ZL_PAIR_ITEM();
         if (b >= NB) return;
         const uint32_t s = offsets[b], e = offsets[b + 1];
-        if (s == e) { if (!carry) pair_store(&bucket_sums[b], half, X::inf()); return; }
+        if (s == e) { pair_store(&bucket_sums[b], half, X::inf()); return; }
         const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
         if (t0 == t1) return;
         const bool first = half == 0 && (!QUAD || sub == 0);
         if (t1 - t0 + 1 > ZL_GIANT_SPAN) { if (first) giant_list[atomicAdd(giant_count, 1u)] = b; return; }
         if (t1 - t0 + 1 > big_span) { if (first) big_list[atomicAdd(big_count, 1u)] = b; return; }
         X acc = X::inf();
-        if (carry) acc = pair_load(&bucket_sums[b], half);
         for (uint32_t t = t0; t <= t1; t++) {
             const X p = pair_load(&partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)], half);
             if constexpr (QUAD) zl::add_full_quad(acc, p, sub);
@@ -462,7 +456,7 @@ __device__ __forceinline__ void zl_block_tree_pair(XYZZ<typename G::F>* sh, XYZZ
 template <class G>
 __global__ void __launch_bounds__(2 * TreeLanes<G>::N) k_msm_merge_big_pair(const uint32_t* __restrict__ offsets, XYZZ<typename G::F>* __restrict__ bucket_sums,
                                                         const XYZZ<typename G::F>* __restrict__ partials, const uint32_t* __restrict__ big_list,
-                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK, uint32_t carry) {
+                                                        const uint32_t* __restrict__ big_count, uint32_t ZL_CHUNK) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
@@ -477,7 +471,6 @@ __global__ void __launch_bounds__(2 * TreeLanes<G>::N) k_msm_merge_big_pair(cons
             const uint32_t s = offsets[b], e = offsets[b + 1];
             const uint32_t t0 = s / ZL_CHUNK, t1 = (e - 1) / ZL_CHUNK;
             X acc = X::inf();
-            if (carry && item == 0) acc = pair_load(&bucket_sums[b], half);
             for (uint32_t t = t0 + item; t <= t1; t += N) {
                 const X p = pair_load(&partials[(size_t)2 * t + (s <= t * ZL_CHUNK ? 0 : 1)], half);
                 zl::add_full(acc, p);
@@ -520,7 +513,7 @@ __global__ void __launch_bounds__(2 * TreeLanes<G>::N) k_msm_merge_giant_pair(co
 // stage 2: one block of ZL_GIANT_PARTS pairs per giant bucket (the one-lane kernel folds the 32 sums serially: 32 Fq2 additions of latency)
 template <class G>
 __global__ void __launch_bounds__(2 * ZL_GIANT_PARTS) k_msm_merge_giant2_pair(XYZZ<typename G::F>* __restrict__ bucket_sums, XYZZ<typename G::F>* __restrict__ giant_tmp,
-                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count, uint32_t carry) {
+                                                          const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count) {
     using B = typename PairBase<typename G::F>::type;
     if constexpr (!std::is_void<B>::value) {
         ZL_SIDE_PRIO();
@@ -533,7 +526,6 @@ __global__ void __launch_bounds__(2 * ZL_GIANT_PARTS) k_msm_merge_giant2_pair(XY
             __syncthreads();
             zl_block_tree_pair<G, ZL_GIANT_PARTS>(sh, acc, item, half);
             if (item == 0) {
-                if (carry) { const X old = pair_load(&bucket_sums[giant_list[it]], half); zl::add_full(acc, old); }
                 pair_store(&bucket_sums[giant_list[it]], half, acc);
             }
         }
@@ -576,11 +568,11 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
 
 // every instantiation MsmJob<G>::tail launches (X as in zl_msm_accumulate.h)
 #define ZL_MSM_TAIL_KERNELS(X, G) \
-    X template __global__ void k_msm_merge<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_big<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
     X template __global__ void k_msm_merge_giant<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
-    X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
+    X template __global__ void k_msm_merge_giant2<G>(XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*); \
     X template __global__ void k_msm_ones<G>(const uint32_t*, const uint32_t*, const Affine<typename G::F>*, XYZZ<typename G::F>*, const Affine<typename G::F>*, uint32_t, XYZZ<typename G::F>*, uint32_t*, const uint32_t*); \
     X template __global__ void k_msm_reduce_level0<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_level0<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
@@ -589,11 +581,11 @@ __global__ void __launch_bounds__(TreeLanes<G>::N) k_msm_window_sum(const XYZZ<t
     X template __global__ void k_msm_fill_empty<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_merge_cuts<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
     X template __global__ void k_msm_merge_cuts_pair<G>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge_big_pair<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_big_pair<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
     X template __global__ void k_msm_merge_giant_pair<G>(const uint32_t*, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
-    X template __global__ void k_msm_merge_giant2_pair<G>(XYZZ<typename G::F>*, XYZZ<typename G::F>*, const uint32_t*, const uint32_t*, uint32_t); \
-    X template __global__ void k_msm_merge_pair<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
-    X template __global__ void k_msm_merge_pair<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_giant2_pair<G>(XYZZ<typename G::F>*, XYZZ<typename G::F>*, const uint32_t*, const uint32_t*); \
+    X template __global__ void k_msm_merge_pair<G, false>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
+    X template __global__ void k_msm_merge_pair<G, true>(const uint32_t*, uint32_t, XYZZ<typename G::F>*, const XYZZ<typename G::F>*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t); \
     X template __global__ void k_msm_reduce_level0_pair<G, false>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_level0_pair<G, true>(const XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, XYZZ<typename G::F>*); \
     X template __global__ void k_msm_reduce_tree_pair<G, false>(const XYZZ<typename G::F>*, XYZZ<typename G::F>*, uint32_t, uint32_t, uint32_t); \
