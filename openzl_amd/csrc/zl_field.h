@@ -286,7 +286,9 @@ ZL_NOINLINE_HD Fp<P> sqr_call12(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t 
 }
 template <class P>
 ZL_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
-#if !defined(ZL_INLINE_MUL) && !(defined(ZL_INLINE_MUL_DEVICE) && defined(__HIP_DEVICE_COMPILE__))
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return mul_impl(a, b);  // host: the 64-bit product inline (the out-of-line entry with its 16 scalar arguments exists for the device's register allocation)
+#elif !defined(ZL_INLINE_MUL) && !(defined(ZL_INLINE_MUL_DEVICE) && defined(__HIP_DEVICE_COMPILE__))
     if constexpr (P::N == 8) return mul_call8<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7]);
     else return mul_call12<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
 #else
@@ -295,7 +297,9 @@ ZL_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
 }
 template <class P>
 ZL_HD Fp<P> sqr(const Fp<P>& a) {
-#if !defined(ZL_INLINE_MUL) && !(defined(ZL_INLINE_MUL_DEVICE) && defined(__HIP_DEVICE_COMPILE__))
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return mul_impl(a, a);
+#elif !defined(ZL_INLINE_MUL) && !(defined(ZL_INLINE_MUL_DEVICE) && defined(__HIP_DEVICE_COMPILE__))
     if constexpr (P::N == 8) return sqr_call8<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7]);
     else return sqr_call12<P>(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11]);
 #else
