@@ -6,6 +6,7 @@
 #include <atomic>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <vector>
@@ -107,6 +108,9 @@ struct zl_bases {
     mutable size_t endo_first = 0, endo_n = 0;
     mutable int endo_k = 0;
     mutable std::vector<uint64_t> first_xy;  // canonical affine words of point 0, fetched once (Groth16: the z_0 = 1 term of a / b queries)
+    // Groth16 per-key state hung on the l_query handle of a proving key (zl_groth16.hip: host tables of the key's fixed points, the folded C query of small
+    // proofs); built on the first proof over the key under zl_bases_cache_mutex, released with the handle
+    mutable std::shared_ptr<void> g16_cache;
 };
 struct zl_scratch {
     void* p = nullptr;
@@ -272,7 +276,8 @@ inline int zl_scratch_get(zl_ctx* ctx, int slot, size_t bytes, void** out) {
     int zl_bases_upload_##G(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out); \
     int zl_bases_generate_##G(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out);                                     \
     int zl_bases_download_##G(zl_ctx* ctx, const zl_bases& b, size_t first, size_t count, uint64_t* out_xy);                \
-    int zl_bases_precompute_##G(zl_ctx* ctx, zl_bases& b, int c);
+    int zl_bases_precompute_##G(zl_ctx* ctx, zl_bases& b, int c);                                                           \
+    int zl_bases_concat_##G(zl_ctx* ctx, const zl_bases* const* parts, const size_t* first, const size_t* n, size_t count, zl_bases* out);
 ZL_DECL_GROUP(BlsG1)
 ZL_DECL_GROUP(BnG1)
 ZL_DECL_GROUP(BlsG2)

@@ -148,6 +148,159 @@ static int r1cs_upload_t(zl_ctx* ctx, const zl_r1cs* cs, zl_r1cs_dev* out) {
     return ZL_OK;
 }
 
+// ---- per-key host state (round 6): the proof's fixed-base products and the folded C query ---------------------------------------------------------------
+// A proof multiplies four points OF THE KEY by its blinding scalars (r delta1, s delta1, r s delta1, s delta2; the folded form below also s alpha1 and
+// r beta1).  As variable-base products they were 256 doublings + 64 additions each (~0.3 ms in G1, ~0.7 ms in G2, one host thread per product); with the
+// multiples d 2^(4 w) P, d = 1 .. 15, w = 0 .. 63, of a key point P tabulated once per key (960 affine points, batch-normalised: one inversion), a product is
+// at most 64 mixed additions and no doubling: ~30 us in G1, ~100 us in G2.
+template <class F>
+struct FixedBase {
+    std::vector<Affine<F>> tab;  // [64][15]
+    XYZZ<F> p = XYZZ<F>::inf();
+    bool tabulated = false;      // false: P is the point at infinity, or some small multiple of it is (a point outside the prime-order group): the plain product
+    void build(const XYZZ<F>& point) {
+        p = point;
+        tabulated = false;
+        tab.clear();
+        if (p.is_inf()) return;
+        std::vector<XYZZ<F>> t((size_t)64 * 15);
+        XYZZ<F> base = p;
+        for (int w = 0; w < 64; w++) {
+            XYZZ<F>* row = &t[(size_t)w * 15];
+            row[0] = base;
+            for (int d = 1; d < 15; d++) {
+                row[d] = row[d - 1];
+                zl::add_full(row[d], base);
+            }
+            zl::add_full(base, row[14]);  // 16 base
+        }
+        for (const XYZZ<F>& e : t) if (e.is_inf()) return;
+        // x = X / zz, y = Y / zzz with 1 / zz = (zz / zzz)^2 (zz^3 = zzz^2): one inversion for all the zzz (prefix products)
+        const size_t n = t.size();
+        std::vector<F> pre(n);
+        pre[0] = t[0].zzz;
+        for (size_t i = 1; i < n; i++) pre[i] = zl::mul(pre[i - 1], t[i].zzz);
+        F run = zl::inv(pre[n - 1]);
+        tab.resize(n);
+        for (size_t i = n; i-- > 0;) {
+            const F izzz = i ? zl::mul(run, pre[i - 1]) : run;
+            run = zl::mul(run, t[i].zzz);
+            const F iz = zl::mul(t[i].zz, izzz);
+            tab[i] = Affine<F>{zl::canon(zl::mul(t[i].x, zl::sqr(iz))), zl::canon(zl::mul(t[i].y, izzz))};
+        }
+        tabulated = true;
+    }
+    XYZZ<F> mul(const uint32_t* k) const {  // k: 256 bits, little-endian words
+        if (!tabulated) return zl::mul_scalar_w4(p, k);
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (int w = 0; w < 64; w++) {
+            const uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+            if (d) {
+                const Affine<F>& e = tab[(size_t)w * 15 + d - 1];
+                zl::add_mixed(acc, e.x, e.y, false);
+            }
+        }
+        return acc;
+    }
+};
+// The folded C query.  C = sum_w z_i L_i + sum h_i H_i + s A + r B1 - r s delta1 with A = alpha1 + sum z_i a_i + r delta1, B1 = beta1 + sum z_i b_i + s delta1, i.e.
+//   C = [ sum_w z_i L_i + sum_i (s z_i) a_i + sum_i (r z_i) b_i + sum h_i H_i ]  +  s alpha1 + r beta1 + r s delta1:
+// ONE multi-scalar multiplication over the concatenation l | a | b1 | h of the key's queries with the scalars z_w | s z | r z | h (the two scaled copies of z cost one
+// Fr product per variable on the device), plus three fixed-base products.  B1 is never formed, the two VARIABLE-base products s A + r B1 (~0.3 ms of host time behind the
+// a and b1 MSMs, on the critical path of a small proof) disappear, and a proof issues two G1 pipelines' worth of launches instead of four.  The price is n_variables more
+// points through the bucket method (the a query is used twice) and scaled scalars that have lost the witness's zeros and ones -- so only proofs whose MSMs
+// are latency, not throughput, take this form (ZL_TUNE_G16_FOLD_LOG_N).  The result is the same group element: the proof bytes do not change (tests/test_groth16.py).
+#define ZL_G16_FOLD_LOG_N 14  // domains up to 2^14 fold on both curves (profiles/r06_fold_ab.log: 2^15 is even on BLS12-381 and a loss on BN254, 2^18 a loss of 14 %)
+template <class G1, class G2>
+struct G16KeyCache {
+    using F1 = typename G1::F;
+    using F2 = typename G2::F;
+    std::vector<uint32_t> key_words;  // alpha1 | beta1 | delta1 | delta2 as handed in: the tables below belong to exactly these
+    FixedBase<F1> alpha1, beta1, delta1;
+    FixedBase<F2> delta2;
+    zl_bases fold;  // l | a | b1 | h
+    uint64_t fold_handles[4] = {0, 0, 0, 0};
+    size_t fold_nv = 0, fold_nw = 0, fold_nh = 0;
+    bool fold_built = false;
+    void drop_fold() {
+        if (fold.d_pts) (void)hipFree(fold.d_pts);
+        if (fold.d_endo) (void)hipFree(fold.d_endo);
+        if (fold.d_inf) (void)hipFree(fold.d_inf);
+        fold = zl_bases{};
+        fold_built = false;
+    }
+    ~G16KeyCache() { drop_fold(); }
+};
+template <class G1, class G2>
+static std::vector<uint32_t> g16_key_words(const zl_g16_pk* pk) {
+    constexpr size_t W1 = 2 * FieldIO<typename G1::F>::WORDS, W2 = 2 * FieldIO<typename G2::F>::WORDS;
+    std::vector<uint32_t> w(3 * W1 + W2);
+    memcpy(&w[0], pk->alpha_g1, W1 * 4);
+    memcpy(&w[W1], pk->beta_g1, W1 * 4);
+    memcpy(&w[2 * W1], pk->delta_g1, W1 * 4);
+    memcpy(&w[3 * W1], pk->delta_g2, W2 * 4);
+    return w;
+}
+// the cache of this key (built on first use), with the folded query for (nv, nw, nh) if `want_fold`.  bs: a, b1, h, l handles of the key
+template <class G1, class G2>
+static int g16_key_cache(zl_ctx* ctx, const zl_g16_pk* pk, const zl_bases* const* bs, bool want_fold, size_t nv, size_t nw, size_t nh,
+                         std::shared_ptr<G16KeyCache<G1, G2>>* out) {
+    using KC = G16KeyCache<G1, G2>;
+    const std::vector<uint32_t> words = g16_key_words<G1, G2>(pk);
+    const uint64_t hs[4] = {pk->l_query, pk->a_query, pk->b_g1_query, pk->h_query};
+    std::lock_guard<std::mutex> lk(zl_bases_cache_mutex());  // (two lanes may prove over one key for the first time together)
+    std::shared_ptr<KC> kc = std::static_pointer_cast<KC>(bs[3]->g16_cache);
+    if (!kc || kc->key_words != words) {
+        kc = std::make_shared<KC>();
+        kc->key_words = words;
+        kc->alpha1.build(affine_from_canon<G1>(pk->alpha_g1));
+        kc->beta1.build(affine_from_canon<G1>(pk->beta_g1));
+        kc->delta1.build(affine_from_canon<G1>(pk->delta_g1));
+        kc->delta2.build(affine_from_canon<G2>(pk->delta_g2));
+        bs[3]->g16_cache = kc;
+    }
+    if (want_fold && !(kc->fold_built && kc->fold_nv == nv && kc->fold_nw == nw && kc->fold_nh == nh && !memcmp(kc->fold_handles, hs, sizeof hs))) {
+        if (kc.use_count() > 2) {  // a proof on another lane still works with the old folded query: a fresh cache object takes its place
+            auto fresh = std::make_shared<KC>();
+            fresh->key_words = kc->key_words;
+            fresh->alpha1 = kc->alpha1;
+            fresh->beta1 = kc->beta1;
+            fresh->delta1 = kc->delta1;
+            fresh->delta2 = kc->delta2;
+            kc = fresh;
+            bs[3]->g16_cache = kc;
+        }
+        kc->drop_fold();
+        const zl_bases* parts[4] = {bs[3], bs[0], bs[1], bs[2]};
+        const size_t first[4] = {0, 0, 0, 0}, n[4] = {nw, nv, nv, nh};
+        zl_bases f;
+        const int rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_bases_concat, ctx, parts, first, n, 4, &f);
+        if (rc) return rc;
+        f.curve = (int)pk->curve;
+        f.group = ZL_G1;
+        kc->fold = f;
+        memcpy(kc->fold_handles, hs, sizeof hs);
+        kc->fold_nv = nv;
+        kc->fold_nw = nw;
+        kc->fold_nh = nh;
+        kc->fold_built = true;
+    }
+    *out = kc;
+    return ZL_OK;
+}
+// the scalars of the folded C query: out_zw = z[ni ..) (canonical), out_sz = s z, out_rz = r z (zm: z in Montgomery form, s and r canonical: the Montgomery product of
+// z R and s is z s, canonical)
+template <class FrP>
+__global__ void __launch_bounds__(256) k_g16_fold_scalars(const Fp<FrP>* __restrict__ zc, const Fp<FrP>* __restrict__ zm, Fp<FrP> s, Fp<FrP> r, uint32_t ni, uint32_t nv,
+                                                          Fp<FrP>* __restrict__ out_zw, Fp<FrP>* __restrict__ out_sz, Fp<FrP>* __restrict__ out_rz) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const Fp<FrP> m = zm[i];
+    out_sz[i] = i ? zl::mul(m, s) : s;  // (variable 0 is the constant ONE: its terms a_0, b_0 enter A and B1 unscaled, whatever the caller wrote there)
+    out_rz[i] = i ? zl::mul(m, r) : r;
+    if (i >= ni) out_zw[i - ni] = zc[i];
+}
+
 template <class G1, class G2>
 // `witness` (optional): the assignment arrives in two pieces, `assignment` = the instance block and `witness` = the witness block, as the
 // compiler holds them (openzl::Groth16::prove): two copies to the device instead of a host-side concatenation of tens of megabytes per proof
@@ -192,7 +345,10 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     size_t bytes = 0;
     auto take = [&](size_t b) { size_t o = bytes; bytes += (b + 255) / 256 * 256; return o; };
     const size_t off_zc = take((size_t)nv * 32), off_zm = take((size_t)nv * 32);
-    const size_t off_a = take((size_t)N * 32), off_b = take((size_t)N * 32), off_c = take((size_t)N * 32), off_h = take((size_t)N * 32);
+    // a small proof's C comes from ONE folded query (G16KeyCache above): its scalars z_w | s z | r z | h are one vector, h (N entries written, N - 1 used) at its end
+    const bool fold = !wm_only && log_n <= (unsigned)zl_tune("ZL_TUNE_G16_FOLD_LOG_N", ZL_G16_FOLD_LOG_N);
+    const size_t fold_head = fold ? (size_t)nw + 2 * (size_t)nv : 0;
+    const size_t off_a = take((size_t)N * 32), off_b = take((size_t)N * 32), off_c = take((size_t)N * 32), off_h = take((fold_head + N) * 32) + fold_head * 32;
     void* base;
     int rc;
     if ((rc = zl_scratch_get(ctx, 8, bytes, &base))) return rc;  // slots 0-7 belong to the MSM / NTT / staging paths
@@ -218,6 +374,13 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         hipLaunchKernelGGL((k_fr_to_mont<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zm, nv);
     }
     Fr *d_a = (Fr*)(d + off_a), *d_b = (Fr*)(d + off_b), *d_c = (Fr*)(d + off_c), *d_h = (Fr*)(d + off_h);
+    Fr* d_fold = d_h - fold_head;
+    if (fold) {
+        Fr sf, rf;
+        memcpy(sf.l, s, 32);
+        memcpy(rf.l, r, 32);
+        hipLaunchKernelGGL((k_g16_fold_scalars<FrP>), dim3((nv + 255) / 256), dim3(256), 0, st, d_zc, d_zm, sf, rf, ni, nv, d_fold, d_fold + nw, d_fold + nw + nv);
+    }
     Fr* dv[3] = {d_a, d_b, d_c};
     // ---- witness map on its own context / stream: spmv, 3 x (ifft, coset fft), pointwise, coset ifft -> h -------------------------
     // It only needs z, like four of the five MSMs, so it runs beside them (memory- and latency-bound kernels in the shadow of the
@@ -282,12 +445,9 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     // ---- the five MSMs ----------------------------------------------------------------------------------------------
     uint64_t part[5][ZL_PARTIAL_WORDS];
     const unsigned char* zc = reinterpret_cast<const unsigned char*>(d_zc);
-    // The G2 MSM (Fq2: one wave per SIMD, half of the issue slots idle) runs on an auxiliary stream with its own scratch
-    // while the four G1 MSMs run on the main stream: the two streams fill each other's gaps (54 -> ~35 ms at 2^20).
-    {
-        const hipError_t e_z = hipStreamSynchronize(st);  // z is complete before the other streams / threads read it
-        if (e_z != hipSuccess) { ctx->last_hip = (int)e_z; return wm_fail(ZL_EHIP); }
-    }
+    // The G2 MSM runs on an auxiliary stream with its own scratch while the G1 MSMs run on the main streams: the two fill each other's gaps (54 -> ~35 ms at 2^20).
+    // Nobody waits for z on the host: the G1 pipeline's streams all start behind an event it records on `st` (zl_msm.hip: ev_begin), the witness map and the G2
+    // stream wait for ev_z (a small proof spent ~35 us here, in front of every launch of its MSMs)
     // first points of the a / b queries (index 0 pairs with z[0] = 1); fetched here, before the MSM streams are busy (the download uses the
     // ctx's own stream and sort scratch)
     uint64_t a0_xy[12], b0_xy[12], b20_xy[24];
@@ -305,18 +465,17 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             memcpy(f.out, f.b->first_xy.data(), f.words * 8);
         }
     }
-    // host work that does not depend on the MSMs (r*delta1, s*delta1, r*s*delta1, s*delta2: ~1300 group operations) runs on a third
-    // thread while the device is busy
+    // the key's host tables (and, for a small proof, its folded C query): built by the first proof over the key
+    std::shared_ptr<G16KeyCache<G1, G2>> kc;
+    if ((rc = g16_key_cache<G1, G2>(ctx, pk, bs, fold, nv, nw, (size_t)N - 1, &kc))) return wm_fail(rc);
+    // host work that does not depend on the MSMs -- the fixed-base products r delta1, s delta2 and (folded form) s alpha1 + r beta1 + r s delta1, or (four-MSM form)
+    // s delta1 and -r s delta1 -- runs on two threads while the device is busy: at most 64 mixed additions each from the key's tables
     uint32_t rw[8], sw[8];
     memcpy(rw, r, 32);
     memcpy(sw, s, 32);
-    const XYZZ<F1> delta1 = affine_from_canon<G1>(pk->delta_g1);
-    const XYZZ<F2> delta2 = affine_from_canon<G2>(pk->delta_g2);
-    XYZZ<F1> r_delta1, s_delta1, rs_delta;
+    XYZZ<F1> r_delta1, s_delta1, rs_delta, c_fixed;
     XYZZ<F2> s_delta2;
-    // (three threads: the four scalar multiplications are ~0.3 ms each in G1 and ~1 ms in G2 -- one after the other they were 1.9 ms, the
-    // longest single item of a small proof)
-    // (r s) delta1 from the product r s in Fr, so that all four are independent
+    // (r s) delta1 from the product r s in Fr, so that the products are independent
     uint32_t rsw[8];
     {
         using FrF = Fp<typename G1::FrP>;
@@ -326,16 +485,27 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         const FrF rs = zl::from_mont(zl::mul(zl::to_mont(rm), zl::to_mont(sm)));
         memcpy(rsw, rs.l, 32);
     }
-    std::thread pre([&]() { r_delta1 = zl::mul_scalar_w4(delta1, rw); lap_us("r delta1 done"); });
-    std::thread pre_c([&]() { rs_delta = zl::mul_scalar_w4(delta1, rsw); zl::neg_inplace(rs_delta); });
-    std::thread pre_b([&]() { s_delta1 = zl::mul_scalar_w4(delta1, sw); });
-    std::thread pre_g2([&]() { s_delta2 = zl::mul_scalar_w4(delta2, sw); lap_us("s delta2 done"); });
+    std::thread pre([&]() {
+        r_delta1 = kc->delta1.mul(rw);
+        lap_us("r delta1 done");
+        rs_delta = kc->delta1.mul(rsw);
+        if (fold) {
+            c_fixed = kc->alpha1.mul(sw);
+            zl::add_full(c_fixed, kc->beta1.mul(rw));
+            zl::add_full(c_fixed, rs_delta);
+        } else {
+            zl::neg_inplace(rs_delta);
+            s_delta1 = kc->delta1.mul(sw);
+        }
+        lap_us("G1 fixed-base products done");
+    });
+    std::thread pre_g2([&]() { s_delta2 = kc->delta2.mul(sw); lap_us("s delta2 done"); });
     lap_us("z on device, host pre started");
     int rc_g2 = ZL_OK;
     XYZZ<F1> g_a = XYZZ<F1>::inf(), g1_b = XYZZ<F1>::inf(), g_c = XYZZ<F1>::inf();
     bool have_c = false;
-    uint64_t a_words[12] = {0};
-    uint8_t a_inf = 0;
+    uint64_t a_words[12] = {0}, b_words[24] = {0};
+    uint8_t a_inf = 0, b_inf = 0;
     {
         zl_ctx* aux = ctx->aux;
         const zl_bases* b2 = bs[4];
@@ -343,9 +513,43 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         uint64_t* out2 = part[4];
         zl_worker& g2 = zl_ctx_worker(ctx, 1);
         g2.run([&, aux, b2, curve, out2]() {
-            if (hipSetDevice(aux->device) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
+            if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ev_z, 0) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
             rc_g2 = ZL_DISPATCH(curve, ZL_G2, zl_msm_run, aux, *b2, 1, zc + 32, nv - 1, out2);
+            if (rc_g2 != ZL_OK) return;
+            // B = beta2 + sum z_i b2_i + s delta2 is complete here: assembled and normalised (the Fq2 inversion) on this thread, beside the G1 pipeline
+            pre_g2.join();
+            XYZZ<F2> g2_b = s_delta2;
+            zl::add_full(g2_b, affine_from_canon<G2>(b20_xy));
+            zl::add_full(g2_b, from_partial<F2>(out2));
+            zl::add_full(g2_b, affine_from_canon<G2>(pk->beta_g2));
+            store_canon<G2>(b_words, &b_inf, g2_b);
+            lap_us("B done");
         });
+        if (fold) {
+            // folded form: the a MSM (for A) and ONE MSM over l | a | b1 | h for all of C's sums; the second waits for the witness map's event
+            const zl_bases* jb[2] = {bs[0], &kc->fold};
+            const size_t jf[2] = {1, 0};
+            const void* js[2] = {zc + 32, d_fold};
+            const size_t jn[2] = {(size_t)nv - 1, fold_head + (size_t)N - 1};
+            const hipEvent_t jw[2] = {nullptr, ev_h};
+            uint64_t jp[2][ZL_PARTIAL_WORDS];
+            const std::function<void(size_t)> on_done = [&](size_t i) {
+                if (i != 0) return;
+                pre.join();
+                g_a = r_delta1;
+                zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
+                zl::add_full(g_a, from_partial<F1>(jp[0]));
+                zl::add_full(g_a, affine_from_canon<G1>(pk->alpha_g1));
+                store_canon<G1>(a_words, &a_inf, g_a);  // A is final: its normalisation (one inversion) runs under the second MSM
+                g_c = c_fixed;
+                have_c = true;
+                lap_us("A done");
+            };
+            rc = ZL_DISPATCH(pk->curve, ZL_G1, zl_msm_run_jobs, ctx, jb, jf, js, jn, jw, 2, &jp[0][0], (const std::atomic<int>*)&h_recorded, &on_done);
+            memcpy(part[0], jp[0], sizeof jp[0]);
+            memcpy(part[3], jp[1], sizeof jp[1]);                 // every sum of C
+            { const XYZZ<F1> none = XYZZ<F1>::inf(); memset(part[2], 0, sizeof part[2]); memcpy(part[2], &none, sizeof none); }
+        } else {
         // the four G1 MSMs as one pipeline (sort | accumulate | tail of consecutive MSMs overlap, zl_msm.hip): l, a, b1 need only z;
         // the h job waits for the witness map's event
         {
@@ -356,14 +560,12 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             const size_t jn[4] = {(size_t)nv - 1, (size_t)nv - 1, (size_t)nw, (size_t)N - 1};
             const hipEvent_t jw[4] = {nullptr, nullptr, nullptr, ev_h};
             uint64_t jp[4][ZL_PARTIAL_WORDS];
-            // A and B1 are complete once the a and b1 MSMs (jobs 0, 1) are: their double-scalar product s A + r B1 (255 doublings + ~190
-            // additions on the host, ~0.4 ms) runs on the pipeline's completion thread while the h MSM and the G2 MSM are still on the device
+            // A and B1 are complete once the a and b1 MSMs (jobs 0, 1) are: their products s A and r B1 (256 doublings + 64 additions each on the host) run on
+            // the pipeline's completion thread and one more while the h MSM and the G2 MSM are still on the device
             const std::function<void(size_t)> on_done = [&](size_t i) {
                 if (i != 1) return;
                 lap_us("a, b1 delivered");
                 pre.join();
-                pre_b.join();
-                pre_c.join();
                 g_a = r_delta1;
                 zl::add_full(g_a, affine_from_canon<G1>(a0_xy));
                 zl::add_full(g_a, from_partial<F1>(jp[0]));
@@ -391,6 +593,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
             memcpy(part[3], jp[2], sizeof jp[2]);
             memcpy(part[2], jp[3], sizeof jp[3]);
         }
+        }
         lap_us("G1 pipeline returned");
         w_wm.wait();
         (void)hipStreamSynchronize(s_wm);  // also on the error path: nothing of this proof may still be running
@@ -399,9 +602,7 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         lap_us("G2 joined");
     }
     if (pre.joinable()) pre.join();
-    if (pre_b.joinable()) pre_b.join();
-    if (pre_c.joinable()) pre_c.join();
-    pre_g2.join();
+    if (pre_g2.joinable()) pre_g2.join();
     if (!rc) rc = rc_g2;
     if (!rc && !have_c) rc = ZL_EHIP;  // (the completion callback did not run: cannot happen after a successful pipeline)
     ctx->timing_on = timing_saved;
@@ -415,22 +616,16 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
     }
     ctx->g16_h = d_h;
     ctx->g16_h_n = N;
-    // ---- host assembly: A, B1 and s A + r B1 - r s delta1 were formed by the completion callback above; what is left needs the last MSMs
-    XYZZ<F2> g2_b = s_delta2;
-    zl::add_full(g2_b, affine_from_canon<G2>(b20_xy));
-    zl::add_full(g2_b, from_partial<F2>(part[4]));
-    zl::add_full(g2_b, affine_from_canon<G2>(pk->beta_g2));
+    // ---- host assembly: A (and, in the four-MSM form, s A + r B1 - r s delta1) were formed by the completion callback above and B by the G2 worker; C needs the last MSMs
     zl::add_full(g_c, from_partial<F1>(part[3]));
     zl::add_full(g_c, from_partial<F1>(part[2]));
     lap_us("assembly");
     memset(out, 0, sizeof *out);
     memcpy(out->a, a_words, sizeof a_words);
     out->a_inf = a_inf;
-    {
-        std::thread nb([&]() { store_canon<G2>(out->b, &out->b_inf, g2_b); });  // the Fq2 inversion beside the Fq one
-        store_canon<G1>(out->c, &out->c_inf, g_c);
-        nb.join();
-    }
+    memcpy(out->b, b_words, sizeof b_words);
+    out->b_inf = b_inf;
+    store_canon<G1>(out->c, &out->c_inf, g_c);
     lap_us("proof normalised");
     return ZL_OK;
 }

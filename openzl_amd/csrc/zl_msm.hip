@@ -628,6 +628,36 @@ static int bases_upload_t(zl_ctx* ctx, const void* xy, size_t n, size_t stride, 
 int ZL_GNAME(zl_bases_upload)(zl_ctx* ctx, const void* xy, size_t n, size_t stride, long inf_off, unsigned flags, zl_bases* out) {
     return bases_upload_t<ZL_G>(ctx, xy, n, stride, inf_off, flags, out);
 }
+// one handle holding the concatenation of ranges of other handles of the same group (device-to-device; Groth16's folded C query, zl_groth16.hip)
+template <class G>
+static int bases_concat_t(zl_ctx* ctx, const zl_bases* const* parts, const size_t* first, const size_t* n, size_t count, zl_bases* out) {
+    using F = typename G::F;
+    size_t total = 0;
+    for (size_t i = 0; i < count; i++) {
+        if (!parts[i] || first[i] > parts[i]->n || n[i] > parts[i]->n - first[i]) return ZL_EINVAL;
+        total += n[i];
+    }
+    if (total >= (1ull << 31)) return ZL_EINVAL;
+    void* d_pts = nullptr;
+    ZL_HIP(ctx, hipMalloc(&d_pts, std::max<size_t>(total, 1) * sizeof(Affine<F>)));
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    size_t at = 0;
+    for (size_t i = 0; i < count && e == hipSuccess; i++) {
+        if (n[i]) e = hipMemcpyAsync(reinterpret_cast<Affine<F>*>(d_pts) + at, reinterpret_cast<const Affine<F>*>(parts[i]->d_pts) + first[i], n[i] * sizeof(Affine<F>), hipMemcpyDeviceToDevice, st);
+        at += n[i];
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; (void)hipFree(d_pts); return ZL_EHIP; }
+    out->d_pts = d_pts;
+    out->n = total;
+    const int rc = bases_flag_inf_t<G>(ctx, out);
+    if (rc) { (void)hipFree(d_pts); out->d_pts = nullptr; out->n = 0; return rc; }
+    return ZL_OK;
+}
+int ZL_GNAME(zl_bases_concat)(zl_ctx* ctx, const zl_bases* const* parts, const size_t* first, const size_t* n, size_t count, zl_bases* out) {
+    return bases_concat_t<ZL_G>(ctx, parts, first, n, count, out);
+}
 template <class G>
 static int bases_generate_t(zl_ctx* ctx, const uint64_t* k, size_t n, zl_bases* out) {
     using F = typename G::F;

@@ -63,3 +63,25 @@ def test_gpu_groth16_prove_matches_oracle(backend, curve, k):
     if k == 1:
         ga, gb, gc = _expected_points(curve, cs, pk, ol.limbs_to_ints(h))
         assert (got[0] == ga).all() and (got[2] == gb).all() and (got[4] == gc).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [po.BLS12_381, po.BN254], ids=lambda c: c.name)
+def test_gpu_groth16_folded_c_query_gives_the_same_proof(backend, curve, monkeypatch):
+    """Small proofs take C from ONE MSM over l | a | b1 | h with the scalars z_w | s z | r z | h (zl_groth16.hip, G16KeyCache) and the key's
+    fixed-base tables; the four-MSM form with s A + r B1 on the host stays for large ones.  Same group elements either way: the proof bytes
+    of both forms are equal to each other and to the oracle's, for ordinary and for degenerate blinding scalars, alternating over one key."""
+    cs, pk, arrays, z, r, s = _case(curve, 8)
+    zero = ol.ints_to_limbs([0], 4)[0]
+    rmax = ol.ints_to_limbs([curve.fr.p - 1], 4)[0]
+    dpk = gu.upload_pk(backend, curve, pk)
+    try:
+        for rr, ss in ((r, s), (zero, zero), (rmax, s), (r, zero)):
+            exp, _ = gu.oracle_prove(curve, arrays, z, pk, rr, ss, threads=8, want_h=1 << cs.domain_log())
+            for mode in ("0", "20", "0", "20"):
+                monkeypatch.setenv("ZL_TUNE_G16_FOLD_LOG_N", mode)
+                got = backend.groth16_prove(curve.cid, dpk, arrays, z, rr, ss)
+                for g, e in zip(got, exp):
+                    assert np.array_equal(np.asarray(g), np.asarray(e)), mode
+    finally:
+        gu.free_pk(backend, dpk)

@@ -57,6 +57,10 @@ for k in 1 64; do
   python tools/timeline.py $(dbof $O/pg$k) 150 > $O/r06_timeline_g16_k$k.txt 2>&1
 done
 python tools/small_lat.py > $O/r06_small_latency.log 2>&1
+# host-side phase times of a one-hash proof: folded form (default), the four-MSM form, BN254
+ZL_HOST_TRACE=1 ITERS=6 python tools/g16_one.py 1 2>&1 | grep -v "prove \|synth\|amdgpu.ids" | tail -19 > $O/r06_fold_trace_after.txt
+ZL_TUNE_G16_FOLD_LOG_N=0 ZL_HOST_TRACE=1 ITERS=6 python tools/g16_one.py 1 2>&1 | grep -v "prove \|synth\|amdgpu.ids" | tail -30 > $O/r06_fold_trace_fourjobs.txt
+CURVE=bn254 ZL_HOST_TRACE=1 ITERS=6 python tools/g16_one.py 1 2>&1 | grep -v "prove \|synth\|amdgpu.ids" | tail -19 > $O/r06_fold_trace_after_bn254.txt
 # effective clocks (in-kernel s_memtime / s_memrealtime) and the SQ issue / stall counters of the two dominant kernels
 ZL_BACKEND_LIB=$R/openzl_amd/libzl_backend.measure.so python tools/clock_probe.py 24 3 > $O/r06_clock_probe_2_24.log 2>&1   # the clock-reading accumulation exists in -DZL_MEASURE builds only (ZL_EXTRA_FLAGS=-DZL_MEASURE ZL_BUILD_TAG=measure python -m openzl_amd.build)
 C="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES"
