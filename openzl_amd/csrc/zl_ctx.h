@@ -54,8 +54,10 @@ struct BnG1 {
     static constexpr int SC_BITS = 254;
     static constexpr int FQ64 = 4;
     static constexpr int COORDS = 1;
-    static constexpr bool GLV = false;
-    static constexpr int ENDO_K = 1;
+    static constexpr bool GLV = true;  // round 6: the same endomorphism split as BLS12-381 G1, with the two-dimensional lattice decomposition (BN254_GLV, k_glv_split_lattice)
+    static constexpr int ENDO_K = 2;
+    using GLVP = BN254_GLV;
+    ZL_HD static F glv_beta() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = GLVP::beta(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F gen_x() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gx(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F gen_y() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::gy(i); return FieldIO<F>::load_mont32(w); }
     ZL_HD static F coeff_b() { uint32_t w[FqP::N]; for (int i = 0; i < FqP::N; i++) w[i] = C::b(i); return FieldIO<F>::load_mont32(w); }

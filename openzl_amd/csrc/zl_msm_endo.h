@@ -134,6 +134,109 @@ __global__ void __launch_bounds__(256) k_glv_split(const uint32_t* __restrict__ 
     o2[0] = make_uint4((uint32_t)k2.lo, (uint32_t)(k2.lo >> 32), (uint32_t)k2.hi, (uint32_t)(k2.hi >> 32));
     o2[1] = make_uint4(0, 0, 0, neg2 << 31);
 }
+// BN254 G1: r is not lambda^2 + lambda + 1 with a 128-bit lambda, so the split is the two-dimensional one of GLV (2001): with the short basis v1 = (a1, b1), v2 = (a2, b2) of the
+// lattice {(a, b): a + b lambda = 0 mod r}, c1 = round(b2 k / r), c2 = round(-b1 k / r) and (k1, k2) = (k, 0) - c1 v1 - c2 v2.  The roundings are taken as
+// (k g_i + 2^255) >> 256 with g_i = round(2^256 |.| / r): at most one off, which moves (k1, k2) by one basis vector and keeps k1 + k2 lambda = k (mod r) exactly.
+// All products are taken on magnitudes, modulo 2^192; |k1|, |k2| < 0.6 * 2^127 (tools/gen_bn254_glv.py runs this arithmetic on edge and random scalars).
+// Same record format as k_glv_split.
+template <int NA, int NB, int NO>
+__device__ __forceinline__ void zl_mul_words(const uint32_t* a, const uint32_t* b, uint32_t* out) {  // out[0 .. NO) = low NO words of a[0 .. NA) * b[0 .. NB)
+    uint64_t acc = 0;
+    uint32_t top = 0;
+#pragma unroll
+    for (int col = 0; col < NO; col++) {
+#pragma unroll
+        for (int x = 0; x < NA; x++) {
+            const int y = col - x;
+            if (y < 0 || y >= NB) continue;
+            const uint64_t pr = (uint64_t)a[x] * b[y];
+            acc += pr;
+            top += acc < pr ? 1u : 0u;
+        }
+        out[col] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)top << 32);
+        top = 0;
+    }
+}
+template <int N>
+__device__ __forceinline__ void zl_addsub_words(uint32_t* acc, const uint32_t* v, bool sub) {  // acc +-= v (mod 2^(32 N))
+    uint32_t carry = sub ? 1u : 0u;  // a - v = a + ~v + 1
+#pragma unroll
+    for (int w = 0; w < N; w++) {
+        const uint64_t x = (uint64_t)acc[w] + (sub ? ~v[w] : v[w]) + carry;
+        acc[w] = (uint32_t)x;
+        carry = (uint32_t)(x >> 32);
+    }
+}
+template <class P>
+__global__ void __launch_bounds__(256) k_glv_split_lattice(const uint32_t* __restrict__ scalars, uint32_t n, const uint8_t* __restrict__ inf, uint32_t* __restrict__ out,
+                                                            int sc_bits, uint32_t* __restrict__ bad) {
+    ZL_SIDE_PRIO();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    uint4 lo4 = sp[0], hi4 = sp[1];
+    zl_flag_wide_scalar(hi4.w, sc_bits, bad);
+    if (inf && inf[i]) lo4 = hi4 = make_uint4(0, 0, 0, 0);
+    uint32_t k[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    zl_reduce_once_mod_r<P>(k);
+    uint32_t g1[5], g2[5], a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+    for (int w = 0; w < 5; w++) { g1[w] = P::g1(w); g2[w] = P::g2(w); }
+#pragma unroll
+    for (int w = 0; w < 4; w++) { a1[w] = P::a1(w); b1[w] = P::b1(w); a2[w] = P::a2(w); b2[w] = P::b2(w); }
+    // c_i = (k g_i + 2^255) >> 256: words 8 .. 11 of the 13-word product (c1 < 2^66, c2 < 2^127)
+    uint32_t pr[13], c1[4], c2[4];
+    const uint32_t half[8] = {0, 0, 0, 0, 0, 0, 0, 0x80000000u};
+    zl_mul_words<8, 5, 13>(k, g1, pr);
+    {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < 13; w++) {
+            const uint64_t x = (uint64_t)pr[w] + (w < 8 ? half[w] : 0u) + carry;
+            pr[w] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) c1[w] = pr[8 + w];
+    zl_mul_words<8, 5, 13>(k, g2, pr);
+    {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < 13; w++) {
+            const uint64_t x = (uint64_t)pr[w] + (w < 8 ? half[w] : 0u) + carry;
+            pr[w] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) c2[w] = pr[8 + w];
+    // k1 = k -+ c1 |a1| -+ c2 |a2|,  k2 = -+ c1 |b1| -+ c2 |b2|   (mod 2^192; the true values are below 2^127 in magnitude)
+    uint32_t k1[6], k2[6] = {0, 0, 0, 0, 0, 0}, t[6];
+#pragma unroll
+    for (int w = 0; w < 6; w++) k1[w] = k[w];
+    zl_mul_words<4, 4, 6>(c1, a1, t);
+    zl_addsub_words<6>(k1, t, P::SUB_C1A1 != 0);
+    zl_mul_words<4, 4, 6>(c2, a2, t);
+    zl_addsub_words<6>(k1, t, P::SUB_C2A2 != 0);
+    zl_mul_words<4, 4, 6>(c1, b1, t);
+    zl_addsub_words<6>(k2, t, P::SUB_C1B1 != 0);
+    zl_mul_words<4, 4, 6>(c2, b2, t);
+    zl_addsub_words<6>(k2, t, P::SUB_C2B2 != 0);
+    uint32_t neg1 = k1[5] >> 31, neg2 = k2[5] >> 31;
+    if (neg1) { uint32_t m[6] = {0, 0, 0, 0, 0, 0}; zl_addsub_words<6>(m, k1, true); for (int w = 0; w < 6; w++) k1[w] = m[w]; }
+    if (neg2) { uint32_t m[6] = {0, 0, 0, 0, 0, 0}; zl_addsub_words<6>(m, k2, true); for (int w = 0; w < 6; w++) k2[w] = m[w]; }
+    if (bad && (k1[4] | k1[5] | (k1[3] >> 31) | k2[4] | k2[5] | (k2[3] >> 31)) != 0u) atomicOr(bad, 2u);  // a half above 127 bits: cannot happen (see above); reported like a non-canonical scalar
+    if ((k1[0] | k1[1] | k1[2] | k1[3]) == 0) neg1 = 0;
+    if ((k2[0] | k2[1] | k2[2] | k2[3]) == 0) neg2 = 0;
+    uint4* o1 = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    uint4* o2 = reinterpret_cast<uint4*>(out + ((size_t)n + i) * 8);
+    o1[0] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
+    o1[1] = make_uint4(0, 0, 0, neg1 << 31);
+    o2[0] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
+    o2[1] = make_uint4(0, 0, 0, neg2 << 31);
+}
 // phib[i] = phi(P_i) = (beta x_i, y_i); the point at infinity (all-zero) stays itself
 template <class G>
 __global__ void __launch_bounds__(128) k_glv_phi(const Affine<typename G::F>* __restrict__ bases, uint32_t n, Affine<typename G::F>* __restrict__ phib) {

@@ -105,6 +105,12 @@ struct MsmJob {
         // call 39.2 -> 39.7 ms, pipelined 36.7 = 36.7), so large inputs keep the plain 255-bit windows.
         static const size_t glv_max = (size_t)1 << zl_tune("ZL_TUNE_GLV_MAX_LOG", 19);
         if constexpr (G::GLV) try_glv = phi_slot_ >= 0 && bs.precomp_c == 0 && !no_glv && n_ >= 1 && n_ <= glv_max && (uint64_t)n_ * G::ENDO_K < (1ull << 31);
+        // BN254 G1 (round 6: two-dimensional split, k_glv_split_lattice): its host Horner is cheap (254 doublings at 0.3 us) against the split's extra device work (2 n
+        // sort records, one more kernel), so between 2^13 and 2^17 points the plain windows are 3-4 % faster as a single call and 8 % pipelined -- BASELINE config 1's size
+        // among them -- while 2^10 (-15 %), 2^17 (-14 %) and 2^19 (-9 %) gain (profiles/r06_small_knobs2.log, r06_bn_glv_ab.log).  BLS12-381 never loses (same logs).
+        if constexpr (G::GLV && G::ENDO_K == 2) {
+            if (G::GLVP::LATTICE && n_ >= ((size_t)1 << 13) && n_ < ((size_t)1 << 17)) try_glv = false;
+        }
         int rc = plan_as(ctx, bs, first_, d_scalars, n_, try_glv);
         // (c <= 3: the top window of a 127-bit half-scalar can reach magnitude H + carry; not worth a special case)
         if (!rc && glv && c <= 3) rc = plan_as(ctx, bs, first_, d_scalars, n_, false);
@@ -148,7 +154,10 @@ struct MsmJob {
         // k_msm_merge for one WORKGROUP per bucket (k_msm_merge_big), which is meant for the few heavy buckets of a skewed input, not for all of them.  Round 6 found
         // the case in a sweep: a 2^14-point G2 MSM (GLS: 65 536 quarter-scalars, c = 11, 64 entries per bucket, 8-entry chunks) spent 3 of its 3.5 ms there --
         // slower than the 2^16-point MSM (1.4 ms).
-        while (ZL_CHUNK < (uint32_t)ZL_CHUNK_MAX && maxE / std::max<uint64_t>(1, (uint64_t)SETS * H) > (uint64_t)4 * ZL_CHUNK) ZL_CHUNK <<= 1;
+        // (Half-scalars of an endomorphism split fill only part of their top window's range -- |k_i| <= 0.67 * 2^127 on BLS12-381, 0.43 * 2^127 on BN254 -- so that
+        // window's buckets are 1.5-2.3x as dense as the average: counted double.  A 2^14-point G1 MSM, 32 entries per bucket on average and 8-entry chunks, sent a
+        // handful of its top window's buckets to k_msm_merge_big: 82 us of a 0.56-ms device chain, profiles/r06_timeline_msm_2_14_glv.txt.)
+        while (ZL_CHUNK < (uint32_t)ZL_CHUNK_MAX && (glv && G::ENDO_K == 2 ? 2u : 1u) * (maxE / std::max<uint64_t>(1, (uint64_t)SETS * H)) > (uint64_t)4 * ZL_CHUNK) ZL_CHUNK <<= 1;
         ZL_CHUNK = (uint32_t)std::max(8, zl_tune("ZL_TUNE_CHUNK", (int)ZL_CHUNK));
         nchunks = (uint32_t)((maxE + ZL_CHUNK - 1) / ZL_CHUNK);
         // bucket reduction (k_msm_reduce_level0 + k_msm_reduce_tree): blocks of 8 buckets (4 / 2 for smaller inputs: more lanes, shorter chains)
@@ -319,7 +328,10 @@ struct MsmJob {
             if ((rc = zl_scratch_get(ctx, slotA, s5tot, &p5))) return rc;
             d_vs = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(p5) + (s5tot - vs_bytes()));
             if constexpr (G::GLV && G::ENDO_K == 2) {
-                hipLaunchKernelGGL((k_glv_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
+                if constexpr (G::GLVP::LATTICE)
+                    hipLaunchKernelGGL((k_glv_split_lattice<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
+                else
+                    hipLaunchKernelGGL((k_glv_split<typename G::GLVP>), dim3((uint32_t)((n_real + 255) / 256)), dim3(256), 0, st, sc, (uint32_t)n_real, d_inf, d_vs, (int)G::SC_BITS, d_bad_scalar);
                 if (phi_owner)
                     hipLaunchKernelGGL((k_glv_phi<G>), dim3((uint32_t)((n_real + 127) / 128)), dim3(128), 0, st, d_bases, (uint32_t)n_real, const_cast<Affine<F>*>(d_phi));
             } else if constexpr (G::GLV && G::ENDO_K == 4) {
@@ -425,8 +437,8 @@ struct MsmJob {
         uint32_t* d_slice_counts = (uint32_t*)((unsigned char*)pd + (((size_t)n * W * 2 + 255) / 256) * 256);
         hipLaunchKernelGGL(k_msm_recode, dim3(nblk), dim3(256), 0, st, sc_eff, (uint32_t)n, c, W, spread_t, glv_i, d_digits, d_ones_list, d_ones_count, inf_eff, sc_bits, bad_eff);
         hipLaunchKernelGGL(k_msm_hist_lds, dim3(nslices, W), dim3(1024), (size_t)H * 4, st, d_digits, (uint32_t)n, H, per_slice, NB, d_slice_counts);
-        if (NB <= 16384 && nslices <= 64) {
-            hipLaunchKernelGGL(k_msm_prefix_small, dim3(1), dim3(1024), 0, st, d_slice_counts, NB, nslices, d_offsets, d_cursor, (const uint32_t*)d_bad_scalar);
+        if (NB <= 14336 && nslices <= 64) {  // (14 336 buckets: 59.6 KB of LDS for the totals beside the 4 KB of the scan)
+            hipLaunchKernelGGL(k_msm_prefix_small, dim3(1), dim3(1024), ((size_t)NB + NB / 16 + 16) * 4, st, d_slice_counts, NB, nslices, d_offsets, d_cursor, (const uint32_t*)d_bad_scalar);
         } else {
         hipLaunchKernelGGL(k_msm_slice_prefix, dim3((NB + 255) / 256), dim3(256), 0, st, d_slice_counts, NB, nslices, d_counts);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, st, d_counts, NB, d_block_sums);
@@ -458,10 +470,10 @@ struct MsmJob {
     }
     static constexpr bool pair_ok() { return G::COORDS == 2 && !std::is_void<typename PairBase<F>::type>::value; }  // an Fq2 group on 28-bit limbs: the lane-pair kernels exist
     int accumulate(zl_ctx* ctx, hipStream_t st) {
-        if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
+        if (pair_ok() && zl_tune("ZL_TUNE_G2_OCTET", 1) && nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 24576))  // Fq2 groups: eight lanes per chunk (zl_fq2pair.h)
             hipLaunchKernelGGL((k_msm_accumulate_pair<G, true>), dim3((nchunks + 7) / 8), dim3(64), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
-        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 49152))  // four lanes per chunk while that still fits the machine at three waves per SIMD
+        else if (nchunks <= (uint64_t)zl_tune("ZL_TUNE_QUAD_ACC_CHUNKS", 24576))  // four lanes per chunk while that is at most ~1.5 waves per SIMD (round 6: 49 152 -> 24 576; at three waves per SIMD the one-lane kernel is faster: 94 against 131 us at 2^14, profiles/r06_small_knobs2.log)
             hipLaunchKernelGGL((k_msm_accumulate_quad<G>), dim3((4 * nchunks + ZL_ACC_BLOCK - 1) / ZL_ACC_BLOCK), dim3(ZL_ACC_BLOCK), 0, st, d_entries, d_offsets, NB, d_bases, d_buckets, d_partials, ZL_CHUNK,
                                glv ? d_phi : d_bases, glv ? (uint32_t)n_real : 0xFFFFFFFFu);
         else if (pair_ok() && zl_tune("ZL_TUNE_G2_PAIR", 1))  // Fq2 groups: two lanes per chunk, two waves per SIMD (zl_fq2pair.h)

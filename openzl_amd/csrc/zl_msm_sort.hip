@@ -707,28 +707,34 @@ __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ block_
         if (flag_in) total_out[1] = *flag_in;
     }
 }
-// Small bucket counts (NB <= 16384): slice prefix + the three scan launches as ONE block of 1024 lanes, 16 consecutive buckets per lane.
+// Small bucket counts (NB <= 14336): slice prefix + the three scan launches as ONE block of 1024 lanes.
 // counts[slice][bucket] -> in-place exclusive prefix over slices; offsets[b] = cursor[b] = exclusive prefix over buckets; offsets[NB] = total,
 // offsets[NB + 1] = *flag_in (as k_scan_top).  Four dependent launches of a few microseconds each are what a small job's sort phase consists of.
+// Round 6: the slice walk runs with consecutive lanes on consecutive buckets (coalesced) and leaves the bucket totals in LDS, where the scan's 16
+// buckets per lane are read -- the first form gave every lane 16 consecutive buckets in GLOBAL memory (64-byte lane stride, 16 x nslices dependent
+// read-modify-writes per lane): 100 us at 12 288 buckets x 8 slices, a fifth of a 2^14-point MSM's device time (profiles/r06_timeline_msm_2_14_glv.txt).
+// LDS: NB + NB / 16 words (bucket b at b + b / 16: the stride of a lane's 16 buckets becomes 17 words, no bank conflicts).
 __global__ void __launch_bounds__(1024) k_msm_prefix_small(uint32_t* __restrict__ counts, uint32_t NB, uint32_t nslices, uint32_t* __restrict__ offsets,
                                                                   uint32_t* __restrict__ cursor, const uint32_t* __restrict__ flag_in) {
     ZL_SIDE_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tot = reinterpret_cast<uint32_t*>(smem);
     __shared__ uint32_t sh[1024];
+    for (uint32_t b = threadIdx.x; b < NB; b += 1024) {
+        uint32_t run = 0;
+        for (uint32_t sl = 0; sl < nslices; sl++) {
+            const uint32_t x = counts[(size_t)sl * NB + b];
+            counts[(size_t)sl * NB + b] = run;
+            run += x;
+        }
+        tot[b + (b >> 4)] = run;
+    }
+    __syncthreads();
     const uint32_t base = threadIdx.x * 16;
-    uint32_t v[16];
     uint32_t s = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        uint32_t run = 0;
-        if (base + k < NB)
-            for (uint32_t sl = 0; sl < nslices; sl++) {
-                const uint32_t x = counts[(size_t)sl * NB + base + k];
-                counts[(size_t)sl * NB + base + k] = run;
-                run += x;
-            }
-        v[k] = run;
-        s += run;
-    }
+    for (int k = 0; k < 16; k++)
+        if (base + k < NB) s += tot[threadIdx.x * 17 + k];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -739,9 +745,17 @@ __global__ void __launch_bounds__(1024) k_msm_prefix_small(uint32_t* __restrict_
     }
     uint32_t run = sh[threadIdx.x] - s;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if (base + k < NB) { offsets[base + k] = run; cursor[base + k] = run; }
-        run += v[k];
+    for (int k = 0; k < 16; k++)
+        if (base + k < NB) {
+            const uint32_t x = tot[threadIdx.x * 17 + k];
+            tot[threadIdx.x * 17 + k] = run;
+            run += x;
+        }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < NB; b += 1024) {
+        const uint32_t o = tot[b + (b >> 4)];
+        offsets[b] = o;
+        cursor[b] = o;
     }
     if (threadIdx.x == 1023) {
         offsets[NB] = sh[1023];

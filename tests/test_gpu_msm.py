@@ -513,6 +513,61 @@ def test_msm_glv_edge_scalars(backend):
         backend.bases_free(h)
 
 
+def test_msm_glv_edge_scalars_bn254(backend):
+    """BN254 G1 has the same endomorphism; r is not lambda^2 + lambda + 1 with a short lambda there, so the split is the two-dimensional lattice one
+    (csrc/zl_msm_endo.h k_glv_split_lattice, constants from tools/gen_bn254_glv.py).  Scalars on its decision boundaries -- multiples of lambda and of
+    the basis entries and their neighbours, 0, 1, r - 1, scalars in [r, 2^254) (reduced once) -- beside random ones, every sort path, single call and
+    pipelined batch, and every edge scalar alone, against the oracle."""
+    import torch
+
+    curve = po.BN254
+    r = curve.fr.p
+    lam = 0xB3C4D79D41A917585BFC41088D8DAAA78B17EA66B99C90DD
+    assert (lam * lam + lam + 1) % r == 0
+    a1, b1 = 9931322734385697763, 147946756881789319000765030803803410728  # |v1|; v2 = (b1 + a1, a1)
+    a2 = a1 + b1
+    assert (a1 - b1 * lam) % r == 0 and (a2 + a1 * lam) % r == 0
+    edge = [0, 1, 2, lam - 1, lam, lam + 1, r - 1, r - 2, r - lam, r - lam - 1, (r - 1) // 2, (r + 1) // 2, a1, a1 - 1, a1 + 1, b1, b1 - 1, b1 + 1, a2, a2 + 1, r - a1, r - b1,
+            r - a2, (b1 >> 1) * lam % r, ((b1 >> 1) + 1) * lam % r, (a1 >> 1) * lam % r, 3 * lam % r, lam * lam % r, (b1 >> 1), (b1 >> 1) + 1, (a2 >> 1), (a2 >> 1) + 1,
+            ((a2 >> 1) + (a1 >> 1) * lam) % r, ((a2 >> 1) + 1 + ((a1 >> 1) + 1) * lam) % r]
+    wide = [r, r + 1, r + lam % (2 ** 254 - r), 2 ** 254 - 1, 2 ** 254 - 2, r + a1, r + 12345]
+    assert all(r <= x < 2 ** 254 for x in wide)
+    n = 3000
+    S = ol.random_scalars(curve, n, 787)
+    S_red = S.copy()
+    S[: len(edge)] = ol.ints_to_limbs([e % r for e in edge], 4)
+    S_red[: len(edge)] = S[: len(edge)]
+    S[60:60 + len(wide)] = ol.ints_to_limbs(wide, 4)
+    S_red[60:60 + len(wide)] = ol.ints_to_limbs([x - r for x in wide], 4)
+    mults = [(j * lam + ((b1 >> 1) if j & 1 else 0)) % r for j in range(40)]
+    S[100:140] = ol.ints_to_limbs(mults, 4)
+    S_red[100:140] = S[100:140]
+    k, B = _bases(curve, n, 788)
+    h = backend.bases_upload(curve.cid, B)
+    exp, einf = ol.oracle_msm_g1(curve, B, S_red, algo=0, threads=4)
+    d_s = torch.from_numpy(S.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    try:
+        for c in (0, 7, 12, 15, 16, 18):
+            backend.set_msm_window(c)
+            got, inf = backend.msm_dev(h, d_s.data_ptr(), n)
+            assert inf == einf and (got == exp).all(), c
+        backend.set_msm_window(0)
+        parts = backend.msm_batch_partial_dev(h, [d_s.data_ptr()] * 4, n)
+        for j in range(4):
+            xy, pinf = backend.partials_sum(curve.cid, parts[j:j + 1])
+            assert pinf == einf and (xy == exp).all(), j
+        backend.set_msm_window(8)
+        for e in edge + wide:
+            s1 = ol.ints_to_limbs([e], 4)
+            got, inf = backend.msm(h, s1)
+            e1, i1 = ol.oracle_msm_g1(curve, B[:1], ol.ints_to_limbs([e % r], 4))
+            assert inf == i1 and (got == e1).all(), hex(e)
+    finally:
+        backend.set_msm_window(0)
+        backend.bases_free(h)
+
+
 def test_msm_scalars_between_r_and_2_255(backend):
     """ADVICE r3 (medium): scalars in [r, 2^255) pass the MODULUS_BITS check but are not canonical.  The plain path returns the sum mod r for them;
     the endomorphism splits (k_glv_split for G1, k_gls_split for G2; n <= 2^19) used to wrap (floor(k / lambda) > lambda + 1) and return a wrong point.
