@@ -348,13 +348,14 @@ static int msm_run_jobs_t(zl_ctx* ctx, const MsmSpec* specs, size_t count, uint6
                                 (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
             if (ok && jobs[i].hE[1]) { frc.store(ZL_EINVAL); ok = false; }  // non-canonical scalar (see msm_run_t)
             finishers.emplace_back([&, i, ok]() {
+                double values_us = 0;
                 if (ok) {
-                    const X total = jobs[i].finish(true);  // (concurrent callers of the host pool each take part in their own loop)
+                    const X total = jobs[i].finish(true, jtrace ? &values_us : nullptr);  // (concurrent callers of the host pool each take part in their own loop)
                     memset(out_partials + i * ZL_PARTIAL_WORDS, 0, ZL_PARTIAL_WORDS * 8);
                     memcpy(out_partials + i * ZL_PARTIAL_WORDS, &total, sizeof(X));
                 }
-                if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu Horner done at %.1f us\n", i,
-                                    (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3);
+                if (jtrace) fprintf(stderr, "[zl_msm jobs] job %zu Horner done at %.1f us (window values %.1f us, %u sets)\n", i,
+                                    (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - jt0).count() / 1e3, values_us, (unsigned)jobs[i].SETS);
                 {
                     std::unique_lock<std::mutex> lk(deliver_mu);
                     deliver_cv.wait(lk, [&] { return delivered == i; });

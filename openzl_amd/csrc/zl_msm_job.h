@@ -1,6 +1,7 @@
 // zl_msm_job.h -- one MSM as a plan over device buffers: window choice, buffer layout, and the launch sequences of its three phases
 // (sort | accumulate | tail) plus the host Horner.  The drivers in zl_msm.hip run one job, or pipeline several on three streams.
 #pragma once
+#include <chrono>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -31,6 +32,27 @@ static int zl_pick_window(size_t n, int sc_bits, bool wide16 = false /* c = 16 a
         if (cost < best) { best = cost; best_c = c; }
     }
     return best_c;
+}
+
+// The 127-bit half-scalars of an endomorphism split on G1 (2 n entries per window, half the windows): the cost model above is fitted on machine-filling sizes and misses
+// what decides a latency-bound MSM (which sort runs, chunk length, four-lane or one-lane kernels): at 2^18 points it picks c = 15 where c = 16 is 13 % faster, at 2^13 / 2^14
+// c = 10 / 11 where 11 / 12 are 8-10 % faster.  Measured best window by size, entries only where the gain is clear and survives inside a proof (profiles/r06_glv_window_sweep.log: every c in 9 .. 17
+// at 2^11 .. 2^19 points); 0 = outside the table, the model decides.
+static int zl_pick_window_half(size_t n_points) {
+    if (n_points < 2) return 0;
+    int lg = 63 - __builtin_clzll((unsigned long long)n_points);
+    if ((double)n_points >= 1.4142 * (double)((size_t)1 << lg)) lg++;  // nearest power of two
+    static const signed char best[9] = {9, 0, 11, 12, 0, 0, 0, 16, 0};  // 2^11 .. 2^19 points; 0 = the model (ties as single calls; c = 12 at 2^16 made a 57 000-constraint proof 8 % slower)
+    return lg >= 11 && lg <= 19 ? best[lg - 11] : 0;
+}
+// ... and the 64-bit quarter-scalars of the G2 split (4 n entries per window): the model's 11 at 2^13 / 2^14 where 12 / 13 are 8-10 % faster, 17 at 2^18 where 14 is 5 % faster
+// (profiles/r06_half_table_ab.log, "G2 window sweep": every c in 8 .. 16 at 2^10 .. 2^18 points)
+static int zl_pick_window_quarter(size_t n_points) {
+    if (n_points < 2) return 0;
+    int lg = 63 - __builtin_clzll((unsigned long long)n_points);
+    if ((double)n_points >= 1.4142 * (double)((size_t)1 << lg)) lg++;
+    static const signed char best[9] = {9, 0, 11, 12, 13, 13, 13, 13, 14};  // 2^10 .. 2^18 points (0: not measured, the model)
+    return lg >= 10 && lg <= 18 ? best[lg - 10] : 0;
 }
 
 static int zl_pick_window_precomp(size_t n, int sc_bits) {
@@ -130,6 +152,17 @@ struct MsmJob {
         bsp = &bs;
         pre = bs.precomp_c > 0;  // table of 2^(c w) P_i present: all windows share one bucket set
         c = pre ? bs.precomp_c : (ctx->msm_c > 0 ? ctx->msm_c : zl_pick_window(n, sc_bits, glv && G::ENDO_K != 2));
+        if (!pre && ctx->msm_c <= 0 && glv && zl_tune("ZL_TUNE_HALF_TABLE", 1)) {
+            int h = 0;
+            if constexpr (G::ENDO_K == 2) {
+                // (BN254: c = 16 at 2^18 is 11 % faster as a single call and 7 % SLOWER inside a 240 000-constraint proof, where four such MSMs and the witness map share
+                // the machine -- the table is BLS12-381's, profiles/r06_tables_mid_ab.log)
+                if (!G::GLVP::LATTICE) h = zl_pick_window_half(n_);
+            } else {
+                h = zl_pick_window_quarter(n_);
+            }
+            if (h) c = h;
+        }
         if (c < 2) c = 2;
         if (c > 24) c = 24;
         W = (sc_bits + 1 + c - 1) / c;
@@ -585,10 +618,12 @@ struct MsmJob {
         }
         return v;
     }
-    X finish(bool parallel = true) const {
+    X finish(bool parallel = true, double* values_us = nullptr) const {  // values_us (developer trace): time of stage 1
         std::vector<X> V(SETS);
+        const auto t0 = std::chrono::steady_clock::now();
         if (parallel && SETS >= 4) zl_pool_get().parallel_for(SETS, [&](size_t w) { V[w] = window_value((int)w); });
         else for (uint32_t w = 0; w < SETS; w++) V[w] = window_value((int)w);
+        if (values_us) *values_us = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() / 1e3;
         X total = V[SETS - 1];
         for (int w = (int)SETS - 2; w >= 0; w--) {
             zl::dbl_n(total, c);  // c doublings in Jacobian coordinates

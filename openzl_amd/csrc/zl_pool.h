@@ -23,6 +23,9 @@ public:
         for (auto& t : th_) t.join();
     }
     // f(0) .. f(n - 1), each exactly once, on the workers and the caller; returns when all are done
+    // (Several callers at once -- the completion threads of a proof's MSMs finish side by side -- each post their own job: the workers take tasks from
+    // whichever posted job still has some.  Round 6: there was ONE job slot, so a second caller's job displaced the first one's and each caller ran most of
+    // its own loop alone.)
     void parallel_for(size_t n, const std::function<void(size_t)>& f) {
         if (n == 0) return;
         if (n == 1 || th_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
@@ -32,14 +35,14 @@ public:
         job->left.store(n, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = job;
-            gen_++;
+            jobs_.push_back(job);
         }
         cv_.notify_all();
         work(*job);
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&]() { return job->left.load(std::memory_order_acquire) == 0; });
-        if (job_ == job) job_.reset();
+        for (size_t i = 0; i < jobs_.size(); i++)
+            if (jobs_[i] == job) { jobs_.erase(jobs_.begin() + (long)i); break; }
     }
 
 private:
@@ -60,15 +63,17 @@ private:
         }
     }
     void loop() {
-        uint64_t seen = 0;
         for (;;) {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&]() { return stop_ || (gen_ != seen && job_); });
+                cv_.wait(lk, [&]() {
+                    if (stop_) return true;
+                    for (auto& x : jobs_)
+                        if (x->next.load(std::memory_order_relaxed) < x->n) { j = x; return true; }
+                    return false;
+                });
                 if (stop_) return;
-                seen = gen_;
-                j = job_;
             }
             work(*j);
         }
@@ -76,8 +81,7 @@ private:
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_, done_;
-    std::shared_ptr<Job> job_;
-    uint64_t gen_ = 0;
+    std::vector<std::shared_ptr<Job>> jobs_;  // posted and not yet completed
     bool stop_ = false;
 };
 zl_pool& zl_pool_get();

@@ -123,6 +123,16 @@ def test_rust_ffi_matches_header():
         assert called in rust_fns, called
 
 
+def test_host_pool_serves_concurrent_callers(tmp_path):
+    """csrc/zl_pool.h: one job per concurrent caller (round 6; it had one job slot, a second caller displaced the first one's job)"""
+    import subprocess
+
+    exe = tmp_path / "pool_stress"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "openzl_amd", "csrc"), os.path.join(ROOT, "tests", "c", "pool_stress.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "bad = 0" in out.stdout, (out.stdout, out.stderr)
+
+
 def _build_inmemory_key(tmp_path):
     import subprocess
 
