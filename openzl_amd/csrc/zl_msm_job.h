@@ -18,10 +18,13 @@
 // developer tuning knobs (profiling sweeps only; unset in production): ZL_TUNE_CHUNK, ZL_TUNE_SEG, ZL_TUNE_FS, ZL_TUNE_RANGES (zl_tune, zl_ctx.h)
 static int zl_pick_window(size_t n, int sc_bits, bool wide16 = false /* c = 16 also runs the three-level sort (GLV jobs) */) {
     // cost in accumulated entries: n per window (+10 % for c <= 16: the one-level LDS counting sort streams every window's digits once per
-    // bucket range and is the slower sort at large n) + ~5.7 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
-    // single-call times at 2^20 .. 2^24, both curves (profiles/r02_msm_sweep_plain.log, r02_msm_sweep_bn254.log): picks 16 up to 2^21,
-    // 18 at 2^22 - 2^23, 19 at 2^24.  c = 17..20 run the three-level sort over W bucket sets (<= 255 sort groups).
-    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", 52) / 10.0;
+    // bucket range and is the slower sort at large n) + ~4.5 per bucket (merge of cut buckets, level-0 running sums, tree).  Fitted on
+    // single-call times at 2^20 .. 2^24, both curves (profiles/r02_msm_sweep_plain.log, r02_msm_sweep_bn254.log), refitted in round 6 (below).  c = 17..20 run the three-level sort over W bucket sets (<= 255 sort groups).
+    // (Round 6: 5.7 -> 5.2 with the merge by chunk boundaries, then 4.5: pipelined sweeps of every window at 2^21 .. 2^23 (profiles/r06_window_sweep_2_21_23.log) have 18 ahead of 17 at
+    // 2^22 by 1.7 % and 19 ahead of 18 at 2^23 by 4 % -- c = 18 is 15 windows with a nearly empty top one, c = 19 is 14 -- and one constant below 4.6 fits all of 2^20: 16, 2^21: 17, 2^22: 18,
+    // 2^23: 19, 2^24: 20.)
+    // Split scalars (sc_bits 127 / 64) keep 5.2: at 4.5 BN254's 2^18 moves to c = 16, which is faster alone and 7 % slower inside a proof (zl_pick_window_half below).
+    const double per_bucket = (double)zl_tune("ZL_TUNE_BUCKET_COST_X10", sc_bits > 200 ? 45 : 52) / 10.0;
     double best = 1e300;
     int best_c = 2;
     for (int c = 2; c <= 20; c++) {
