@@ -292,5 +292,6 @@ ZL_DECL_GROUP(BnG2)
      : ((curve) == ZL_BN254 && (group) == ZL_G2)     ? fn##_BnG2(__VA_ARGS__)                \
                                                      : (int)ZL_EINVAL)
 int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags);
+int zl_ntt_run_batch(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags, unsigned count, size_t stride_bytes);  // `count` equal transforms, one launch per pass
 int zl_ntt_cross_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags);
 void zl_ntt_free(zl_ctx* ctx);

@@ -414,9 +414,18 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         }
         if (hipGetLastError() != hipSuccess) return fail(ZL_EHIP);
         int r;
-        for (int m = 0; m < 3; m++) {
-            if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) return fail(r);
-            if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) return fail(r);
+        // a, b, c go through their inverse transform and their coset transform three at a time (one launch per pass, grid.y = vector): a transform of <= 2^16 elements
+        // is a chain of passes of ~20 us each whatever its size (16 workgroups at 2^14), so six of the witness map's seven transforms cost the latency of two
+        // (interleaved A/B, profiles/r06_ntt_batch_ab.log: 1 882 constraints 1.00 -> 0.86 ms, 14 977: 1.58 -> 1.45 (BN254 1.25 -> 1.10), 2^16 - 2^18: -2 %; at 2^20 the passes fill
+        // the machine and three at a time is 1-2 % SLOWER beside the G2 accumulation: domains up to 2^18 only)
+        if (off_c - off_b == off_b - off_a && log_n <= (unsigned)zl_tune("ZL_TUNE_NTT_BATCH_LOG_N", 18)) {
+            if ((r = zl_ntt_run_batch(wm, pk->curve, d_a, log_n, ZL_MONT | ZL_INVERSE, 3, off_b - off_a))) return fail(r);
+            if ((r = zl_ntt_run_batch(wm, pk->curve, d_a, log_n, ZL_MONT | ZL_COSET, 3, off_b - off_a))) return fail(r);
+        } else {
+            for (int m = 0; m < 3; m++) {
+                if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_INVERSE))) return fail(r);
+                if ((r = zl_ntt_run(wm, pk->curve, dv[m], log_n, ZL_MONT | ZL_COSET))) return fail(r);
+            }
         }
         Fr g;
         for (int i = 0; i < Fr::N; i++) g.l[i] = FrP::generator(i);
@@ -512,6 +521,9 @@ static int groth16_prove_t(zl_ctx* ctx, const zl_g16_pk* pk, const zl_r1cs_dev* 
         const int curve = pk->curve;
         uint64_t* out2 = part[4];
         zl_worker& g2 = zl_ctx_worker(ctx, 1);
+        // (Tried: every MSM of a folded proof behind the witness map, so that the accumulations do not sit on the SIMDs its short passes need -- slower at every size, 235 constraints
+        // 0.67 -> 0.74, 14 977: 1.58 -> 1.61 (profiles/r06_gate_ab.log): a 2^14 transform is two passes of ~20 us on 16 workgroups whether or not the machine is busy.  What helped
+        // is running a, b, c through each transform in one launch, above.)
         g2.run([&, aux, b2, curve, out2]() {
             if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ev_z, 0) != hipSuccess) { rc_g2 = ZL_EHIP; return; }
             rc_g2 = ZL_DISPATCH(curve, ZL_G2, zl_msm_run, aux, *b2, 1, zc + 32, nv - 1, out2);

@@ -43,6 +43,7 @@ struct NttArgs {
     const void* row_tw;       // middle pass (lazy form): w_N^((r K0(hi)) << shift) for every (hi, r), hi = the tile's high index (or null: combined per tile)
     const void* last_tw;      // last pass of a multi-pass transform: the complete inter-factor twiddle of every element, in load order (or null)
     uint32_t ninv[8];
+    uint64_t in_batch, out_batch;  // bytes between the vectors of a batch (blockIdx.y = vector): equal-size transforms of one launch (Groth16's witness map: three at a time)
 };
 
 template <class F>
@@ -87,6 +88,8 @@ __device__ __forceinline__ F twiddle2(const F* lo, const F* hi, uint32_t L, uint
 template <class FrP, bool LAST>
 __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_pass(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
     using F = Fp<FrP>;
+    in = reinterpret_cast<const Fp<FrP>*>(reinterpret_cast<const unsigned char*>(in) + (size_t)blockIdx.y * a.in_batch);
+    out = reinterpret_cast<Fp<FrP>*>(reinterpret_cast<unsigned char*>(out) + (size_t)blockIdx.y * a.out_batch);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                       // [8][NTT_TILE]
     const uint32_t tid = threadIdx.x;
@@ -417,6 +420,8 @@ __device__ __forceinline__ Fr28<P28> const28(WordsFn f) {
 template <class FrP, bool LAST, int MINB = 2>
 __global__ void __launch_bounds__(NTT28_THREADS, MINB) k_ntt_pass28(const Fp<FrP>* __restrict__ in, Fp<FrP>* __restrict__ out, NttArgs a) {
     using P28 = typename Fr28Of<FrP>::type;
+    in = reinterpret_cast<const Fp<FrP>*>(reinterpret_cast<const unsigned char*>(in) + (size_t)blockIdx.y * a.in_batch);
+    out = reinterpret_cast<Fp<FrP>*>(reinterpret_cast<unsigned char*>(out) + (size_t)blockIdx.y * a.out_batch);
     using E = Fr28<P28>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* sh = reinterpret_cast<uint32_t*>(smem);                          // [L][NTT28_TILE]
@@ -800,7 +805,8 @@ static int ntt_tables(zl_ctx* ctx, int curve, unsigned n, bool inverse, zl_twidd
 }
 
 template <class FrP>
-static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned flags) {
+// count > 1: `count` equal-size transforms with the same flags, vector v at d_data + v * stride_bytes, in ONE launch per pass (grid.y = count)
+static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned flags, unsigned count = 1, size_t stride_bytes = 0) {
     using F = Fp<FrP>;
     if (n > (unsigned)FrP::TWO_ADICITY || n > 30) return ZL_EINVAL;
     const bool inverse = flags & ZL_INVERSE, coset = flags & ZL_COSET;
@@ -823,7 +829,7 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
     F* scratch = nullptr;
     if (pl.P > 1) {
         void* p;
-        if ((rc = zl_scratch_get(ctx, 6, N * (lazy ? ScratchBytes<typename Fr28Of<FrP>::type>::value : sizeof(F)), &p))) return rc;  // lazy passes: the limbs as they are between passes
+        if ((rc = zl_scratch_get(ctx, 6, (size_t)count * N * (lazy ? ScratchBytes<typename Fr28Of<FrP>::type>::value : sizeof(F)), &p))) return rc;  // lazy passes: the limbs as they are between passes
         scratch = reinterpret_cast<F*>(p);
     }
     const unsigned L = tw->lo_bits;
@@ -962,21 +968,24 @@ static int ntt_run_t(zl_ctx* ctx, int curve, void* d_data, unsigned n, unsigned 
         const uint64_t tiles = (uint64_t)N >> (a.s + logC);
         const F* src = (p == 1) ? data : scratch;
         F* dst = last ? data : scratch;
+        const size_t scratch_vec = N * (lazy ? ScratchBytes<typename Fr28Of<FrP>::type>::value : sizeof(F));
+        a.in_batch = (p == 1) ? stride_bytes : scratch_vec;
+        a.out_batch = last ? stride_bytes : scratch_vec;
         if (lazy) {
             // tile + butterfly roots (+ the per-row twiddles of a middle pass that has no row table): 45 KB at s = 8 -> three workgroups per CU
             using E28 = Fr28<typename Fr28Of<FrP>::type>;
             const size_t lds28 = (size_t)E28::L * 4 * NTT28_TILE + sizeof(E28) * ((a.w_unpacked ? 0 : ((size_t)1 << a.s) / 2) + ((!last && p > 1 && !a.row_tw) ? ((size_t)1 << a.s) : 0));
             if (ctx->ntt_fit_beside && NTT28_THREADS == 256) {
-                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 5>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
-                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 5>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 5>), dim3((uint32_t)tiles, count), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 5>), dim3((uint32_t)tiles, count), dim3(NTT28_THREADS), lds28, st, src, dst, a);
             } else {
-                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 2>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
-                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 2>), dim3((uint32_t)tiles), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                if (last) hipLaunchKernelGGL((k_ntt_pass28<FrP, true, 2>), dim3((uint32_t)tiles, count), dim3(NTT28_THREADS), lds28, st, src, dst, a);
+                else hipLaunchKernelGGL((k_ntt_pass28<FrP, false, 2>), dim3((uint32_t)tiles, count), dim3(NTT28_THREADS), lds28, st, src, dst, a);
             }
         } else {
         const size_t lds = (size_t)F::N * 4 * NTT_TILE + sizeof(F) * (((size_t)1 << a.s) / 2 + ((size_t)1 << a.s));
-        if (last) hipLaunchKernelGGL((k_ntt_pass<FrP, true>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
-        else hipLaunchKernelGGL((k_ntt_pass<FrP, false>), dim3((uint32_t)tiles), dim3(NTT_THREADS), lds, st, src, dst, a);
+        if (last) hipLaunchKernelGGL((k_ntt_pass<FrP, true>), dim3((uint32_t)tiles, count), dim3(NTT_THREADS), lds, st, src, dst, a);
+        else hipLaunchKernelGGL((k_ntt_pass<FrP, false>), dim3((uint32_t)tiles, count), dim3(NTT_THREADS), lds, st, src, dst, a);
         }
         S_prev += a.s;
     }
@@ -1139,6 +1148,13 @@ int zl_ntt_cross_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsig
     return ZL_EINVAL;
 }
 
+int zl_ntt_run_batch(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags, unsigned count, size_t stride_bytes) {
+    if (count == 0) return ZL_OK;
+    if (count > 65535 || (count > 1 && stride_bytes < ((size_t)32 << log_n))) return ZL_EINVAL;
+    if (curve == ZL_BLS12_381) return ntt_run_t<BLS12_381_Fr>(ctx, curve, d_data, log_n, flags, count, stride_bytes);
+    if (curve == ZL_BN254) return ntt_run_t<BN254_Fr>(ctx, curve, d_data, log_n, flags, count, stride_bytes);
+    return ZL_EINVAL;
+}
 int zl_ntt_run(zl_ctx* ctx, int curve, void* d_data, unsigned log_n, unsigned flags) {
     if (curve == ZL_BLS12_381) return ntt_run_t<BLS12_381_Fr>(ctx, curve, d_data, log_n, flags);
     if (curve == ZL_BN254) return ntt_run_t<BN254_Fr>(ctx, curve, d_data, log_n, flags);
