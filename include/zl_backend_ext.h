@@ -48,6 +48,10 @@ int zl_partial_from_affine(zl_curve_t curve, zl_group_t group, const uint64_t* x
  * Montgomery between the legs (ZL_MONT_IN / ZL_MONT_OUT pick the outer representation).  1 <= log_g <= 4, 2*log_g <= log_n.
  * openzl_amd/sharded.py drives the three steps over torch.distributed (RCCL all_to_all_single). */
 int zl_ntt_cross_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags);
+/* `count` transforms of the same size and flags in one launch per pass: vector v starts at d_data + v * stride_elems elements (stride_elems >= 2^log_n).  What the
+ * Groth16 witness map does with its a, b, c vectors (groth16.rs:445-457 -> ark-groth16's witness map: three iffts, three coset ffts): below ~2^16 elements a transform
+ * is a chain of latency-bound passes, and three of them cost what one does.  Results are those of `count` zl_ntt_dev calls. */
+int zl_ntt_batch_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags, unsigned count, size_t stride_elems);
 
 /* ---- multi-GPU in one process: G devices, one zl_ctx each, RCCL (ncclCommInitAll) between them ------------------
  * Upload / generate / precompute every rank's shard of the bases on ITS ctx (zl_mctx_ctx(m, rank)) with the single-device calls above.

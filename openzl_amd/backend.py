@@ -25,7 +25,7 @@ u8p = C.POINTER(C.c_uint8)
 ABI_SYMBOLS = [
     "zl_ctx_create", "zl_ctx_destroy", "zl_ctx_fork", "zl_ctx_set_stream", "zl_ctx_sync", "zl_ctx_set_msm_window", "zl_ctx_last_hip_error",
     "zl_strerror", "zl_describe", "zl_bases_upload", "zl_bases_generate", "zl_bases_download", "zl_bases_precompute", "zl_bases_free", "zl_msm",
-    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_poseidon_chain_witness", "zl_circuit_free", "zl_circuit_export",
+    "zl_msm_dev", "zl_msm_partial_dev", "zl_msm_batch_partial_dev", "zl_partials_sum", "zl_partial_from_affine", "zl_ntt", "zl_ntt_dev", "zl_ntt_batch_dev", "zl_ntt_cross_dev", "zl_ctx_enable_timing", "zl_last_timing", "zl_groth16_prove", "zl_groth16_last_h", "zl_r1cs_upload", "zl_r1cs_free", "zl_groth16_prove_resident", "zl_groth16_prove_sharded", "zl_circuit_poseidon_chain", "zl_circuit_poseidon_chain_witness", "zl_circuit_free", "zl_circuit_export",
     "zl_circuit_is_satisfied", "zl_poseidon_permute", "zl_groth16_compile", "zl_groth16_keys_free", "zl_groth16_keys_pk",
     "zl_groth16_keys_trapdoor", "zl_groth16_prove_circuit", "zl_groth16_prove_circuits", "zl_ctx_drop_lanes", "zl_groth16_verify", "zl_pairing",
     "zl_ctx_create_multi", "zl_mctx_destroy", "zl_mctx_size", "zl_mctx_ctx", "zl_mctx_uses_rccl", "zl_mctx_last_rccl_error", "zl_msm_sharded", "zl_ntt_sharded",
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None):
     L.zl_ntt.argtypes = [vp, C.c_int, u64p, C.c_uint, C.c_uint]
     L.zl_ntt_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint]
     L.zl_ntt_cross_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    L.zl_ntt_batch_dev.argtypes = [vp, C.c_int, vp, C.c_uint, C.c_uint, C.c_uint, C.c_size_t]
     L.zl_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.zl_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.zl_groth16_prove.argtypes = [vp, C.POINTER(G16PkC), C.POINTER(R1csC), u64p, u64p, u64p, C.POINTER(G16ProofC)]
@@ -333,6 +334,10 @@ class Backend:
     def ntt_dev_flags(self, curve: int, d_data: int, log_n: int, flags: int):
         """zl_ntt_dev with raw flags (ZL_MONT_IN / ZL_MONT_OUT legs of the distributed transform)."""
         self._check(self.L.zl_ntt_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags), "zl_ntt_dev")
+
+    def ntt_batch_dev(self, curve: int, d_data: int, log_n: int, flags: int, count: int, stride_elems: int):
+        """`count` equal transforms, one launch per pass (include/zl_backend_ext.h: zl_ntt_batch_dev)."""
+        self._check(self.L.zl_ntt_batch_dev(self._ctx, curve, C.c_void_p(d_data), log_n, flags, count, stride_elems), "zl_ntt_batch_dev")
 
     def ntt_cross_dev(self, curve: int, d_data: int, log_n: int, log_g: int, rank: int, flags: int):
         """Cross-rank step of the distributed transform (include/zl_backend.h: zl_ntt_cross_dev)."""

@@ -428,6 +428,14 @@ int zl_ntt_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsi
     ZL_HIP(ctx, hipSetDevice(ctx->device));
     return zl_ntt_run(ctx, curve, d_data, log_n, flags);
 }
+int zl_ntt_batch_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned flags, unsigned count, size_t stride_elems) {
+    if (!ctx || !d_data) return ZL_EINVAL;
+    if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;
+    if (flags & ~(ZL_MONT | ZL_COSET | ZL_INVERSE | ZL_MONT_IN | ZL_MONT_OUT)) return ZL_EINVAL;
+    if (log_n > 30 || count > 65535 || (count > 1 && stride_elems < ((size_t)1 << log_n))) return ZL_EINVAL;
+    ZL_HIP(ctx, hipSetDevice(ctx->device));
+    return zl_ntt_run_batch(ctx, curve, d_data, log_n, flags, count, stride_elems * 32);
+}
 int zl_ntt_cross_dev(zl_ctx* ctx, zl_curve_t curve, void* d_data, unsigned log_n, unsigned log_g, unsigned rank, unsigned flags) {
     if (!ctx || !d_data) return ZL_EINVAL;
     if (curve != ZL_BLS12_381 && curve != ZL_BN254) return ZL_EINVAL;

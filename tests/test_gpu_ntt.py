@@ -96,3 +96,26 @@ def test_ntt_four_pass_sizes_roundtrip_and_spot_checks(backend, coset):
         for cf in reversed(coeffs):
             acc = (acc * pt + cf) % r
         assert ol.limbs_to_ints(X2[k:k + 1])[0] == acc, k
+
+
+@pytest.mark.parametrize("curve", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n", [1, 8, 11, 14, 17, 20])  # one, two and three passes (17: a middle pass with its row table)
+def test_ntt_batch_equals_single_transforms(backend, curve, log_n):
+    """zl_ntt_batch_dev (Groth16's witness map: a, b, c through each transform in one launch per pass) = the same transforms one at a time, for every
+    variant, with a stride larger than the vectors (the gaps must stay untouched)"""
+    import torch
+    from openzl_amd.backend import ZL_COSET, ZL_INVERSE, ZL_MONT
+
+    n = 1 << log_n
+    count, stride = 3, n + 8
+    x = ol.random_scalars(curve, count * stride, 4000 + log_n)
+    for flags in (ZL_MONT, ZL_MONT | ZL_INVERSE, ZL_MONT | ZL_COSET, ZL_MONT | ZL_INVERSE | ZL_COSET, 0):
+        d_b = torch.from_numpy(x.view(np.int64).copy()).cuda()
+        d_s = torch.from_numpy(x.view(np.int64).copy()).cuda()
+        backend.ntt_batch_dev(curve.cid, d_b.data_ptr(), log_n, flags, count, stride)
+        for v in range(count):
+            backend.ntt_dev_flags(curve.cid, d_s.data_ptr() + v * stride * 32, log_n, flags)
+        torch.cuda.synchronize()
+        assert torch.equal(d_b, d_s), flags
+        gaps = d_b.cpu().numpy().view(np.uint64).reshape(count, stride, 4)[:, n:, :]
+        assert (gaps == x.reshape(count, stride, 4)[:, n:, :]).all()
